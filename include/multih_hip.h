@@ -1,0 +1,150 @@
+/* multih_hip.h — C ABI of the MI355X-native Multi-H hot-path engine.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * C++/torch types, status codes instead of exceptions.  The reference has no
+ * FFI — its boundary is the C++ class `MultiH` (M/MultiH.h:20-149, "M/" =
+ * /root/reference/MultiH/MultiH/).  `multi-h_amd/host/MultiH.{h,cpp}` re-creates
+ * that class on top of these entry points; INTEGRATION.md shows the binding a
+ * reference maintainer would add.  Each entry point cites the reference code
+ * whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - all pointers are HOST pointers unless a name ends in `_dev`;
+ *   - homographies are 9 doubles, row-major (cv::Mat 3x3 CV_64F `.data`);
+ *   - labels at this boundary: -1 = outlier, 0..Nh-1 = plane (M/MultiH.cpp:547-568);
+ *   - every function returns MH_OK (0) or a negative MH_ERR_*; mh_last_error()
+ *     gives the message of the calling thread's last failure;
+ *   - an engine is used from one thread at a time (as the reference class is);
+ *   - the engine fails loudly (MH_ERR_NO_DEVICE) when no gfx950 device is
+ *     usable: there is NO CPU fallback anywhere behind this header.
+ */
+#ifndef MULTIH_HIP_H
+#define MULTIH_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_ABI_VERSION 1
+
+/* exported even when the library is built with -fvisibility=hidden */
+#if defined(__GNUC__) || defined(__clang__)
+#define MH_API __attribute__((visibility("default")))
+#else
+#define MH_API
+#endif
+
+enum {
+    MH_OK = 0,
+    MH_ERR_NO_DEVICE = -1,   /* no HIP device / wrong arch */
+    MH_ERR_INVALID = -2,     /* bad argument or call order */
+    MH_ERR_HIP = -3,         /* a HIP runtime call failed */
+    MH_ERR_NOT_SET = -4,     /* required input (points, F, neighbours, models) missing */
+    MH_ERR_OVERFLOW = -5     /* an int32 energy of the reference's type would overflow */
+};
+
+typedef struct mh_engine mh_engine;
+
+/* ---- library ---------------------------------------------------------- */
+MH_API int mh_abi_version(void);
+MH_API const char* mh_last_error(void);
+MH_API int mh_device_count(void);              /* number of visible HIP devices (0 if none) */
+
+/* ---- lifetime / parameters -------------------------------------------- */
+/* MultiH::MultiH, M/MultiH.h:49-53 + M/MultiH.cpp:10-21.  One HIP stream per engine. */
+MH_API int mh_create(mh_engine** out, int device);
+MH_API void mh_destroy(mh_engine* e);
+/* thr_F, thr_H, locality, lambda, min_inliers: the ctor arguments (defaults 3.0, 2.5, 0.002, 0.5, 0). */
+MH_API int mh_set_params(mh_engine* e, double thr_fund_mat, double thr_hom, double locality,
+                  double lambda, int min_inliers);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the engine's own. */
+MH_API int mh_set_stream(mh_engine* e, void* hip_stream);
+MH_API int mh_synchronize(mh_engine* e);
+
+/* ---- inputs ------------------------------------------------------------ */
+/* Correspondences as the reference holds them after filtering: src_points, dst_points
+ * (vector<cv::Point2d> -> n x 2 doubles each) and affinities (2x2 CV_64F -> n x 4 doubles,
+ * order a11 a12 a21 a22, M/MultiH.cpp:928-931).  affines may be NULL if re-estimation is
+ * not used.  Stored in HBM as struct-of-arrays. */
+MH_API int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst_xy,
+                           const double* affines, int n);
+/* fundamental_matrix (row-major 9) and epipole_2 (x, y with third coordinate 1),
+ * the members GetFundamentalMatrixAndRefineData computes (M/MultiH.cpp:775-799). */
+MH_API int mh_set_epipolar(mh_engine* e, const double F[9], const double e2[2]);
+/* `neighbours` of ClusterMergingAndLabeling (M/MultiH.cpp:252-253) as a DIRECTED hit list in
+ * CSR form: row i lists the trainIdx hits of query i (self hits allowed; skipped as in
+ * M/MultiH.cpp:537).  Multiplicity semantics of setNeighbors are reproduced (SURVEY A-2). */
+MH_API int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col, int n);
+/* Exact k-NN hit list built on the GPU in float32 (x1,y1,x2,y2) space — the engine's own
+ * replacement for the FLANN radius search (deviation documented). */
+MH_API int mh_build_neighbors_knn(mh_engine* e, int k);
+/* Copy the symmetric weighted graph the engine derived (rowptr n+1, col/w nnz).  Pass NULLs to
+ * query nnz only. */
+MH_API int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz);
+
+/* ---- propose: hypothesis batch ----------------------------------------- */
+/* Sample `m` 4-tuples with the counter RNG (seed, first..first+m-1) and solve the normalised
+ * 4-point DLT for each on the GPU (north_star; stands where the reference calls
+ * cv::findHomography: M/MultiH.cpp:725, M/MultipleHomographies.h:144,339).  The batch stays
+ * resident in HBM as the engine's current model set. */
+MH_API int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int m);
+/* Upload an explicit model set (m x 9) as the current model set. */
+MH_API int mh_set_models(mh_engine* e, const double* H, int m);
+MH_API int mh_get_models(mh_engine* e, double* H /* m x 9 */);
+MH_API int mh_get_model_count(mh_engine* e, int* m);
+MH_API int mh_get_samples(mh_engine* e, int* idx /* m x 4, valid after mh_propose_dlt4 */);
+
+/* ---- score -------------------------------------------------------------- */
+/* Inlier count of every current model over all points, forward transfer error, strict
+ * d2 < thr2 (M/MultiH.cpp:430-443).  point_mask (n bytes, nullable) restricts the count to
+ * points with mask != 0.  counts (m ints, nullable) receives a host copy; the counts also
+ * stay resident (mh_device_buffer MH_BUF_COUNTS). */
+MH_API int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* counts);
+/* The N x M residual matrix of north_star, model-major: R[m*n + i] = d2(point i, model m),
+ * written to HBM by one kernel that also produces the inlier counts.  R_host (nullable)
+ * receives a host copy — leave NULL to keep the matrix on the device only. */
+MH_API int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts);
+/* Label points with the single model idx where inlier (ComputeInliersOfHomography,
+ * M/MultiH.cpp:743-768): labels[i] = label_value if d2 < thr2, else unchanged. */
+MH_API int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int* labels /* in/out n */);
+/* Per-model inlier moments {n, Sx, Sy, Sxx, Sxy, Syy} and smallest eigenvalue of the 3x3
+ * scatter — the collinearity test of MergingStep (M/MultiH.cpp:446-463). */
+MH_API int mh_inlier_moments(mh_engine* e, double thr2, double* moments /* m x 6 */, double* min_eig /* m */);
+
+/* ---- label --------------------------------------------------------------- */
+/* dataEnergy (M/MultiH.cpp:473-504) for every (site, label): cost[i*(Nh+1)+l], int32, label 0 =
+ * outlier, l>=1 = current model l-1.  cost (nullable) receives a host copy. */
+MH_API int mh_data_cost(mh_engine* e, int* cost);
+/* alpha-expansion over the current data cost and neighbour graph with the Potts term
+ * round(100*lambda) (M/MultiH.cpp:506-511; GCoptimization.cpp:975-1058,1212-1289).
+ * labels: in = initial labeling in GCO numbering 0..Nh (NULL = all zero), out = result in GCO
+ * numbering.  energy: final int32 energy; cycles: executed cycles. */
+MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy, int* cycles);
+/* GetHomographyHAFNonminimal for every label (M/MultiH.cpp:913-989 + the 1/lambda rescale of
+ * Homography_RefineHAFCallback.h:33-34).  labels: -1..Nh-1 per point.  Updates the current
+ * model set in place; H_out (nullable) receives a host copy. */
+MH_API int mh_reestimate(mh_engine* e, const int* labels, double* H_out);
+/* LabelingStep (M/MultiH.cpp:513-602): data cost -> expansion (warm start iff warm != 0, from
+ * `labeling` + 1) -> labels - 1 -> re-estimation.  labeling: in/out n ints (-1..Nh-1). */
+MH_API int mh_labeling_step(mh_engine* e, int warm, int* labeling, double* energy, int* cycles);
+
+/* ---- device-side access (bench / multi-GPU plumbing) --------------------- */
+enum { MH_BUF_COUNTS = 0, MH_BUF_MODELS = 1, MH_BUF_RESIDUALS = 2, MH_BUF_LABELS = 3, MH_BUF_COST = 4 };
+/* Device pointer and size in bytes of a resident buffer (valid until the next call that
+ * re-allocates it).  Used to wrap the per-model scores in a tensor for the RCCL all-gather. */
+MH_API int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long* bytes);
+
+/* Per-kernel HIP-event timing on the engine's stream.  When enabled every launch of the
+ * instrumented kernels is bracketed by events; stats are resolved at the next synchronize. */
+enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K_EXPAND = 4,
+       MH_K_REESTIMATE = 5, MH_K_COUNT_ = 6 };
+MH_API int mh_profile_enable(mh_engine* e, int on);
+MH_API int mh_profile_reset(mh_engine* e);
+MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);
+/* Selects a tuning variant of the residual kernel (bench sweeps); 0 = default. */
+MH_API int mh_set_tuning(mh_engine* e, int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTIH_HIP_H */

@@ -1,0 +1,97 @@
+"""In-tree build of the gfx950 engine: multi-h_amd/libmultih_hip.so (C ABI,
+include/multih_hip.h) and the C++ host layer multi-h_amd/libmultih_host.so
+(class MultiH over the C ABI) plus its harness binary.
+
+hipcc cross-compiles without a GPU; the .so files are git-ignored but travel to
+the GPU box with the gpurun snapshot.  -ffp-contract=off is part of the
+numerical contract (every FP64 operation rounds once, like the reference's
+scalar C++ built by MSVC /fp:precise or g++ -ffp-contract=off)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libmultih_hip.so")
+HOST_LIB = os.path.join(HERE, "libmultih_host.so")
+HARNESS = os.path.join(HERE, "multih_harness")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+KERNEL_SOURCES = ["residual.hip", "dlt4.hip", "datacost.hip", "reestimate.hip", "expand.hip",
+                  "knn.hip", "capi.hip"]
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
+        raise RuntimeError("build failed: " + os.path.basename(cmd[-1]))
+
+
+def build_engine(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
+    headers.append(os.path.join(ROOT, "include", "multih_hip.h"))
+    jobs = []
+    objs = []
+    for src in KERNEL_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    if jobs:
+        if verbose:
+            print(f"[build] compiling {len(jobs)} HIP translation unit(s) for {ARCH}")
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _newer(LIB, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """C++ host mirror of the reference class (no HIP in these files; g++)."""
+    srcs = [os.path.join(HOST, f) for f in ("MultiH.cpp", "mean_shift.cpp")]
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    hdrs.append(os.path.join(ROOT, "include", "multih_hip.h"))
+    cxx = os.environ.get("CXX", "g++")
+    flags = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-I" + os.path.join(ROOT, "include"),
+             "-I" + HOST]
+    if force or _newer(HOST_LIB, srcs + hdrs + [LIB]):
+        if verbose:
+            print("[build] host layer (class MultiH over the C ABI)")
+        _run([cxx] + flags + ["-shared", "-o", HOST_LIB] + srcs +
+             ["-L" + HERE, "-lmultih_hip", "-Wl,-rpath,$ORIGIN"])
+    main = os.path.join(HOST, "main.cpp")
+    if os.path.exists(main) and (force or _newer(HARNESS, [main, HOST_LIB] + hdrs)):
+        _run([cxx] + flags + ["-o", HARNESS, main, "-L" + HERE, "-lmultih_host", "-lmultih_hip",
+                              "-Wl,-rpath,$ORIGIN"])
+    return HOST_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_engine(force, verbose)
+    if os.path.exists(os.path.join(HOST, "MultiH.cpp")):
+        build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("ok:", LIB)

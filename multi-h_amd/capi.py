@@ -1,0 +1,254 @@
+"""ctypes binding of include/multih_hip.h (libmultih_hip.so) for tests, bench
+and multi-GPU plumbing.  One method per C entry point, numpy in / numpy out; no
+computation happens in Python and nothing here falls back to the CPU: if the
+library is missing or no gfx950 device is visible, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmultih_hip.so")
+
+MH_OK = 0
+ERR_NAMES = {-1: "MH_ERR_NO_DEVICE", -2: "MH_ERR_INVALID", -3: "MH_ERR_HIP", -4: "MH_ERR_NOT_SET",
+             -5: "MH_ERR_OVERFLOW"}
+BUF_COUNTS, BUF_MODELS, BUF_RESIDUALS, BUF_LABELS, BUF_COST = 0, 1, 2, 3, 4
+K_DLT4, K_RESIDUAL, K_SCORE, K_DATACOST, K_EXPAND, K_REESTIMATE = 0, 1, 2, 3, 4, 5
+
+# every symbol include/multih_hip.h declares (tests check the export table against this)
+SYMBOLS = [
+    "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
+    "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
+    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_dlt4",
+    "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_score",
+    "mh_residual_matrix", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
+    "mh_profile_get", "mh_set_tuning",
+]
+
+
+class MultiHError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen the engine; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} is not built; run `python multi-h_amd/build.py` "
+                                "(or __graft_entry__.build())")
+    lib = C.CDLL(p)
+    lib.mh_last_error.restype = C.c_char_p
+    lib.mh_destroy.restype = None
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Engine:
+    """Thin owner of one `mh_engine*`."""
+
+    def __init__(self, device: int = 0, thr_fund_mat: float = 3.0, thr_hom: float = 2.5,
+                 locality: float = 0.002, lam: float = 0.5, min_inliers: int = 0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        self._check(self.lib.mh_create(C.byref(self._h), int(device)))
+        self.n = 0
+        self.set_params(thr_fund_mat, thr_hom, locality, lam, min_inliers)
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != MH_OK:
+            raise MultiHError(rc, (self.lib.mh_last_error() or b"").decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.mh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- parameters / inputs ------------------------------------------------
+    def set_params(self, thr_fund_mat, thr_hom, locality, lam, min_inliers=0):
+        self._check(self.lib.mh_set_params(self._h, C.c_double(thr_fund_mat), C.c_double(thr_hom),
+                                           C.c_double(locality), C.c_double(lam), int(min_inliers)))
+        self.thr_hom, self.lam = float(thr_hom), float(lam)
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.lib.mh_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._check(self.lib.mh_synchronize(self._h))
+
+    def set_correspondences(self, src, dst, aff=None):
+        src, dst = _f64(src), _f64(dst)
+        n = src.shape[0]
+        ap = None
+        if aff is not None:
+            aff = _f64(aff).reshape(n, 4)
+            ap = _p(aff, C.c_double)
+        self._check(self.lib.mh_set_correspondences(self._h, _p(src, C.c_double), _p(dst, C.c_double), ap, n))
+        self.n = n
+
+    def set_epipolar(self, F, e2):
+        F, e2 = _f64(F).reshape(9), _f64(e2).reshape(2)
+        self._check(self.lib.mh_set_epipolar(self._h, _p(F, C.c_double), _p(e2, C.c_double)))
+
+    def set_neighbors_csr(self, rowptr, col):
+        rowptr, col = _i32(rowptr), _i32(col)
+        cp = _p(col, C.c_int) if col.size else None
+        self._check(self.lib.mh_set_neighbors_csr(self._h, _p(rowptr, C.c_int), cp, rowptr.size - 1))
+
+    def build_neighbors_knn(self, k: int):
+        self._check(self.lib.mh_build_neighbors_knn(self._h, int(k)))
+
+    def get_sym_graph(self):
+        nnz = C.c_int(0)
+        self._check(self.lib.mh_get_sym_graph(self._h, None, None, None, C.byref(nnz)))
+        rp = np.empty(self.n + 1, dtype=np.int32)
+        col = np.empty(nnz.value, dtype=np.int32)
+        w = np.empty(nnz.value, dtype=np.int32)
+        self._check(self.lib.mh_get_sym_graph(self._h, _p(rp, C.c_int), _p(col, C.c_int), _p(w, C.c_int), None))
+        return rp, col, w
+
+    # -- propose ------------------------------------------------------------
+    def propose_dlt4(self, seed: int, first: int, m: int):
+        self._check(self.lib.mh_propose_dlt4(self._h, C.c_ulonglong(seed), C.c_longlong(first), int(m)))
+
+    def set_models(self, H):
+        H = _f64(H).reshape(-1, 9)
+        self._check(self.lib.mh_set_models(self._h, _p(H, C.c_double), H.shape[0]))
+
+    @property
+    def model_count(self) -> int:
+        m = C.c_int(0)
+        self._check(self.lib.mh_get_model_count(self._h, C.byref(m)))
+        return m.value
+
+    def get_models(self):
+        H = np.empty((self.model_count, 9), dtype=np.float64)
+        self._check(self.lib.mh_get_models(self._h, _p(H, C.c_double)))
+        return H
+
+    def get_samples(self):
+        idx = np.empty((self.model_count, 4), dtype=np.int32)
+        self._check(self.lib.mh_get_samples(self._h, _p(idx, C.c_int)))
+        return idx
+
+    # -- score --------------------------------------------------------------
+    def score(self, thr2: float, mask=None, fetch: bool = True):
+        cnt = np.empty(self.model_count, dtype=np.int32) if fetch else None
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            mp = _p(mask, C.c_ubyte)
+        self._check(self.lib.mh_score(self._h, C.c_double(thr2), mp, _p(cnt, C.c_int) if fetch else None))
+        return cnt
+
+    def residual_matrix(self, thr2: float, fetch_R: bool = True, fetch_counts: bool = True):
+        m = self.model_count
+        R = np.empty((m, self.n), dtype=np.float64) if fetch_R else None
+        cnt = np.empty(m, dtype=np.int32) if fetch_counts else None
+        self._check(self.lib.mh_residual_matrix(self._h, C.c_double(thr2),
+                                                _p(R, C.c_double) if fetch_R else None,
+                                                _p(cnt, C.c_int) if fetch_counts else None))
+        return R, cnt
+
+    def inliers_of_model(self, idx: int, thr2: float, label_value: int, labels):
+        labels = _i32(labels).copy()
+        self._check(self.lib.mh_inliers_of_model(self._h, int(idx), C.c_double(thr2), int(label_value),
+                                                 _p(labels, C.c_int)))
+        return labels
+
+    def inlier_moments(self, thr2: float):
+        m = self.model_count
+        mo = np.empty((m, 6), dtype=np.float64)
+        me = np.empty(m, dtype=np.float64)
+        self._check(self.lib.mh_inlier_moments(self._h, C.c_double(thr2), _p(mo, C.c_double), _p(me, C.c_double)))
+        return mo, me
+
+    # -- label --------------------------------------------------------------
+    def data_cost(self, fetch: bool = True):
+        cost = np.empty((self.n, self.model_count + 1), dtype=np.int32) if fetch else None
+        self._check(self.lib.mh_data_cost(self._h, _p(cost, C.c_int) if fetch else None))
+        return cost
+
+    def expand(self, init_labels=None):
+        labels = np.empty(self.n, dtype=np.int32)
+        ip = None
+        if init_labels is not None:
+            init_labels = _i32(init_labels)
+            ip = _p(init_labels, C.c_int)
+        energy, cycles = C.c_int(0), C.c_int(0)
+        self._check(self.lib.mh_expand(self._h, ip, _p(labels, C.c_int), C.byref(energy), C.byref(cycles)))
+        return labels, energy.value, cycles.value
+
+    def reestimate(self, labels):
+        labels = _i32(labels)
+        H = np.empty((self.model_count, 9), dtype=np.float64)
+        self._check(self.lib.mh_reestimate(self._h, _p(labels, C.c_int), _p(H, C.c_double)))
+        return H
+
+    def labeling_step(self, warm: bool, labeling):
+        lab = _i32(labeling).copy()
+        energy, cycles = C.c_double(0), C.c_int(0)
+        self._check(self.lib.mh_labeling_step(self._h, int(bool(warm)), _p(lab, C.c_int), C.byref(energy),
+                                              C.byref(cycles)))
+        return lab, energy.value, cycles.value
+
+    # -- device access / profiling -----------------------------------------
+    def device_buffer(self, which: int):
+        ptr, nbytes = C.c_void_p(), C.c_ulonglong(0)
+        self._check(self.lib.mh_device_buffer(self._h, int(which), C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.mh_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._check(self.lib.mh_profile_reset(self._h))
+
+    def profile_get(self, kernel: int):
+        n, ms = C.c_int(0), C.c_double(0)
+        self._check(self.lib.mh_profile_get(self._h, int(kernel), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def set_tuning(self, key: int, value: int):
+        self._check(self.lib.mh_set_tuning(self._h, int(key), int(value)))
+
+
+def device_count() -> int:
+    return int(load_library().mh_device_count())

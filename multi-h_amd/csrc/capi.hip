@@ -1,0 +1,743 @@
+// capi.hip — implementation of the C ABI declared in include/multih_hip.h.
+// Owns device buffers, the HIP stream and the per-kernel event timers; every
+// computation is a launch of a gfx950 kernel from this directory.  There is no
+// CPU fallback: without a usable HIP device mh_create fails (MH_ERR_NO_DEVICE).
+
+#include "../../include/multih_hip.h"
+#include "mh_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace mh;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(MH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;        // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int launches = 0;
+    double total_ms = 0.0;
+};
+
+struct mh_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // MultiH ctor members, M/MultiH.cpp:10-21
+    double thr_F = 3.0, thr_H = 2.5, locality = 0.002, lambda = 0.5;
+    int min_inliers = 0;
+
+    int n = 0;
+    bool have_aff = false, have_epi = false, have_graph = false;
+    DevBuf<double> x1, y1, x2, y2, a11, a12, a21, a22;
+    Epipolar epi{};
+
+    // symmetric weighted graph
+    std::vector<int> g_rowptr, g_col, g_w, g_rev;
+    DevBuf<int> d_rowptr, d_col, d_w, d_rev;
+
+    // model set
+    int m = 0;
+    bool have_samples = false;
+    DevBuf<double> H;
+    DevBuf<int> samples, counts;
+    DevBuf<double> R;
+    long long ldr = 0;
+    DevBuf<unsigned char> mask;
+    DevBuf<double> moments, min_eig;
+
+    // labeling
+    int cost_L = 0;
+    DevBuf<int> cost, labels_in, labels_pts, label_counts;
+    DevBuf<int> ew_label, ew_cur, ew_cap, ew_excess, ew_sink, ew_height, ew_flags;
+    DevBuf<long long> ew_acc;
+    int* h_flags = nullptr;
+    long long* h_acc = nullptr;
+    DevBuf<int> knn_tmp;
+
+    bool profiling = false;
+    KernelTimer timers[MH_K_COUNT_];
+    int tune_residual_variant = 0;
+    ExpandStats last_expand{};
+
+    Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n }; }
+};
+
+namespace {
+
+struct ScopedTimer {
+    mh_engine* e;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(mh_engine* e_, int k_) : e(e_), k(k_)
+    {
+        if (!e->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, e->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, e->stream);
+        e->timers[k].pending.emplace_back(a, b);
+    }
+};
+
+void resolve_timers(mh_engine* e)
+{
+    for (int k = 0; k < MH_K_COUNT_; ++k) {
+        KernelTimer& t = e->timers[k];
+        for (auto& pr : t.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pr.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                t.total_ms += ms;
+                t.launches += 1;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        t.pending.clear();
+    }
+}
+
+int require_points(mh_engine* e)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (e->n <= 0) return fail(MH_ERR_NOT_SET, "correspondences are not set");
+    return MH_OK;
+}
+
+int require_models(mh_engine* e)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
+    return MH_OK;
+}
+
+// Symmetric weighted CSR with reverse-arc index from a directed hit list.
+// setNeighbors semantics (GCoptimization.cpp:1656-1681, M/MultiH.cpp:532-540):
+// every directed hit i->j (j != i) appends j to i's list and i to j's list, so the
+// pair weight is mult(i,j) = #[i->j] + #[j->i]   (SURVEY A-2).
+int build_sym_graph(mh_engine* e, const int* rowptr, const int* col, int n)
+{
+    std::vector<int> deg(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (rowptr[i + 1] < rowptr[i]) return fail(MH_ERR_INVALID, "rowptr must be non-decreasing");
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int j = col[k];
+            if (j < 0 || j >= n) return fail(MH_ERR_INVALID, "neighbour index out of range");
+            if (j == i) continue;
+            ++deg[i];
+            ++deg[j];
+        }
+    }
+    std::vector<long long> start(n + 1, 0);
+    for (int i = 0; i < n; ++i) start[i + 1] = start[i] + deg[i];
+    if (start[n] > 0x7fffffffll) return fail(MH_ERR_OVERFLOW, "too many neighbour entries");
+    std::vector<int> raw((size_t)start[n]);
+    std::vector<long long> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < n; ++i)
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int j = col[k];
+            if (j == i) continue;
+            raw[(size_t)fill[i]++] = j;
+            raw[(size_t)fill[j]++] = i;
+        }
+    e->g_rowptr.assign(n + 1, 0);
+    e->g_col.clear();
+    e->g_w.clear();
+    for (int i = 0; i < n; ++i) {
+        int* b = raw.data() + start[i];
+        int* en = raw.data() + start[i + 1];
+        std::sort(b, en);
+        for (int* p = b; p < en;) {
+            int* q = p;
+            while (q < en && *q == *p) ++q;
+            e->g_col.push_back(*p);
+            e->g_w.push_back((int)(q - p));
+            p = q;
+        }
+        e->g_rowptr[i + 1] = (int)e->g_col.size();
+    }
+    const int nnz = (int)e->g_col.size();
+    e->g_rev.assign(nnz, -1);
+    for (int i = 0; i < n; ++i)
+        for (int k = e->g_rowptr[i]; k < e->g_rowptr[i + 1]; ++k) {
+            const int j = e->g_col[k];
+            const int* b = e->g_col.data() + e->g_rowptr[j];
+            const int* en = e->g_col.data() + e->g_rowptr[j + 1];
+            const int* it = std::lower_bound(b, en, i);
+            e->g_rev[k] = (int)(it - e->g_col.data());
+        }
+    return MH_OK;
+}
+
+int upload_graph(mh_engine* e)
+{
+    const int n = e->n, nnz = (int)e->g_col.size();
+    HIPCHK(e->d_rowptr.reserve(n + 1));
+    HIPCHK(e->d_col.reserve(nnz));
+    HIPCHK(e->d_w.reserve(nnz));
+    HIPCHK(e->d_rev.reserve(nnz));
+    HIPCHK(hipMemcpyAsync(e->d_rowptr.p, e->g_rowptr.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, e->stream));
+    if (nnz) {
+        HIPCHK(hipMemcpyAsync(e->d_col.p, e->g_col.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_w.p, e->g_w.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_rev.p, e->g_rev.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_graph = true;
+    return MH_OK;
+}
+
+int ensure_expand_work(mh_engine* e)
+{
+    const int n = e->n, nnz = (int)e->g_col.size();
+    HIPCHK(e->ew_label.reserve(n));
+    HIPCHK(e->ew_cur.reserve(n));
+    HIPCHK(e->ew_cap.reserve(nnz));
+    HIPCHK(e->ew_excess.reserve(n));
+    HIPCHK(e->ew_sink.reserve(n));
+    HIPCHK(e->ew_height.reserve(n));
+    HIPCHK(e->ew_flags.reserve(16));
+    HIPCHK(e->ew_acc.reserve(8));
+    if (!e->h_flags) HIPCHK(hipHostMalloc((void**)&e->h_flags, sizeof(int) * 16));
+    if (!e->h_acc) HIPCHK(hipHostMalloc((void**)&e->h_acc, sizeof(long long) * 8));
+    return MH_OK;
+}
+
+int do_data_cost(mh_engine* e)
+{
+    const int L = e->m + 1;
+    HIPCHK(e->cost.reserve((size_t)e->n * L));
+    {
+        ScopedTimer t(e, MH_K_DATACOST);
+        HIPCHK(launch_data_cost(e->pts(), e->H.p, e->m, e->lambda, e->thr_H * e->thr_H, e->cost.p, e->stream));
+    }
+    e->cost_L = L;
+    return MH_OK;
+}
+
+// init_dev: device pointer to initial labels (GCO numbering) or null.
+int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
+{
+    if (!e->have_graph) return fail(MH_ERR_NOT_SET, "neighbour graph is not set");
+    if (e->cost_L != e->m + 1) return fail(MH_ERR_NOT_SET, "data cost is stale; call mh_data_cost first");
+    int rc = ensure_expand_work(e);
+    if (rc) return rc;
+    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size() };
+    ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_excess.p, e->ew_sink.p,
+                  e->ew_height.p, e->ew_flags.p, e->ew_acc.p, e->h_flags, e->h_acc };
+    const int potts = (int)std::round(100.0 * e->lambda);     // M/MultiH.h:41, MultiH.cpp:510
+    ExpandStats st{};
+    {
+        ScopedTimer t(e, MH_K_EXPAND);
+        HIPCHK(launch_init_labeling(e->cost.p, e->cost_L, e->n, init_dev, w.label, w.cur_cost, e->stream));
+        hipError_t he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
+        if (he == hipErrorInvalidValue && st.energy == -1)
+            return fail(MH_ERR_OVERFLOW, "int32 energy term overflow in alpha-expansion");
+        HIPCHK(he);
+    }
+    e->last_expand = st;
+    if (st.energy > 0x7fffffffll || st.energy < -0x7fffffffll)
+        return fail(MH_ERR_OVERFLOW, "total energy exceeds the reference's int32 EnergyType");
+    if (energy) *energy = st.energy;
+    if (cycles) *cycles = st.cycles;
+    return MH_OK;
+}
+
+__global__ void k_shift_labels(int n, const int* in, int delta, int* out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] + delta;
+}
+
+__global__ void k_split_soa(int n, const double* src, const double* dst, const double* aff,
+                            double* x1, double* y1, double* x2, double* y2, double* a11,
+                            double* a12, double* a21, double* a22)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    x1[i] = src[2 * i]; y1[i] = src[2 * i + 1];
+    x2[i] = dst[2 * i]; y2[i] = dst[2 * i + 1];
+    if (aff) { a11[i] = aff[4 * i]; a12[i] = aff[4 * i + 1]; a21[i] = aff[4 * i + 2]; a22[i] = aff[4 * i + 3]; }
+}
+
+} // namespace
+
+extern "C" {
+
+int mh_abi_version(void) { return MH_ABI_VERSION; }
+
+const char* mh_last_error(void) { return g_err.c_str(); }
+
+int mh_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int mh_create(mh_engine** out, int device)
+{
+    if (!out) return fail(MH_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+        return fail(MH_ERR_NO_DEVICE, "no HIP device visible; the Multi-H engine has no CPU fallback");
+    if (device < 0 || device >= c) return fail(MH_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MH_ERR_NO_DEVICE, std::string("device arch is ") + prop.gcnArchName +
+                                           "; this library carries gfx950 code objects only");
+    mh_engine* e = new (std::nothrow) mh_engine();
+    if (!e) return fail(MH_ERR_INVALID, "out of host memory");
+    e->device = device;
+    hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete e; return fail(MH_ERR_HIP, hipGetErrorString(he)); }
+    e->stream = e->own_stream;
+    *out = e;
+    return MH_OK;
+}
+
+void mh_destroy(mh_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    resolve_timers(e);
+    e->x1.release(); e->y1.release(); e->x2.release(); e->y2.release();
+    e->a11.release(); e->a12.release(); e->a21.release(); e->a22.release();
+    e->d_rowptr.release(); e->d_col.release(); e->d_w.release(); e->d_rev.release();
+    e->H.release(); e->samples.release(); e->counts.release(); e->R.release(); e->mask.release();
+    e->moments.release(); e->min_eig.release();
+    e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
+    e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
+    e->ew_sink.release(); e->ew_height.release(); e->ew_flags.release(); e->ew_acc.release();
+    e->knn_tmp.release();
+    if (e->h_flags) (void)hipHostFree(e->h_flags);
+    if (e->h_acc) (void)hipHostFree(e->h_acc);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int mh_set_params(mh_engine* e, double thr_F, double thr_H, double locality, double lambda, int min_inliers)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (!(thr_H > 0.0) || !(lambda > 0.0)) return fail(MH_ERR_INVALID, "thr_hom and lambda must be positive");
+    e->thr_F = thr_F; e->thr_H = thr_H; e->locality = locality; e->lambda = lambda;
+    e->min_inliers = min_inliers;
+    e->cost_L = 0;
+    return MH_OK;
+}
+
+int mh_set_stream(mh_engine* e, void* hip_stream)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return MH_OK;
+}
+
+int mh_synchronize(mh_engine* e)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    resolve_timers(e);
+    return MH_OK;
+}
+
+int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst_xy,
+                           const double* affines, int n)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (!src_xy || !dst_xy || n <= 0) return fail(MH_ERR_INVALID, "src/dst must be non-null and n > 0");
+    HIPCHK(hipSetDevice(e->device));
+    // +1 element of slack: the 16-B vector loads of the residual sweep never cross the end,
+    // but keep the allocation even-sized for them.
+    const size_t cap = (size_t)n + 2;
+    HIPCHK(e->x1.reserve(cap)); HIPCHK(e->y1.reserve(cap));
+    HIPCHK(e->x2.reserve(cap)); HIPCHK(e->y2.reserve(cap));
+    HIPCHK(e->a11.reserve(cap)); HIPCHK(e->a12.reserve(cap));
+    HIPCHK(e->a21.reserve(cap)); HIPCHK(e->a22.reserve(cap));
+    DevBuf<double> s, d, a;
+    HIPCHK(s.reserve((size_t)n * 2));
+    HIPCHK(d.reserve((size_t)n * 2));
+    HIPCHK(hipMemcpyAsync(s.p, src_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.p, dst_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, e->stream));
+    if (affines) {
+        HIPCHK(a.reserve((size_t)n * 4));
+        HIPCHK(hipMemcpyAsync(a.p, affines, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));
+    }
+    hipLaunchKernelGGL(k_split_soa, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, s.p, d.p,
+                       affines ? a.p : nullptr, e->x1.p, e->y1.p, e->x2.p, e->y2.p, e->a11.p,
+                       e->a12.p, e->a21.p, e->a22.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    s.release(); d.release(); a.release();
+    e->n = n;
+    e->have_aff = affines != nullptr;
+    e->have_graph = false;
+    e->g_rowptr.clear(); e->g_col.clear(); e->g_w.clear(); e->g_rev.clear();
+    e->cost_L = 0;
+    return MH_OK;
+}
+
+int mh_set_epipolar(mh_engine* e, const double F[9], const double e2[2])
+{
+    if (!e || !F || !e2) return fail(MH_ERR_INVALID, "null argument");
+    for (int i = 0; i < 9; ++i) e->epi.F[i] = F[i];
+    e->epi.ex = e2[0];
+    e->epi.ey = e2[1];
+    e->have_epi = true;
+    return MH_OK;
+}
+
+int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col, int n)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!rowptr || n != e->n) return fail(MH_ERR_INVALID, "rowptr null or n != number of correspondences");
+    if (rowptr[n] > 0 && !col) return fail(MH_ERR_INVALID, "col is null");
+    rc = build_sym_graph(e, rowptr, col, n);
+    if (rc) return rc;
+    return upload_graph(e);
+}
+
+int mh_build_neighbors_knn(mh_engine* e, int k)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (k < 1 || k > 32 || k >= e->n) return fail(MH_ERR_INVALID, "k must be in [1, 32] and < n");
+    HIPCHK(e->knn_tmp.reserve((size_t)e->n * k));
+    HIPCHK(launch_knn(e->pts(), k, e->knn_tmp.p, e->stream));
+    std::vector<int> col((size_t)e->n * k), rowptr(e->n + 1);
+    HIPCHK(hipMemcpyAsync(col.data(), e->knn_tmp.p, sizeof(int) * col.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i <= e->n; ++i) rowptr[i] = i * k;
+    rc = build_sym_graph(e, rowptr.data(), col.data(), e->n);
+    if (rc) return rc;
+    return upload_graph(e);
+}
+
+int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (!e->have_graph) return fail(MH_ERR_NOT_SET, "neighbour graph is not set");
+    if (nnz) *nnz = (int)e->g_col.size();
+    if (rowptr) std::copy(e->g_rowptr.begin(), e->g_rowptr.end(), rowptr);
+    if (col) std::copy(e->g_col.begin(), e->g_col.end(), col);
+    if (w) std::copy(e->g_w.begin(), e->g_w.end(), w);
+    return MH_OK;
+}
+
+int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int m)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (m <= 0) return fail(MH_ERR_INVALID, "m must be positive");
+    if (e->n < 4) return fail(MH_ERR_INVALID, "need at least 4 correspondences");
+    HIPCHK(e->H.reserve((size_t)m * 9));
+    HIPCHK(e->samples.reserve((size_t)m * 4));
+    HIPCHK(e->counts.reserve(m));
+    {
+        ScopedTimer t(e, MH_K_DLT4);
+        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples.p, e->H.p, e->stream));
+    }
+    e->m = m;
+    e->have_samples = true;
+    e->cost_L = 0;
+    return MH_OK;
+}
+
+int mh_set_models(mh_engine* e, const double* H, int m)
+{
+    if (!e || !H || m <= 0) return fail(MH_ERR_INVALID, "null argument or m <= 0");
+    HIPCHK(e->H.reserve((size_t)m * 9));
+    HIPCHK(e->counts.reserve(m));
+    HIPCHK(hipMemcpyAsync(e->H.p, H, sizeof(double) * 9 * m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->m = m;
+    e->have_samples = false;
+    e->cost_L = 0;
+    return MH_OK;
+}
+
+int mh_get_models(mh_engine* e, double* H)
+{
+    if (!e || !H) return fail(MH_ERR_INVALID, "null argument");
+    if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
+    HIPCHK(hipMemcpyAsync(H, e->H.p, sizeof(double) * 9 * e->m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_get_model_count(mh_engine* e, int* m)
+{
+    if (!e || !m) return fail(MH_ERR_INVALID, "null argument");
+    *m = e->m;
+    return MH_OK;
+}
+
+int mh_get_samples(mh_engine* e, int* idx)
+{
+    if (!e || !idx) return fail(MH_ERR_INVALID, "null argument");
+    if (!e->have_samples) return fail(MH_ERR_NOT_SET, "no sampled batch; call mh_propose_dlt4");
+    HIPCHK(hipMemcpyAsync(idx, e->samples.p, sizeof(int) * 4 * e->m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* counts)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    HIPCHK(e->counts.reserve(e->m));
+    const unsigned char* dmask = nullptr;
+    if (point_mask) {
+        HIPCHK(e->mask.reserve((size_t)e->n + 2));
+        HIPCHK(hipMemcpyAsync(e->mask.p, point_mask, e->n, hipMemcpyHostToDevice, e->stream));
+        dmask = e->mask.p;
+    }
+    {
+        ScopedTimer t(e, MH_K_SCORE);
+        HIPCHK(launch_score(e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p, e->stream));
+    }
+    if (counts) {
+        HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return MH_OK;
+}
+
+int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    e->ldr = residual_ld(e->n);
+    HIPCHK(e->R.reserve((size_t)e->m * (size_t)e->ldr));
+    HIPCHK(e->counts.reserve(e->m));
+    {
+        ScopedTimer t(e, MH_K_RESIDUAL);
+        HIPCHK(launch_residual(e->pts(), e->H.p, e->m, thr2, e->R.p, e->ldr, e->counts.p,
+                               e->tune_residual_variant, e->stream));
+    }
+    if (R_host)
+        HIPCHK(hipMemcpy2DAsync(R_host, sizeof(double) * e->n, e->R.p, sizeof(double) * e->ldr,
+                                sizeof(double) * e->n, e->m, hipMemcpyDeviceToHost, e->stream));
+    if (counts)
+        HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
+    if (R_host || counts) HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int* labels)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    if (idx < 0 || idx >= e->m || !labels) return fail(MH_ERR_INVALID, "bad model index or null labels");
+    HIPCHK(e->labels_pts.reserve(e->n));
+    HIPCHK(hipMemcpyAsync(e->labels_pts.p, labels, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(launch_inliers_of_model(e->pts(), e->H.p, idx, thr2, label_value, e->labels_pts.p, e->stream));
+    HIPCHK(hipMemcpyAsync(labels, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_inlier_moments(mh_engine* e, double thr2, double* moments, double* min_eig)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    HIPCHK(e->moments.reserve((size_t)e->m * 6));
+    HIPCHK(e->min_eig.reserve(e->m));
+    HIPCHK(launch_moments(e->pts(), e->H.p, e->m, thr2, e->moments.p, e->min_eig.p, e->stream));
+    if (moments)
+        HIPCHK(hipMemcpyAsync(moments, e->moments.p, sizeof(double) * 6 * e->m, hipMemcpyDeviceToHost, e->stream));
+    if (min_eig)
+        HIPCHK(hipMemcpyAsync(min_eig, e->min_eig.p, sizeof(double) * e->m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_data_cost(mh_engine* e, int* cost)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    rc = do_data_cost(e);
+    if (rc) return rc;
+    if (cost) {
+        HIPCHK(hipMemcpyAsync(cost, e->cost.p, sizeof(int) * (size_t)e->n * e->cost_L, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return MH_OK;
+}
+
+int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy, int* cycles)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    const int* init_dev = nullptr;
+    if (init_labels) {
+        for (int i = 0; i < e->n; ++i)
+            if (init_labels[i] < 0 || init_labels[i] > e->m)
+                return fail(MH_ERR_INVALID, "initial label out of range 0..Nh");
+        HIPCHK(e->labels_in.reserve(e->n));
+        HIPCHK(hipMemcpyAsync(e->labels_in.p, init_labels, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
+        init_dev = e->labels_in.p;
+    }
+    long long en = 0;
+    rc = do_expand(e, init_dev, &en, cycles);
+    if (rc) return rc;
+    if (energy) *energy = (int)en;
+    if (labels_out) {
+        HIPCHK(hipMemcpyAsync(labels_out, e->ew_label.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return MH_OK;
+}
+
+int mh_reestimate(mh_engine* e, const int* labels, double* H_out)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    if (!labels) return fail(MH_ERR_INVALID, "labels is null");
+    if (!e->have_aff) return fail(MH_ERR_NOT_SET, "affinities are not set");
+    if (!e->have_epi) return fail(MH_ERR_NOT_SET, "fundamental matrix / epipole are not set");
+    HIPCHK(e->labels_pts.reserve(e->n));
+    HIPCHK(e->label_counts.reserve(e->m));
+    HIPCHK(hipMemcpyAsync(e->labels_pts.p, labels, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
+    Affines a{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
+    {
+        ScopedTimer t(e, MH_K_REESTIMATE);
+        HIPCHK(launch_reestimate(e->pts(), a, e->labels_pts.p, e->m, e->epi, e->H.p, e->label_counts.p, e->stream));
+    }
+    e->cost_L = 0;
+    if (H_out) {
+        HIPCHK(hipMemcpyAsync(H_out, e->H.p, sizeof(double) * 9 * e->m, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return MH_OK;
+}
+
+int mh_labeling_step(mh_engine* e, int warm, int* labeling, double* energy, int* cycles)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    if (!labeling) return fail(MH_ERR_INVALID, "labeling is null");
+    if (!e->have_aff || !e->have_epi) return fail(MH_ERR_NOT_SET, "affinities / epipolar geometry are not set");
+    rc = do_data_cost(e);
+    if (rc) return rc;
+    const int* init_dev = nullptr;
+    const dim3 grid((e->n + 255) / 256), blk(256);
+    if (warm) {                                                   // M/MultiH.cpp:525-529
+        for (int i = 0; i < e->n; ++i)
+            if (labeling[i] < -1 || labeling[i] >= e->m)
+                return fail(MH_ERR_INVALID, "warm-start label out of range -1..Nh-1");
+        HIPCHK(e->labels_in.reserve(e->n));
+        HIPCHK(hipMemcpyAsync(e->labels_in.p, labeling, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(k_shift_labels, grid, blk, 0, e->stream, e->n, e->labels_in.p, 1, e->labels_in.p);
+        init_dev = e->labels_in.p;
+    }
+    long long en = 0;
+    rc = do_expand(e, init_dev, &en, cycles);
+    if (rc) return rc;
+    HIPCHK(e->labels_pts.reserve(e->n));
+    HIPCHK(e->label_counts.reserve(e->m));
+    hipLaunchKernelGGL(k_shift_labels, grid, blk, 0, e->stream, e->n, e->ew_label.p, -1, e->labels_pts.p); // :547-568
+    Affines a{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
+    {
+        ScopedTimer t(e, MH_K_REESTIMATE);
+        HIPCHK(launch_reestimate(e->pts(), a, e->labels_pts.p, e->m, e->epi, e->H.p, e->label_counts.p, e->stream));
+    }
+    e->cost_L = 0;                                               // models changed
+    HIPCHK(hipMemcpyAsync(labeling, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (energy) *energy = (double)en;
+    return MH_OK;
+}
+
+int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long* bytes)
+{
+    if (!e || !ptr_dev || !bytes) return fail(MH_ERR_INVALID, "null argument");
+    switch (which) {
+    case MH_BUF_COUNTS: *ptr_dev = e->counts.p; *bytes = sizeof(int) * (size_t)e->m; break;
+    case MH_BUF_MODELS: *ptr_dev = e->H.p; *bytes = sizeof(double) * 9 * (size_t)e->m; break;
+    case MH_BUF_RESIDUALS: *ptr_dev = e->R.p; *bytes = sizeof(double) * (size_t)e->m * (size_t)e->ldr; break;
+    case MH_BUF_LABELS: *ptr_dev = e->ew_label.p; *bytes = sizeof(int) * (size_t)e->n; break;
+    case MH_BUF_COST: *ptr_dev = e->cost.p; *bytes = sizeof(int) * (size_t)e->n * e->cost_L; break;
+    default: return fail(MH_ERR_INVALID, "unknown buffer id");
+    }
+    if (!*ptr_dev) return fail(MH_ERR_NOT_SET, "buffer has not been produced yet");
+    return MH_OK;
+}
+
+int mh_profile_enable(mh_engine* e, int on)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    e->profiling = on != 0;
+    return MH_OK;
+}
+
+int mh_profile_reset(mh_engine* e)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    resolve_timers(e);
+    for (int k = 0; k < MH_K_COUNT_; ++k) { e->timers[k].launches = 0; e->timers[k].total_ms = 0.0; }
+    return MH_OK;
+}
+
+int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms)
+{
+    if (!e || kernel < 0 || kernel >= MH_K_COUNT_) return fail(MH_ERR_INVALID, "bad kernel id");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    resolve_timers(e);
+    if (launches) *launches = e->timers[kernel].launches;
+    if (total_ms) *total_ms = e->timers[kernel].total_ms;
+    return MH_OK;
+}
+
+int mh_set_tuning(mh_engine* e, int key, int value)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
+    return fail(MH_ERR_INVALID, "unknown tuning key");
+}
+
+} // extern "C"

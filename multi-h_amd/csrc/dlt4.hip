@@ -1,0 +1,209 @@
+// dlt4.hip — propose step: counter-RNG 4-tuples + batched normalised 4-point
+// DLT, gfx950.  Stands where the reference calls cv::findHomography on minimal
+// samples (M/MultiH.cpp:725, M/MultipleHomographies.h:118-144,328-339); there
+// is no in-tree reference arithmetic, the definition is DESIGN.md §Propose.
+//
+// Per hypothesis: Hartley-normalise the 4 correspondences (centroid, mean
+// distance sqrt 2 — the recipe of NormalizePoints,
+// Homography_Refine3PTCallback.h:236-271), build the 8x9 DLT matrix A and find
+// its null vector with a one-sided (Hestenes) Jacobi SVD: column pairs of
+// W = [A; I9] are rotated until all columns of the A-part are mutually
+// orthogonal; the I-part column under the vanishing A-column is the null
+// vector.  De-normalise, scale to unit Frobenius norm, h33 >= 0.
+//
+// Mapping: a wavefront solves 16 hypotheses at once, 4 lanes each.  The
+// round-robin schedule gives 9 rounds of 4 DISJOINT column pairs per sweep;
+// lane (slot s = lane>>4) rotates pair s of the round for hypothesis lane&15.
+// W lives in LDS as W[wave][row*9+col][hyp] (17x9 doubles per hypothesis,
+// 19.1 KiB per wave) so the 16 hypotheses of a wave sit in consecutive banks.
+// Disjoint pairs commute exactly, so the result equals a serial sweep in
+// schedule order bit for bit.  All operations round once (-ffp-contract=off).
+
+#include "mh_kernels.hpp"
+
+namespace mh {
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Four distinct indices for hypothesis m: draw c gives r = splitmix64(seed + (m<<8) + c),
+// idx = ((r>>32)*N)>>32; duplicates inside the tuple are rejected; at most 64 draws.
+__device__ __forceinline__ void sample4(unsigned long long seed, unsigned long long m,
+                                        unsigned int N, int out[4])
+{
+    int got = 0;
+    for (unsigned int c = 0; c < 64 && got < 4; ++c) {
+        const unsigned long long r = splitmix64(seed + (m << 8) + c);
+        const int idx = (int)(((r >> 32) * (unsigned long long)N) >> 32);
+        bool dup = false;
+        for (int k = 0; k < got; ++k) dup = dup || (out[k] == idx);
+        if (!dup) out[got++] = idx;
+    }
+    for (; got < 4; ++got) out[got] = out[0];
+}
+
+// circle-method schedule: round r, slot k (1..4): a = (r+k)%9, b = (r+9-k)%9
+__device__ __forceinline__ void rr_pair(int r, int slot, int& p, int& q)
+{
+    const int k = slot + 1;
+    const int a = (r + k) % 9, b = (r + 9 - k) % 9;
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
+constexpr int HPW = 16;                  // hypotheses per wave
+constexpr int WROWS = 17, WCOLS = 9;
+
+__global__ void __launch_bounds__(256)
+k_dlt4(const double* __restrict__ x1, const double* __restrict__ y1,
+       const double* __restrict__ x2, const double* __restrict__ y2, int N,
+       unsigned long long seed, long long first, int M, int* __restrict__ idx_out,
+       double* __restrict__ H_out)
+{
+    __shared__ double sW[4][WROWS * WCOLS][HPW];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int hs = lane & (HPW - 1);
+    const int slot = lane >> 4;
+    const int m = (blockIdx.x * 4 + wave) * HPW + hs;
+    const bool live = m < M;
+    double (*W)[HPW] = sW[wave];
+#define WE(r, c) W[(r) * WCOLS + (c)][hs]
+
+    // ---- sample + normalise (all 4 lanes of a hypothesis redundantly) ----
+    int id[4] = { 0, 0, 0, 0 };
+    double sx[4], sy[4], dx[4], dy[4];
+    if (live) sample4(seed, (unsigned long long)(first + m), (unsigned int)N, id);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sx[k] = x1[id[k]]; sy[k] = y1[id[k]]; dx[k] = x2[id[k]]; dy[k] = y2[id[k]];
+    }
+    if (live && slot == 0 && idx_out) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) idx_out[4 * (size_t)m + k] = id[k];
+    }
+    double cx1 = ((sx[0] + sx[1]) + sx[2]) + sx[3], cy1 = ((sy[0] + sy[1]) + sy[2]) + sy[3];
+    double cx2 = ((dx[0] + dx[1]) + dx[2]) + dx[3], cy2 = ((dy[0] + dy[1]) + dy[2]) + dy[3];
+    cx1 = cx1 * 0.25; cy1 = cy1 * 0.25; cx2 = cx2 * 0.25; cy2 = cy2 * 0.25;
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double ax = sx[k] - cx1, ay = sy[k] - cy1, bx = dx[k] - cx2, by = dy[k] - cy2;
+        d1 = d1 + sqrt(ax * ax + ay * ay);
+        d2 = d2 + sqrt(bx * bx + by * by);
+    }
+    const double s1 = sqrt(2.0) / (d1 * 0.25), s2 = sqrt(2.0) / (d2 * 0.25);
+
+    // ---- fill W: lane `slot` writes the two rows of correspondence `slot` ----
+    {
+        double x = 0.0, y = 0.0, u = 0.0, v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k == slot) {
+                x = (sx[k] - cx1) * s1; y = (sy[k] - cy1) * s1;
+                u = (dx[k] - cx2) * s2; v = (dy[k] - cy2) * s2;
+            }
+        const int r0 = 2 * slot, r1 = 2 * slot + 1;
+        WE(r0, 0) = -x; WE(r0, 1) = -y; WE(r0, 2) = -1.0; WE(r0, 3) = 0.0; WE(r0, 4) = 0.0;
+        WE(r0, 5) = 0.0; WE(r0, 6) = u * x; WE(r0, 7) = u * y; WE(r0, 8) = u;
+        WE(r1, 0) = 0.0; WE(r1, 1) = 0.0; WE(r1, 2) = 0.0; WE(r1, 3) = -x; WE(r1, 4) = -y;
+        WE(r1, 5) = -1.0; WE(r1, 6) = v * x; WE(r1, 7) = v * y; WE(r1, 8) = v;
+        // identity part: slot s writes rows 8+3s .. 8+3s+2 (slot 3: none)
+        if (slot < 3)
+            for (int i = 3 * slot; i < 3 * slot + 3; ++i)
+                for (int j = 0; j < 9; ++j) WE(8 + i, j) = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    // ---- one-sided Jacobi sweeps ----
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotated = 0;
+        for (int r = 0; r < 9; ++r) {
+            int p, q;
+            rr_pair(r, slot, p, q);
+            double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double wp = WE(i, p), wq = WE(i, q);
+                alpha = alpha + wp * wp;
+                beta = beta + wq * wq;
+                gamma = gamma + wp * wq;
+            }
+            // rotate only if |gamma| > 1e-15*sqrt(alpha*beta) and neither column has already
+            // vanished (norm < 1e-14; Hartley-normalised data).  NaN never rotates.
+            const bool rot = live && (gamma != 0.0) && (gamma * gamma > 1e-30 * (alpha * beta)) &&
+                             (alpha >= 1e-28) && (beta >= 1e-28);
+            if (rot) {
+                ++rotated;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double sg = (zeta >= 0.0) ? 1.0 : -1.0;
+                const double t = sg / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t);
+                const double s = c * t;
+#pragma unroll
+                for (int i = 0; i < WROWS; ++i) {
+                    const double wp = WE(i, p), wq = WE(i, q);
+                    WE(i, p) = c * wp - s * wq;
+                    WE(i, q) = s * wp + c * wq;
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(rotated)) break;
+    }
+
+    // ---- extract null vector, de-normalise (slot 0 of each live hypothesis) ----
+    if (live && slot == 0) {
+        int jm = 0;
+        double best = 0.0;
+        for (int j = 0; j < 9; ++j) {
+            double a = 0.0;
+            for (int i = 0; i < 8; ++i) a = a + WE(i, j) * WE(i, j);
+            if (j == 0 || a < best) { best = a; jm = j; }
+        }
+        double g[9];
+        for (int j = 0; j < 9; ++j) g[j] = WE(8 + j, jm);
+        double A1[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double a = g[3 * r], b = g[3 * r + 1], c = g[3 * r + 2];
+            A1[3 * r] = a * s1;
+            A1[3 * r + 1] = b * s1;
+            A1[3 * r + 2] = (c - (a * s1) * cx1) - (b * s1) * cy1;
+        }
+        const double is2 = 1.0 / s2;
+        double Hh[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Hh[j] = A1[j] * is2 + cx2 * A1[6 + j];
+            Hh[3 + j] = A1[3 + j] * is2 + cy2 * A1[6 + j];
+            Hh[6 + j] = A1[6 + j];
+        }
+        double fro = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) fro = fro + Hh[j] * Hh[j];
+        double sc = 1.0 / sqrt(fro);
+        if (Hh[8] < 0.0) sc = -sc;
+        double* out = H_out + 9 * (size_t)m;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) out[j] = Hh[j] * sc;
+    }
+#undef WE
+}
+
+hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,
+                       int* idx_out, double* H_out, hipStream_t s)
+{
+    if (M <= 0) return hipSuccess;
+    const int per_block = 4 * HPW;
+    hipLaunchKernelGGL(k_dlt4, dim3((M + per_block - 1) / per_block), dim3(256), 0, s, p.x1, p.y1,
+                       p.x2, p.y2, p.n, seed, first, M, idx_out, H_out);
+    return hipGetLastError();
+}
+
+} // namespace mh

@@ -1,0 +1,411 @@
+// expand.hip — alpha-expansion relabel sweep on gfx950.
+//
+// Replaces GCoptimization::expansion's standard-cycle branch
+// (GCoptimization.cpp:1032-1049), oneExpansionIteration (:1278-1289) and
+// alpha_expansion (:1212-1274) together with the Energy/Graph/BK max-flow
+// stack underneath (energy.h:204-253,324-328; maxflow.cpp:472-604;
+// graph.h:478-488).  Energies are int32 like the reference's
+// (GCoptimization.h:166-170); totals are accumulated in int64 and checked.
+//
+// Per move (label alpha, fixed order 0..L-1, :1285-1286):
+//   k_move_setup   builds the binary energy's s-t graph on the PERSISTENT
+//                  symmetric CSR (only capacities change per move):
+//                    t-links  : add_term1(i, E0=cost(i,alpha), E1=cost(i,cur))   (:336-342)
+//                               + Potts terms against neighbours already at alpha (:360-362)
+//                               + the D part of add_term2 for j<i with different labels (energy.h:220)
+//                    n-links  : for active pair i>j: cap(i->j)=w*potts,
+//                               cap(j->i)= (l_i==l_j) ? w*potts : 0              (energy.h:221-252)
+//                  and turns t-links into excess / sink capacity (Graph::add_tweights keeps
+//                  only the difference).
+//   push-relabel   lock-free preflow push (one thread per site, agent-scope atomics on
+//                  excess and residual capacities, heights written only by their owner),
+//                  interleaved with exact global relabelling (chaotic min-relaxation from
+//                  the sink to a fixed point).  Finished when, right after a global
+//                  relabel, no site with positive excess can still reach the sink.
+//   cut read-out   the sites that cannot reach the sink in the residual graph
+//                  (height == n after the final relabel) are the SOURCE side and take
+//                  alpha (var 0, :429-433).  This is BK's what_segment rule (free nodes
+//                  default to SOURCE, graph.h:478-488) = the unique minimal sink side of
+//                  any maximum (pre)flow, so labels are solver-independent (SURVEY A-1).
+//   k_delta/apply  accept iff the total energy strictly decreases (:1259,1273),
+//                  decided on the device from the int64 energy difference.
+// A cycle ends with k_energy; the loop stops when the energy is unchanged (:1045).
+//
+// Roofline: irregular, latency/atomic bound (no dense tile anywhere); reported as
+// moves/s and launches per move, not as a bandwidth fraction.
+
+#include "mh_kernels.hpp"
+
+namespace mh {
+
+enum { F_ACTIVE = 0, F_CHANGED = 1, F_EXCESS_NODES = 2, F_ACCEPTED = 3, F_OVERFLOW = 4, F_COUNT = 8 };
+enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_COUNT = 4 };
+
+#define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__global__ void __launch_bounds__(256)
+k_init_labeling(const int* __restrict__ cost, int L, int n, const int* __restrict__ init,
+                int* __restrict__ label, int* __restrict__ cur_cost)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int l = init ? init[i] : 0;
+    label[i] = l;
+    cur_cost[i] = cost[(size_t)i * L + l];        // updateLabelingDataCosts, :445-451
+}
+
+// solveSpecialCases (:470-491): no neighbours at all -> per-site argmin, first minimum wins.
+__global__ void __launch_bounds__(256)
+k_argmin_labels(const int* __restrict__ cost, int L, int n, int* __restrict__ label,
+                long long* __restrict__ acc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    long long mine = 0;
+    if (i < n) {
+        int best = 0, bc = cost[(size_t)i * L];
+        for (int l = 1; l < L; ++l) {
+            const int c = cost[(size_t)i * L + l];
+            if (c < bc) { bc = c; best = l; }
+        }
+        label[i] = best;
+        mine = bc;
+    }
+    __shared__ long long s[256];
+    s[threadIdx.x] = mine;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd((unsigned long long*)&acc[A_ENERGY], (unsigned long long)s[0]);
+}
+
+__global__ void __launch_bounds__(256)
+k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
+             const int* __restrict__ label, const int* __restrict__ cur_cost,
+             int* __restrict__ cap, int* __restrict__ excess, int* __restrict__ sink_cap,
+             int* __restrict__ flags, long long* __restrict__ acc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const int li = label[i];
+    const int k0 = g.rowptr[i], k1 = g.rowptr[i + 1];
+    if (li == alpha) {
+        excess[i] = 0;
+        sink_cap[i] = 0;
+        for (int k = k0; k < k1; ++k) cap[k] = 0;
+        return;
+    }
+    long long S = cur_cost[i];
+    const long long K = cost[(size_t)i * L + alpha];
+    for (int k = k0; k < k1; ++k) {
+        const int j = g.col[k];
+        const int wk = g.w[k] * potts;
+        const int lj = label[j];
+        if (lj == alpha) { S += wk; cap[k] = 0; }
+        else if (j < i) { if (li != lj) S += wk; cap[k] = wk; }
+        else { cap[k] = (li == lj) ? wk : 0; }
+    }
+    const long long tr = S - K;
+    if (tr > 0x7fffffffll || -tr > 0x7fffffffll) atomicExch(&flags[F_OVERFLOW], 1);
+    const int ex = tr > 0 ? (int)tr : 0;
+    excess[i] = ex;
+    sink_cap[i] = tr < 0 ? (int)(-tr) : 0;
+    if (ex > 0) {
+        atomicAdd(&flags[F_EXCESS_NODES], 1);
+        atomicAdd((unsigned long long*)&acc[A_EXCESS_SUM], (unsigned long long)ex);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_bfs_init(int n, int alpha, const int* __restrict__ label, const int* __restrict__ sink_cap,
+           int* __restrict__ height)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    height[i] = (label[i] != alpha && sink_cap[i] > 0) ? 1 : n;
+}
+
+// Chaotic min-relaxation towards exact residual distances to the sink.  Values are
+// always upper bounds realised by residual paths and only decrease, so any schedule
+// converges to the BFS distances; `changed` is raised when a launch lowered anything.
+template <int ROUNDS>
+__global__ void __launch_bounds__(256)
+k_bfs_relax(Graph g, int alpha, const int* __restrict__ label, const int* __restrict__ cap,
+            int* height, int* __restrict__ flags)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= g.n) return;
+    if (label[u] == alpha) return;
+    const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
+    int hu = height[u];
+    bool any = false;
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (hu <= 1) break;
+        int best = hu;
+        for (int k = k0; k < k1; ++k) {
+            if (cap[k] > 0) {
+                const int hv = LD(&height[g.col[k]]) + 1;
+                if (hv < best) best = hv;
+            }
+        }
+        if (best < hu) {
+            hu = best;
+            ST(&height[u], hu);
+            any = true;
+        }
+    }
+    if (any) flags[F_CHANGED] = 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_count_active(int n, const int* __restrict__ excess, const int* __restrict__ height,
+               int* __restrict__ flags)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = (i < n) && excess[i] > 0 && height[i] < n;
+    const unsigned long long b = __ballot(act);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&flags[F_ACTIVE], __popcll(b));
+}
+
+// Lock-free push-relabel (Hong's formulation): the owner thread of u is the only one
+// that lowers excess[u], lowers cap[u->*], touches sink_cap[u] or writes height[u]; other
+// threads only ADD to excess[u] and to cap[u->*] (reverse arcs of their pushes).
+template <int CYCLES>
+__global__ void __launch_bounds__(256)
+k_push_relabel(Graph g, int alpha, const int* __restrict__ label, int* cap, int* excess,
+               int* __restrict__ sink_cap, int* height)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= g.n) return;
+    if (label[u] == alpha) return;
+    const int n = g.n;
+    const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
+    int hu = height[u];
+    for (int cyc = 0; cyc < CYCLES; ++cyc) {
+        if (hu >= n) break;
+        int e = LD(&excess[u]);
+        if (e <= 0) continue;
+        const int sc = sink_cap[u];
+        if (sc > 0) {                               // t-link: h(t) = 0, h(u) = 1
+            const int d = e < sc ? e : sc;
+            sink_cap[u] = sc - d;
+            atomicSub(&excess[u], d);
+            e -= d;
+            if (e == 0) continue;
+        }
+        int hmin = 0x7fffffff, kmin = -1;
+        for (int k = k0; k < k1; ++k) {
+            if (LD(&cap[k]) > 0) {
+                const int hv = LD(&height[g.col[k]]);
+                if (hv < hmin) { hmin = hv; kmin = k; }
+            }
+        }
+        if (kmin < 0) { hu = n; ST(&height[u], hu); break; }     // no way out at all
+        if (hu > hmin) {
+            const int c = LD(&cap[kmin]);
+            const int d = e < c ? e : c;
+            atomicSub(&cap[kmin], d);
+            atomicAdd(&cap[g.rev[kmin]], d);
+            atomicSub(&excess[u], d);
+            atomicAdd(&excess[g.col[kmin]], d);
+        } else {
+            hu = hmin + 1;
+            if (hu > n) hu = n;
+            ST(&height[u], hu);
+        }
+    }
+}
+
+// Energy difference of the candidate labeling (sites with height == n take alpha).
+__global__ void __launch_bounds__(256)
+k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
+        const int* __restrict__ label, const int* __restrict__ cur_cost,
+        const int* __restrict__ height, long long* __restrict__ acc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    long long mine = 0;
+    if (i < g.n) {
+        const int oi = label[i];
+        const int ni = (oi != alpha && height[i] >= g.n) ? alpha : oi;
+        if (ni != oi) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
+        for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) {
+            const int j = g.col[k];
+            if (j < i) {
+                const int oj = label[j];
+                const int nj = (oj != alpha && height[j] >= g.n) ? alpha : oj;
+                const int dn = (ni != nj) - (oi != oj);
+                mine += (long long)dn * g.w[k] * potts;
+            }
+        }
+    }
+    __shared__ long long s[256];
+    s[threadIdx.x] = mine;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s[0] != 0)
+        atomicAdd((unsigned long long*)&acc[A_DELTA], (unsigned long long)s[0]);
+}
+
+__global__ void __launch_bounds__(256)
+k_apply(int n, const int* __restrict__ cost, int L, int alpha, int* __restrict__ label,
+        int* __restrict__ cur_cost, const int* __restrict__ height,
+        const long long* __restrict__ acc, int* __restrict__ flags)
+{
+    if (acc[A_DELTA] >= 0) return;                   // strict decrease only (:1259)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) flags[F_ACCEPTED] += 1;
+    if (i >= n) return;
+    if (label[i] != alpha && height[i] >= n) {       // applyNewLabeling, :423-441
+        label[i] = alpha;
+        cur_cost[i] = cost[(size_t)i * L + alpha];
+    }
+}
+
+// compute_energy = data + smooth (:953-956; giveSmoothEnergyInternal :267-286)
+__global__ void __launch_bounds__(256)
+k_energy(Graph g, int potts, const int* __restrict__ label, const int* __restrict__ cur_cost,
+         long long* __restrict__ acc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    long long mine = 0;
+    if (i < g.n) {
+        mine = cur_cost[i];
+        const int li = label[i];
+        for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) {
+            const int j = g.col[k];
+            if (j < i && label[j] != li) mine += (long long)g.w[k] * potts;
+        }
+    }
+    __shared__ long long s[256];
+    s[threadIdx.x] = mine;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd((unsigned long long*)&acc[A_ENERGY], (unsigned long long)s[0]);
+}
+
+hipError_t launch_init_labeling(const int* cost, int L, int n, const int* init, int* label,
+                                int* cur_cost, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_labeling, dim3((n + 255) / 256), dim3(256), 0, s, cost, L, n, init,
+                       label, cur_cost);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long long* acc,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL(k_argmin_labels, dim3((n + 255) / 256), dim3(256), 0, s, cost, L, n, label,
+                       acc);
+    return hipGetLastError();
+}
+
+#define RET_IF(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+static hipError_t fetch(ExpandWork& w, hipStream_t s)
+{
+    RET_IF(hipMemcpyAsync(w.h_flags, w.flags, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
+    RET_IF(hipMemcpyAsync(w.h_acc, w.acc, sizeof(long long) * A_COUNT, hipMemcpyDeviceToHost, s));
+    return hipStreamSynchronize(s);
+}
+
+static hipError_t total_energy(const Graph& g, int potts, ExpandWork& w, long long* out,
+                               hipStream_t s)
+{
+    const dim3 grid((g.n + 255) / 256), blk(256);
+    RET_IF(hipMemsetAsync(&w.acc[A_ENERGY], 0, sizeof(long long), s));
+    hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.acc);
+    RET_IF(hipGetLastError());
+    RET_IF(fetch(w, s));
+    *out = w.h_acc[A_ENERGY];
+    return hipSuccess;
+}
+
+hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, ExpandWork& w,
+                         int max_cycles, ExpandStats* st, hipStream_t s)
+{
+    const dim3 grid((g.n + 255) / 256), blk(256);
+    ExpandStats stats = {};
+    RET_IF(hipMemsetAsync(w.flags, 0, sizeof(int) * F_COUNT, s));
+    RET_IF(hipMemsetAsync(w.acc, 0, sizeof(long long) * A_COUNT, s));
+
+    if (g.nnz == 0) {                                  // solveSpecialCases, :470-491
+        RET_IF(launch_argmin_labels(cost, L, g.n, w.label, w.acc, s));
+        RET_IF(fetch(w, s));
+        stats.energy = w.h_acc[A_ENERGY];
+        if (st) *st = stats;
+        return hipSuccess;
+    }
+
+    long long energy = 0, old_energy = 0;
+    RET_IF(total_energy(g, potts, w, &energy, s));     // :1036
+    for (int cycle = 1; cycle <= max_cycles; ++cycle) {
+        old_energy = energy;
+        for (int alpha = 0; alpha < L; ++alpha) {
+            ++stats.moves;
+            RET_IF(hipMemsetAsync(w.flags, 0, sizeof(int) * 3, s));     // ACTIVE, CHANGED, EXCESS_NODES
+            RET_IF(hipMemsetAsync(w.acc, 0, sizeof(long long), s));     // DELTA
+            hipLaunchKernelGGL(k_move_setup, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
+                               w.cur_cost, w.cap, w.excess, w.sink_cap, w.flags, w.acc);
+            RET_IF(hipGetLastError());
+            RET_IF(fetch(w, s));
+            if (w.h_flags[F_OVERFLOW] || w.h_acc[A_EXCESS_SUM] > 0x7fffffffll) {
+                if (st) { stats.energy = -1; *st = stats; }
+                return hipErrorInvalidValue;           // int32 energy terms would overflow
+            }
+            RET_IF(hipMemsetAsync(&w.acc[A_EXCESS_SUM], 0, sizeof(long long), s));
+            // No excess anywhere: max-flow is 0, after == before, the move is rejected (:1259).
+            if (w.h_flags[F_EXCESS_NODES] == 0) continue;
+
+            for (int round = 0; round < 100000; ++round) {
+                // exact global relabel
+                hipLaunchKernelGGL(k_bfs_init, grid, blk, 0, s, g.n, alpha, w.label, w.sink_cap,
+                                   w.height);
+                for (;;) {
+                    RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
+                    for (int b = 0; b < 4; ++b) {
+                        if (b == 3) RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
+                        hipLaunchKernelGGL((k_bfs_relax<4>), grid, blk, 0, s, g, alpha, w.label,
+                                           w.cap, w.height, w.flags);
+                        ++stats.bfs_launches;
+                    }
+                    RET_IF(hipGetLastError());
+                    RET_IF(fetch(w, s));
+                    if (!w.h_flags[F_CHANGED]) break;
+                }
+                RET_IF(hipMemsetAsync(&w.flags[F_ACTIVE], 0, sizeof(int), s));
+                hipLaunchKernelGGL(k_count_active, grid, blk, 0, s, g.n, w.excess, w.height, w.flags);
+                RET_IF(hipGetLastError());
+                RET_IF(fetch(w, s));
+                if (w.h_flags[F_ACTIVE] == 0) break;
+                for (int b = 0; b < 8; ++b) {
+                    hipLaunchKernelGGL((k_push_relabel<8>), grid, blk, 0, s, g, alpha, w.label,
+                                       w.cap, w.excess, w.sink_cap, w.height);
+                    ++stats.pr_launches;
+                }
+                RET_IF(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_delta, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
+                               w.cur_cost, w.height, w.acc);
+            hipLaunchKernelGGL(k_apply, grid, blk, 0, s, g.n, cost, L, alpha, w.label, w.cur_cost,
+                               w.height, w.acc, w.flags);
+            RET_IF(hipGetLastError());
+        }
+        RET_IF(total_energy(g, potts, w, &energy, s));
+        stats.cycles = cycle;
+        if (energy == old_energy) break;               // :1045
+    }
+    stats.energy = energy;
+    stats.accepted = w.h_flags[F_ACCEPTED];
+    if (st) *st = stats;
+    return hipSuccess;
+}
+
+} // namespace mh

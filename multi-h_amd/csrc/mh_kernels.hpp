@@ -1,0 +1,95 @@
+// mh_kernels.hpp — private launch interface between the C-ABI layer (capi.hip)
+// and the gfx950 kernels.  Nothing here is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mh {
+
+// Correspondences resident in HBM as struct-of-arrays (coalesced 16-B loads).
+struct Points {
+    const double* x1;
+    const double* y1;
+    const double* x2;
+    const double* y2;
+    int n;
+};
+
+struct Affines {            // a11 a12 a21 a22, SoA
+    const double* a11;
+    const double* a12;
+    const double* a21;
+    const double* a22;
+};
+
+struct Epipolar {           // passed by value to kernels
+    double F[9];
+    double ex, ey;
+};
+
+// Leading dimension (in doubles) of the residual matrix rows: rows start 128-B aligned.
+inline long long residual_ld(int n) { return ((long long)n + 15) & ~15ll; }
+
+// --- residual.hip -----------------------------------------------------------
+// variant: 0 default; tuning knob for bench sweeps (see residual.hip).
+hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
+                           long long ldr, int* counts, int variant, hipStream_t s);
+hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
+                        const unsigned char* mask, int* counts, hipStream_t s);
+hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
+                                   int label_value, int* labels, hipStream_t s);
+hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,
+                          double* min_eig, hipStream_t s);
+
+// --- dlt4.hip ---------------------------------------------------------------
+hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,
+                       int* idx_out, double* H_out, hipStream_t s);
+
+// --- datacost.hip -----------------------------------------------------------
+hipError_t launch_data_cost(const Points& p, const double* H, int Nh, double lambda, double thr2,
+                            int* cost, hipStream_t s);
+
+// --- reestimate.hip ---------------------------------------------------------
+hipError_t launch_reestimate(const Points& p, const Affines& a, const int* labels, int Nh,
+                             const Epipolar& ep, double* H, int* counts, hipStream_t s);
+
+// --- expand.hip -------------------------------------------------------------
+struct Graph {              // symmetric weighted CSR in HBM
+    const int* rowptr;      // n+1
+    const int* col;         // nnz
+    const int* w;           // nnz  multiplicity mult(i,j)
+    const int* rev;         // nnz  index of the reverse arc
+    int n, nnz;
+};
+
+struct ExpandWork {         // scratch owned by the engine
+    int* label;             // n   current labeling (GCO numbering)
+    int* cur_cost;          // n   cost[i][label[i]]
+    int* cap;               // nnz residual capacities
+    int* excess;            // n
+    int* sink_cap;          // n
+    int* height;            // n
+    int* flags;             // device control words (see expand.hip)
+    long long* acc;         // device 64-bit accumulators
+    int* h_flags;           // pinned host mirror of flags
+    long long* h_acc;       // pinned host mirror of acc
+};
+
+struct ExpandStats {
+    int cycles;
+    long long energy;
+    int moves, accepted;
+    long long pr_launches, bfs_launches;
+};
+
+hipError_t run_expansion(const Graph& g, const int* cost /* n x L */, int L, int potts,
+                         ExpandWork& w, int max_cycles, ExpandStats* st, hipStream_t s);
+hipError_t launch_init_labeling(const int* cost, int L, int n, const int* init_or_null_dev,
+                                int* label, int* cur_cost, hipStream_t s);
+hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long long* acc,
+                                hipStream_t s);
+
+// --- knn.hip ----------------------------------------------------------------
+hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, hipStream_t s);
+
+} // namespace mh

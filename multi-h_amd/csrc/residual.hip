@@ -1,0 +1,282 @@
+// residual.hip — forward-transfer residual matrix, inlier scoring, single-model
+// labelling and the collinearity moments, for gfx950 (MI355X, wave64).
+//
+// Arithmetic (bit-exact with the reference's FP64 expression, compiled with
+// -ffp-contract=off so every operation rounds once, in the reference's
+// association order, M/MultiH.cpp:434-441 / :491-498 / :755-762):
+//     s  = (h6*x + h7*y) + h8
+//     u  = ((h0*x + h1*y) + h2) / s        v = ((h3*x + h4*y) + h5) / s
+//     d2 = (x2-u)^2 + (y2-v)^2             inlier  <=>  d2 < thr^2   (strict)
+//
+// k_residual — the HBM-bound kernel of the roofline run.
+//   Work split: one workgroup (256 threads = 4 waves) owns MC consecutive
+//   models and sweeps ALL points, so the per-model inlier count is finished
+//   inside the workgroup (ballot + s_bcnt1 per wave, 4-way LDS add at the end)
+//   with no global atomics.  Each lane holds PPL points in registers; for every
+//   model the wave reads the 9 coefficients from LDS (staged once per
+//   workgroup, broadcast reads), evaluates PPL residuals per lane and issues 16-B
+//   stores so that one wave-instruction writes 1 KiB of one row of R, eight
+//   whole 128-B lines.  Rows start 128-B aligned (ld = N rounded up to 16).
+//   The correspondence array (32 B/point, 1.6 MB at N = 50k) is re-read once
+//   per workgroup from the XCD's 4 MiB L2, where it stays resident on every
+//   XCD; HBM sees the 8 B/pair store stream only.
+//   Algorithmic bytes per launch: 8*N*M (R) + 32*N + 72*M + 4*M.
+// k_score — same sweep without the stores (FP64-VALU/division bound).
+
+#include "mh_kernels.hpp"
+#include "mh_device.hpp"
+
+namespace mh {
+
+// PPL = points per lane (even), MC = models per workgroup.
+// WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
+// NT: non-temporal stores for the R stream.
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT>
+__global__ void __launch_bounds__(256)
+k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
+           const double* __restrict__ x2, const double* __restrict__ y2, int N,
+           const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
+           long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+           int psplit)
+{
+    constexpr int CH = PPL / 2;                 // 16-B chunks per lane
+    constexpr int WAVE_PTS = 64 * PPL;          // points per wave per tile
+    constexpr int TILE = 4 * WAVE_PTS;          // points per workgroup per tile
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * MC;
+
+    // Stage this workgroup's MC x 9 coefficients in LDS once; the sweep reads them
+    // back with wave-uniform (broadcast) ds_reads.  Keeping them in SGPRs instead
+    // makes the compiler hoist 18*MC scalar registers out of the loop and spill.
+    __shared__ double s_h[MC * 9];
+    for (int i = threadIdx.x; i < MC * 9; i += 256) {
+        const size_t g = (size_t)m0 * 9 + i;
+        s_h[i] = (g < (size_t)M * 9) ? H[g] : 0.0;
+    }
+    __syncthreads();
+
+    int cnt = 0;                                // lane mi of each wave counts model m0+mi
+    static_assert(MC <= 64, "one counting lane per model");
+
+    for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
+        double px[PPL], py[PPL], qx[PPL], qy[PPL];
+        bool ok[PPL];
+        const int wbase = base + wave * WAVE_PTS;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int n = wbase + c * 128 + lane * 2;
+            if (n + 1 < N) {
+                const double2 a = *reinterpret_cast<const double2*>(x1 + n);
+                const double2 b = *reinterpret_cast<const double2*>(y1 + n);
+                const double2 cc = *reinterpret_cast<const double2*>(x2 + n);
+                const double2 d = *reinterpret_cast<const double2*>(y2 + n);
+                px[2 * c] = a.x; px[2 * c + 1] = a.y;
+                py[2 * c] = b.x; py[2 * c + 1] = b.y;
+                qx[2 * c] = cc.x; qx[2 * c + 1] = cc.y;
+                qy[2 * c] = d.x; qy[2 * c + 1] = d.y;
+                ok[2 * c] = true; ok[2 * c + 1] = true;
+            } else if (n < N) {
+                px[2 * c] = x1[n]; py[2 * c] = y1[n]; qx[2 * c] = x2[n]; qy[2 * c] = y2[n];
+                px[2 * c + 1] = 0.0; py[2 * c + 1] = 0.0; qx[2 * c + 1] = 0.0; qy[2 * c + 1] = 0.0;
+                ok[2 * c] = true; ok[2 * c + 1] = false;
+            } else {
+                px[2 * c] = 0.0; py[2 * c] = 0.0; qx[2 * c] = 0.0; qy[2 * c] = 0.0;
+                px[2 * c + 1] = 0.0; py[2 * c + 1] = 0.0; qx[2 * c + 1] = 0.0; qy[2 * c + 1] = 0.0;
+                ok[2 * c] = false; ok[2 * c + 1] = false;
+            }
+            if (MASK) {
+                if (ok[2 * c]) ok[2 * c] = mask[n] != 0;
+                if (ok[2 * c + 1]) ok[2 * c + 1] = mask[n + 1] != 0;
+            }
+        }
+
+        // Not unrolled on purpose: an unrolled model loop lets LICM hoist all MC*9
+        // coefficients out of the point sweep (288 registers at MC = 16).
+#pragma unroll 1
+        for (int mi = 0; mi < MC; ++mi) {
+            const int m = m0 + mi;
+            if (m < M) {                                   // wave-uniform
+                const double* h = s_h + 9 * mi;
+                const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5],
+                             h6 = h[6], h7 = h[7], h8 = h[8];
+                int c_m = 0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const double d0 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                             py[2 * c], qx[2 * c], qy[2 * c]);
+                    const double d1 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                             py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
+                    if (WRITE_R) {
+                        const int n = wbase + c * 128 + lane * 2;
+                        double* dstp = R + (size_t)m * ldr + n;
+                        if (n + 1 < N) {
+                            if (NT) {
+                                __builtin_nontemporal_store(d0, dstp);
+                                __builtin_nontemporal_store(d1, dstp + 1);
+                            } else {
+                                *reinterpret_cast<double2*>(dstp) = make_double2(d0, d1);
+                            }
+                        } else if (n < N) {
+                            dstp[0] = d0;
+                        }
+                    }
+                    c_m += __popcll(__ballot(ok[2 * c] && d0 < thr2));
+                    c_m += __popcll(__ballot(ok[2 * c + 1] && d1 < thr2));
+                }
+                cnt += (lane == mi) ? c_m : 0;
+            }
+        }
+    }
+
+    __shared__ int s_cnt[4][MC];
+    if (lane < MC) s_cnt[wave][lane] = cnt;
+    __syncthreads();
+    if (threadIdx.x < MC && m0 + (int)threadIdx.x < M) {
+        const int t = threadIdx.x;
+        const int c = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+        if (psplit == 1) counts[m0 + t] = c;
+        else atomicAdd(&counts[m0 + t], c);           // integer: order-independent
+    }
+}
+
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT>
+static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
+                            long long ldr, int* counts, const unsigned char* mask, hipStream_t s)
+{
+    if (M <= 0 || p.n <= 0) return hipSuccess;
+    const int gx = (M + MC - 1) / MC;
+    const int tile = 256 * PPL;
+    const int ntiles = (p.n + tile - 1) / tile;
+    int psplit = 1;
+    if (gx < 1024) {                       // few models: split the point sweep to fill the chip
+        psplit = (2048 + gx - 1) / gx;
+        if (psplit > ntiles) psplit = ntiles;
+        if (psplit < 1) psplit = 1;
+    }
+    if (psplit > 1) {
+        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(gx, psplit);
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT>), grid, dim3(256), 0, s, p.x1, p.y1,
+                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit);
+    return hipGetLastError();
+}
+
+hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
+                           long long ldr, int* counts, int variant, hipStream_t s)
+{
+    switch (variant) {
+    case 1: return launch_rs<2, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 2: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 3: return launch_rs<2, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 4: return launch_rs<2, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    default: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    }
+}
+
+hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
+                        const unsigned char* mask, int* counts, hipStream_t s)
+{
+    if (mask) return launch_rs<2, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
+    return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+}
+
+// ComputeInliersOfHomography, M/MultiH.cpp:743-768.
+__global__ void __launch_bounds__(256)
+k_inliers_of_model(const double* __restrict__ x1, const double* __restrict__ y1,
+                   const double* __restrict__ x2, const double* __restrict__ y2, int N,
+                   const double* __restrict__ H, int idx, double thr2, int label_value,
+                   int* __restrict__ labels)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double* h = H + 9 * (size_t)idx;
+    const double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n],
+                             x2[n], y2[n]);
+    if (d2 < thr2) labels[n] = label_value;
+}
+
+hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
+                                   int label_value, int* labels, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_inliers_of_model, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1,
+                       p.x2, p.y2, p.n, H, idx, thr2, label_value, labels);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Collinearity moments (M/MultiH.cpp:446-463).  One workgroup per model.  The
+// FP64 sums use the engine's deterministic order: lane t of 256 adds its points
+// t, t+256, ... in increasing order, then a binary tree v[t] += v[t+s],
+// s = 128..1.  Thread 0 finishes with a cyclic-Jacobi 3x3 eigen solve.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_moments(const double* __restrict__ x1, const double* __restrict__ y1,
+          const double* __restrict__ x2, const double* __restrict__ y2, int N,
+          const double* __restrict__ H, double thr2, double* __restrict__ moments,
+          double* __restrict__ min_eig)
+{
+    const int m = blockIdx.x;
+    const int t = threadIdx.x;
+    const double* h = H + 9 * (size_t)m;
+    const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6],
+                 h7 = h[7], h8 = h[8];
+    double acc[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+    int cnt = 0;
+    for (int n = t; n < N; n += 256) {
+        const double x = x1[n], y = y1[n];
+        const double d2 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, x, y, x2[n], y2[n]);
+        if (d2 < thr2) {
+            acc[0] = acc[0] + x;
+            acc[1] = acc[1] + y;
+            acc[2] = acc[2] + x * x;
+            acc[3] = acc[3] + x * y;
+            acc[4] = acc[4] + y * y;
+            ++cnt;
+        }
+    }
+    __shared__ double sv[256][5];
+    __shared__ int sc[256];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sv[t][k] = acc[k];
+    sc[t] = cnt;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sv[t][k] = sv[t][k] + sv[t + s][k];
+            sc[t] += sc[t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        double* mo = moments + 6 * (size_t)m;
+        const double c = (double)sc[0];
+        mo[0] = c; mo[1] = sv[0][0]; mo[2] = sv[0][1]; mo[3] = sv[0][2]; mo[4] = sv[0][3];
+        mo[5] = sv[0][4];
+        if (min_eig) {
+            double a[9] = { sv[0][2], sv[0][3], sv[0][0], sv[0][3], sv[0][4], sv[0][1],
+                            sv[0][0], sv[0][1], c };
+            double v[9], d[3];
+            jacobi_sym_dev(3, a, v, d);
+            double mn = d[0];
+            if (d[1] < mn) mn = d[1];
+            if (d[2] < mn) mn = d[2];
+            min_eig[m] = mn;
+        }
+    }
+}
+
+hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,
+                          double* min_eig, hipStream_t s)
+{
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_moments, dim3(M), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, thr2,
+                       moments, min_eig);
+    return hipGetLastError();
+}
+
+} // namespace mh

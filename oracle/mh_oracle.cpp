@@ -1,0 +1,864 @@
+// mh_oracle.cpp — CPU ORACLE for the Multi-H propose-score-label hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+// `cpu_baseline` leg and __graft_entry__.smoke() may load it, and only as
+// the checker.  The shipped engine (multi-h_amd/csrc) never links or calls
+// anything in this directory.
+//
+// It restates, in plain scalar FP64 / int32 C++, the arithmetic of the
+// reference (danini/multi-h) for the path BASELINE.json names.  "M/" below is
+// /root/reference/MultiH/MultiH/.  Every function cites the lines it follows.
+//
+// Parity status of each piece:
+//   residual / score / data cost / Potts / alpha-expansion labels : PINNED
+//       - formulas restated line by line from M/MultiH.cpp,
+//       - known-answer constants from the harness defaults (4901/9802/200/50),
+//       - alpha-expansion labels+energies checked against the reference's own
+//         GCoptimization sources compiled unmodified (oracle/_ref, see Makefile)
+//         and against fixtures generated from them (tests/golden).
+//   HAF non-minimal re-estimation, collinearity test : formulas pinned to
+//       M/MultiH.cpp:913-989 / :446-463; the symmetric eigen-solver they call
+//       (cv::eigen, OpenCV 3.1.0 core, not under /root/reference) is restated
+//       as a cyclic Jacobi solver -> "parity unpinned at the cv::eigen
+//       boundary"; cross-checked with numpy.linalg.eigh in tests.
+//   4-point DLT, hypothesis sampling : NO reference source exists (only
+//       cv::findHomography call sites) -> "parity unpinned"; this file is the
+//       definition (Hartley-normalised DLT, one-sided Jacobi null space,
+//       splitmix64 counter RNG); cross-checked with numpy.linalg.svd in tests.
+//
+// Build:  g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared (oracle/Makefile)
+// -ffp-contract=off matters: the GPU side is compiled the same way so that
+// every FP64 operation rounds once, in the reference's association order.
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <omp.h>
+
+#define MHO_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------
+// 1. Forward transfer residual, inlier score            
+// ---------------------------------------------------------------------------
+
+// d^2 of one (point, model) pair.  Operation order of M/MultiH.cpp:434-441:
+//   s  = h6*x + h7*y + h8          (left-to-right:  (h6*x + h7*y) + h8)
+//   u  = (h0*x + h1*y + h2) / s ;  v = (h3*x + h4*y + h5) / s
+//   dx = x2 - u ; dy = y2 - v ;    d2 = dx*dx + dy*dy
+// (M/MultiH.cpp:495-496,759-760 compute u - x2 instead; the squares are
+// bit-identical, so one function serves all four copies of the formula.)
+static inline double fwd_d2(const double* h, double x, double y, double x2, double y2)
+{
+    const double s = h[6] * x + h[7] * y + h[8];
+    const double u = (h[0] * x + h[1] * y + h[2]) / s;
+    const double v = (h[3] * x + h[4] * y + h[5]) / s;
+    const double dx = x2 - u;
+    const double dy = y2 - v;
+    return dx * dx + dy * dy;
+}
+
+// Residual matrix R[m*N + n] (model-major), M/MultiH.cpp:432-443 without the
+// threshold.  The reference never stores it; north_star materialises it.
+MHO_API void mho_residual_matrix(const double* x1, const double* y1,
+                                 const double* x2, const double* y2, int N,
+                                 const double* H, int M, double* R)
+{
+    for (int m = 0; m < M; ++m) {
+        const double* h = H + 9 * (size_t)m;
+        double* r = R + (size_t)m * N;
+        for (int n = 0; n < N; ++n) r[n] = fwd_d2(h, x1[n], y1[n], x2[n], y2[n]);
+    }
+}
+
+// Inlier counts, strict '<' (M/MultiH.cpp:441; MultipleHomographies.h:166).
+// mask (optional, may be NULL): only points with mask[n] != 0 are counted.
+MHO_API void mho_score(const double* x1, const double* y1, const double* x2,
+                       const double* y2, int N, const double* H, int M,
+                       double thr2, const unsigned char* mask, int* counts)
+{
+    for (int m = 0; m < M; ++m) {
+        const double* h = H + 9 * (size_t)m;
+        int c = 0;
+        for (int n = 0; n < N; ++n) {
+            if (mask && !mask[n]) continue;
+            if (fwd_d2(h, x1[n], y1[n], x2[n], y2[n]) < thr2) ++c;
+        }
+        counts[m] = c;
+    }
+}
+
+// Same loop, OpenMP over models: the "best-effort CPU" baseline B2 of BASELINE.md
+// (the reference's own loop is serial, M/MultiH.cpp:415-466).  Returns threads used.
+MHO_API int mho_score_mt(const double* x1, const double* y1, const double* x2,
+                         const double* y2, int N, const double* H, int M,
+                         double thr2, int* counts)
+{
+    int threads = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        threads = omp_get_num_threads();
+#pragma omp for schedule(static)
+        for (int m = 0; m < M; ++m) {
+            const double* h = H + 9 * (size_t)m;
+            int c = 0;
+            for (int n = 0; n < N; ++n)
+                if (fwd_d2(h, x1[n], y1[n], x2[n], y2[n]) < thr2) ++c;
+            counts[m] = c;
+        }
+    }
+    return threads;
+}
+
+// ComputeInliersOfHomography, M/MultiH.cpp:743-768: label[i] = idx where the
+// point is an inlier, untouched otherwise.
+MHO_API void mho_inliers_of_homography(const double* x1, const double* y1,
+                                       const double* x2, const double* y2, int N,
+                                       const double* h, double thr2, int idx,
+                                       int* labeling)
+{
+    for (int n = 0; n < N; ++n)
+        if (fwd_d2(h, x1[n], y1[n], x2[n], y2[n]) < thr2) labeling[n] = idx;
+}
+
+// ---------------------------------------------------------------------------
+// 2. PEARL data cost and Potts smoothness               
+// ---------------------------------------------------------------------------
+
+// dataEnergy, M/MultiH.cpp:473-504 with EnergyDataStruct M/MultiH.h:33-46:
+//   lam = 100/lambda ; T = thr2*81/16
+//   l == 0           -> round(lam*T)
+//   d2 < T           -> round(lam*(1 - d2/T))     (A-4: decreasing in d2)
+//   otherwise        -> 2*round(lam*T)
+// round() is C round (half away from zero); the double->int conversion is the
+// implicit one of the reference's `return round(...)` from an int function.
+static inline int data_energy(const double* H, int l, double x, double y,
+                              double x2, double y2, double lam, double T)
+{
+    if (l == 0) return (int)round(lam * T);
+    const double d2 = fwd_d2(H + 9 * (size_t)(l - 1), x, y, x2, y2);
+    if (d2 < T) return (int)round(lam * (1.0 - (d2 / T)));
+    return 2 * (int)round(lam * T);
+}
+
+// cost[n*(Nh+1) + l]  (site-major, the layout GCO's array data cost uses).
+MHO_API void mho_data_cost(const double* x1, const double* y1, const double* x2,
+                           const double* y2, int N, const double* H, int Nh,
+                           double lambda, double thr2, int* cost)
+{
+    const double lam = 100.0 / lambda;        // one_per_energy_lambda, MultiH.h:42
+    const double T = thr2 * 81.0 / 16.0;      // truncated_sqr_threshold, MultiH.h:44
+    const int L = Nh + 1;
+    for (int n = 0; n < N; ++n)
+        for (int l = 0; l < L; ++l)
+            cost[(size_t)n * L + l] = data_energy(H, l, x1[n], y1[n], x2[n], y2[n], lam, T);
+}
+
+// smoothnessEnergy, M/MultiH.cpp:506-511: l1 != l2 ? round(100*lambda) : 0.
+MHO_API int mho_potts(double lambda) { return (int)round(100.0 * lambda); }
+
+// ---------------------------------------------------------------------------
+// 3. Neighbourhood semantics                             
+// ---------------------------------------------------------------------------
+
+// LabelingStep calls setNeighbors(i, j) for EVERY directed hit j != i
+// (M/MultiH.cpp:532-540); each call appends j to i's list and i to j's list
+// (GCoptimization.cpp:1672-1679).  The pair weight seen by the energy is thus
+// mult(i,j) = #[i->j] + #[j->i].  This builds that symmetric weighted CSR.
+struct SymGraph {
+    std::vector<int> rowptr, col, w;
+};
+
+static void build_sym(int N, const int* hit_rowptr, const int* hit_col, SymGraph& g)
+{
+    std::vector<std::vector<int>> adj(N);
+    for (int i = 0; i < N; ++i)
+        for (int k = hit_rowptr[i]; k < hit_rowptr[i + 1]; ++k) {
+            const int j = hit_col[k];
+            if (j == i) continue;             // M/MultiH.cpp:537
+            adj[i].push_back(j);
+            adj[j].push_back(i);
+        }
+    g.rowptr.assign(N + 1, 0);
+    g.col.clear();
+    g.w.clear();
+    for (int i = 0; i < N; ++i) {
+        std::sort(adj[i].begin(), adj[i].end());
+        for (size_t k = 0; k < adj[i].size();) {
+            size_t e = k;
+            while (e < adj[i].size() && adj[i][e] == adj[i][k]) ++e;
+            g.col.push_back(adj[i][k]);
+            g.w.push_back((int)(e - k));
+            k = e;
+        }
+        g.rowptr[i + 1] = (int)g.col.size();
+    }
+}
+
+// Exposed so tests can check the engine's own graph builder against it.
+// Returns nnz; if out arrays are NULL only counts.
+MHO_API int mho_build_sym_graph(int N, const int* hit_rowptr, const int* hit_col,
+                                int* rowptr, int* col, int* w)
+{
+    SymGraph g;
+    build_sym(N, hit_rowptr, hit_col, g);
+    if (rowptr) std::copy(g.rowptr.begin(), g.rowptr.end(), rowptr);
+    if (col) std::copy(g.col.begin(), g.col.end(), col);
+    if (w) std::copy(g.w.begin(), g.w.end(), w);
+    return (int)g.col.size();
+}
+
+// ---------------------------------------------------------------------------
+// 4. alpha-expansion                                     
+// ---------------------------------------------------------------------------
+// Restates GCoptimization::expansion's standard-cycle branch
+// (GCoptimization.cpp:1032-1049), oneExpansionIteration (:1278-1289),
+// alpha_expansion (:1212-1274), the graph construction of
+// setupDataCostsExpansion (:336-342) / setupSmoothCostsExpansion (:346-373)
+// through Energy::add_term1/add_term2 (energy.h:204-253), and the cut read-out
+// get_var == what_segment (graph.h:478-488): a node is SINK (var 1, keeps its
+// label) iff it can reach t in the final residual graph, SOURCE (var 0, takes
+// alpha) otherwise (SURVEY A-1).  The max-flow itself is Dinic's algorithm —
+// any exact max-flow yields the same canonical cut, which is what the
+// reference comparison in tests/test_oracle_vs_ref.py demonstrates.
+// All energies are int32 as in the reference (GCoptimization.h:166-170).
+
+namespace {
+
+struct Dinic {
+    int n;
+    std::vector<int> head, nxt, to, cap, level, it;
+    explicit Dinic(int n_) : n(n_), head(n_, -1) {}
+    void add_edge(int u, int v, int c, int rc)
+    {
+        to.push_back(v); cap.push_back(c); nxt.push_back(head[u]); head[u] = (int)to.size() - 1;
+        to.push_back(u); cap.push_back(rc); nxt.push_back(head[v]); head[v] = (int)to.size() - 1;
+    }
+    bool bfs(int s, int t)
+    {
+        level.assign(n, -1);
+        std::vector<int> q; q.reserve(n);
+        q.push_back(s); level[s] = 0;
+        for (size_t qi = 0; qi < q.size(); ++qi) {
+            int u = q[qi];
+            for (int e = head[u]; e >= 0; e = nxt[e])
+                if (cap[e] > 0 && level[to[e]] < 0) { level[to[e]] = level[u] + 1; q.push_back(to[e]); }
+        }
+        return level[t] >= 0;
+    }
+    // iterative DFS augment
+    long long maxflow(int s, int t)
+    {
+        long long flow = 0;
+        std::vector<int> path_e;
+        while (bfs(s, t)) {
+            it = head;
+            for (;;) {
+                // find one augmenting path in the level graph
+                path_e.clear();
+                int u = s;
+                bool found = false;
+                for (;;) {
+                    if (u == t) { found = true; break; }
+                    int& e = it[u];
+                    while (e >= 0 && !(cap[e] > 0 && level[to[e]] == level[u] + 1)) e = nxt[e];
+                    if (e >= 0) { path_e.push_back(e); u = to[e]; }
+                    else {
+                        if (path_e.empty()) break;
+                        level[u] = -1;          // dead end
+                        int pe = path_e.back(); path_e.pop_back();
+                        u = to[pe ^ 1];
+                        it[u] = nxt[it[u]];
+                    }
+                }
+                if (!found) break;
+                int f = INT32_MAX;
+                for (int e : path_e) f = std::min(f, cap[e]);
+                for (int e : path_e) { cap[e] -= f; cap[e ^ 1] += f; }
+                flow += f;
+            }
+        }
+        return flow;
+    }
+};
+
+struct Expander {
+    int N, L;
+    const int* cost;             // N*L
+    const SymGraph* g;
+    int potts;
+    std::vector<int> label, curCost, lookup;
+
+    int smooth_energy() const     // giveSmoothEnergyInternal, GCoptimization.cpp:267-286
+    {
+        int e = 0;
+        for (int i = 0; i < N; ++i)
+            for (int k = g->rowptr[i]; k < g->rowptr[i + 1]; ++k) {
+                int j = g->col[k];
+                if (j < i && label[i] != label[j]) e += g->w[k] * potts;
+            }
+        return e;
+    }
+    int data_energy_sum() const
+    {
+        int e = 0;
+        for (int i = 0; i < N; ++i) e += curCost[i];
+        return e;
+    }
+    int compute_energy() const { return data_energy_sum() + smooth_energy(); } // :953-956
+
+    bool alpha_expansion(int alpha)          // GCoptimization.cpp:1212-1274
+    {
+        std::vector<int> active;
+        for (int i = 0; i < N; ++i) if (label[i] != alpha) active.push_back(i); // :324-332
+        const int size = (int)active.size();
+        if (size == 0) return false;
+        for (int v = 0; v < size; ++v) lookup[active[v]] = v;
+
+        // t-link accumulators: add_tweights(x, cap_source, cap_sink)
+        std::vector<long long> srcCap(size, 0), snkCap(size, 0);
+        long long before = 0;                 // m_beforeExpansionEnergy
+        Dinic G(size + 2);
+        const int S = size, T = size + 1;
+        // data terms: add_term1(i, E0 = cost(site,alpha), E1 = current cost)  (:336-342)
+        for (int v = 0; v < size; ++v) {
+            const int site = active[v];
+            const int e0 = cost[(size_t)site * L + alpha], e1 = curCost[site];
+            before += e1;
+            srcCap[v] += e1; snkCap[v] += e0;   // add_tweights(x, B=E1, A=E0), energy.h:207
+        }
+        // smooth terms (:346-373), Potts
+        for (int v = size - 1; v >= 0; --v) {
+            const int site = active[v];
+            for (int k = g->rowptr[site]; k < g->rowptr[site + 1]; ++k) {
+                const int nSite = g->col[k], w = g->w[k];
+                if (lookup[nSite] == -1) {
+                    // neighbour already has alpha: term1(E0 = V(alpha,alpha)=0, E1 = V(l_site, alpha))
+                    const int e1 = potts * w;   // l_site != alpha by construction
+                    before += e1;
+                    srcCap[v] += e1;
+                } else if (nSite < site) {
+                    const int u = lookup[nSite];
+                    const int e00 = 0, e01 = potts * w, e10 = potts * w;
+                    const int e11 = (label[site] != label[nSite]) ? potts * w : 0;
+                    before += e11;
+                    // add_term2(x=v, y=u, A=e00, B=e01, C=e10, D=e11), energy.h:211-253
+                    srcCap[v] += e11; snkCap[v] += e00;
+                    const int B = e01 - e00, C = e10 - e11;   // both >= 0 for Potts
+                    G.add_edge(v, u, B, C);
+                }
+            }
+        }
+        for (int v = 0; v < size; ++v) {
+            // Graph::add_tweights keeps only the difference and books min() as flow
+            const long long m = std::min(srcCap[v], snkCap[v]);
+            const long long s = srcCap[v] - m, t = snkCap[v] - m;
+            if (s > 0) G.add_edge(S, v, (int)s, 0);
+            if (t > 0) G.add_edge(v, T, (int)t, 0);
+        }
+        long long constFlow = 0;
+        for (int v = 0; v < size; ++v) constFlow += std::min(srcCap[v], snkCap[v]);
+        const long long after = constFlow + G.maxflow(S, T);      // e.minimize()
+
+        const bool accept = after < before;                       // strict, :1259
+        if (accept) {
+            // canonical cut: reverse BFS from T over arcs with residual capacity
+            std::vector<char> reachT(size + 2, 0);
+            std::vector<int> q; q.push_back(T); reachT[T] = 1;
+            for (size_t qi = 0; qi < q.size(); ++qi) {
+                int x = q[qi];
+                // arcs y->x with residual cap > 0: for edge e out of x, reverse e^1 goes to[e]->x
+                for (int e = G.head[x]; e >= 0; e = G.nxt[e]) {
+                    int y = G.to[e];
+                    if (!reachT[y] && G.cap[e ^ 1] > 0) { reachT[y] = 1; q.push_back(y); }
+                }
+            }
+            // applyNewLabeling (:423-441): var == 0 (SOURCE) takes alpha
+            for (int v = 0; v < size; ++v)
+                if (!reachT[v]) {
+                    const int site = active[v];
+                    label[site] = alpha;
+                    curCost[site] = cost[(size_t)site * L + alpha];
+                }
+        }
+        for (int v = 0; v < size; ++v) lookup[active[v]] = -1;
+        return accept;
+    }
+};
+
+} // namespace
+
+// labels: in = initial labeling (GCO default is all 0; LabelingStep warm-starts
+// with previous+1 when !changed, M/MultiH.cpp:525-529), out = result.
+// hits CSR: directed radius/kNN hits (self hits allowed, skipped).
+// Returns final int32 energy; *cycles_out = number of cycles executed.
+MHO_API int mho_expand(int N, int L, const int* cost, const int* hit_rowptr,
+                       const int* hit_col, int potts, int* labels, int max_cycles,
+                       int* cycles_out, int* energies_out /* optional, per cycle */)
+{
+    SymGraph g;
+    build_sym(N, hit_rowptr, hit_col, g);
+    if (cycles_out) *cycles_out = 0;
+
+    // solveSpecialCases (GCoptimization.cpp:455-491): no neighbours at all ->
+    // independent per-site argmin, first minimum wins.
+    if (g.col.empty()) {
+        int energy = 0;
+        for (int i = 0; i < N; ++i) {
+            int best = 0, bc = cost[(size_t)i * L];
+            for (int l = 1; l < L; ++l) {
+                int c = cost[(size_t)i * L + l];
+                if (c < bc) { bc = c; best = l; }
+            }
+            labels[i] = best;
+            energy += bc;
+        }
+        return energy;
+    }
+
+    Expander ex;
+    ex.N = N; ex.L = L; ex.cost = cost; ex.g = &g; ex.potts = potts;
+    ex.label.assign(labels, labels + N);
+    ex.curCost.resize(N);
+    ex.lookup.assign(N, -1);
+    for (int i = 0; i < N; ++i) ex.curCost[i] = cost[(size_t)i * L + ex.label[i]]; // :445-451
+
+    int new_energy = ex.compute_energy();     // :1036
+    int old_energy;
+    int cyc = 0;
+    for (int cycle = 1; cycle <= max_cycles; ++cycle) {
+        old_energy = new_energy;
+        for (int a = 0; a < L; ++a) ex.alpha_expansion(a);   // fixed order, :1285-1286
+        new_energy = ex.compute_energy();
+        if (energies_out) energies_out[cyc] = new_energy;
+        ++cyc;
+        if (new_energy == old_energy) break;                 // :1045
+    }
+    if (cycles_out) *cycles_out = cyc;
+    std::copy(ex.label.begin(), ex.label.end(), labels);
+    return new_energy;
+}
+
+// Total energy of a given labeling (data + smooth), for property tests.
+MHO_API long long mho_labeling_energy(int N, int L, const int* cost, const int* hit_rowptr,
+                                      const int* hit_col, int potts, const int* labels)
+{
+    SymGraph g;
+    build_sym(N, hit_rowptr, hit_col, g);
+    long long e = 0;
+    for (int i = 0; i < N; ++i) {
+        e += cost[(size_t)i * L + labels[i]];
+        for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k)
+            if (g.col[k] < i && labels[i] != labels[g.col[k]]) e += (long long)g.w[k] * potts;
+    }
+    return e;
+}
+
+// ---------------------------------------------------------------------------
+// 5. Symmetric eigen-solver (stands in for cv::eigen, OpenCV 3.1.0)
+// ---------------------------------------------------------------------------
+// Cyclic Jacobi, fixed (p,q) order, rotation skipped when the off-diagonal is
+// exactly zero; stops after a sweep whose off-diagonal sum of squares is
+// <= 1e-30 * (sum of squares of the diagonal), max 30 sweeps.  a is n*n row
+// major (destroyed), v gets eigenvectors as COLUMNS, d the eigenvalues
+// (unsorted).  The GPU re-estimation kernel uses the same recurrence so that
+// both sides round identically.
+static void jacobi_sym(int n, double* a, double* v, double* d)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag = diag + a[i * n + i] * a[i * n + i];
+            for (int j = i + 1; j < n; ++j) off = off + a[i * n + j] * a[i * n + j];
+        }
+        if (off <= 1e-30 * diag) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < n; ++k) {            // columns p,q of A
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {            // rows p,q of A
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {            // accumulate V
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq;
+                    v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) d[i] = a[i * n + i];
+}
+
+MHO_API void mho_jacobi_sym(int n, const double* a_in, double* evecs_cols, double* evals)
+{
+    std::vector<double> a(a_in, a_in + n * n);
+    jacobi_sym(n, a.data(), evecs_cols, evals);
+}
+
+// ---------------------------------------------------------------------------
+// 6. Deterministic strided-tree reduction
+// ---------------------------------------------------------------------------
+// FP sums that feed thresholds or homographies must round identically on CPU
+// and GPU.  The reference's own summation order is inside OpenCV (gemm) and
+// unknowable, so the order is DEFINED here: W = 256 strided partial sums
+// (lane t adds items t, t+W, t+2W, ... in increasing order, starting from
+// 0.0), then a binary tree  v[t] += v[t+s]  for s = 128, 64, ..., 1.
+enum { MHO_W = 256 };
+
+struct TreeAcc {
+    int K;
+    std::vector<double> part;                 // W*K
+    explicit TreeAcc(int k) : K(k), part((size_t)MHO_W * k, 0.0) {}
+    void add(int item_index, const double* contrib)
+    {
+        double* p = &part[(size_t)(item_index % MHO_W) * K];
+        for (int k = 0; k < K; ++k) p[k] = p[k] + contrib[k];
+    }
+    void finish(double* out)
+    {
+        for (int s = MHO_W / 2; s >= 1; s >>= 1)
+            for (int t = 0; t < s; ++t)
+                for (int k = 0; k < K; ++k)
+                    part[(size_t)t * K + k] = part[(size_t)t * K + k] + part[(size_t)(t + s) * K + k];
+        for (int k = 0; k < K; ++k) out[k] = part[k];
+    }
+};
+
+// ---------------------------------------------------------------------------
+// 7. Collinearity (straightness) test                    
+// ---------------------------------------------------------------------------
+// M/MultiH.cpp:446-463: S = sum over inliers of [x y 1]^T [x y 1]; reject the
+// model if the smallest eigenvalue of S < straightness_threshold (0.005) or
+// inliers < 3.  moments out: {n, Sx, Sy, Sxx, Sxy, Syy} per model (n as double).
+// Items are indexed by POINT index n (not by inlier rank) in the tree sum.
+MHO_API void mho_inlier_moments(const double* x1, const double* y1, const double* x2,
+                                const double* y2, int N, const double* H, int M,
+                                double thr2, double* moments /* M*6 */, double* min_eig /* M */)
+{
+    for (int m = 0; m < M; ++m) {
+        const double* h = H + 9 * (size_t)m;
+        TreeAcc acc(5);
+        int cnt = 0;
+        for (int n = 0; n < N; ++n) {
+            if (fwd_d2(h, x1[n], y1[n], x2[n], y2[n]) < thr2) {
+                const double x = x1[n], y = y1[n];
+                const double c[5] = { x, y, x * x, x * y, y * y };
+                acc.add(n, c);
+                ++cnt;
+            }
+        }
+        double s[5];
+        acc.finish(s);
+        double* mo = moments + 6 * (size_t)m;
+        mo[0] = (double)cnt; mo[1] = s[0]; mo[2] = s[1]; mo[3] = s[2]; mo[4] = s[3]; mo[5] = s[4];
+        if (min_eig) {
+            double a[9] = { s[2], s[3], s[0],  s[3], s[4], s[1],  s[0], s[1], (double)cnt };
+            double v[9], d[3];
+            jacobi_sym(3, a, v, d);
+            min_eig[m] = std::min(d[0], std::min(d[1], d[2]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 8. HAF non-minimal re-estimation                       
+// ---------------------------------------------------------------------------
+// GetHomographyHAFNonminimal, M/MultiH.cpp:913-989, for every label at once:
+// six rows per point (:938-966), A^T A (4x4), eigenvector of the smallest
+// eigenvalue (:970-982), rows 1-2 of H from e2, F, lambda (:984-989), then the
+// in-place rescale of RefineHomographyHAF (Homography_RefineHAFCallback.h:33-34).
+// The LM loop that follows has no effect on the output (SURVEY A-3) and reads
+// out of bounds; it is deliberately not restated.
+// A^T A is accumulated with the strided tree (items indexed by site index).
+// Labels: -1 = outlier, 0..Nh-1.  A label without points keeps its H
+// (M/MultiH.cpp:592-593).
+static void haf_rows(double a11, double a12, double a21, double a22, double x1, double y1,
+                     double x2, double y2, const double* F, double ex, double ey,
+                     double r[6][4])
+{
+    r[0][0] = a11 * x1 + x2 - ex; r[0][1] = a11 * y1;           r[0][2] = a11; r[0][3] = -F[3];
+    r[1][0] = a12 * x1;           r[1][1] = a12 * y1 + x2 - ex; r[1][2] = a12; r[1][3] = -F[4];
+    r[2][0] = a21 * x1 + y2 - ey; r[2][1] = a21 * y1;           r[2][2] = a21; r[2][3] = F[0];
+    r[3][0] = a22 * x1;           r[3][1] = a22 * y1 + y2 - ey; r[3][2] = a22; r[3][3] = F[1];
+    r[4][0] = ex * x1 - x2 * x1;  r[4][1] = ex * y1 - x2 * y1;  r[4][2] = ex - x2;
+    r[4][3] = x1 * F[3] + y1 * F[4] + F[5];
+    r[5][0] = ey * x1 - y2 * x1;  r[5][1] = ey * y1 - y2 * y1;  r[5][2] = ey - y2;
+    r[5][3] = -(x1 * F[0] + y1 * F[1] + F[2]);
+}
+
+MHO_API void mho_haf_reestimate(const double* x1, const double* y1, const double* x2,
+                                const double* y2, const double* aff /* N*4: a11 a12 a21 a22 */,
+                                int N, const int* labels, int Nh, const double* F,
+                                const double* e2 /* ex, ey */, double* H /* Nh*9 in/out */,
+                                int* counts_out /* optional Nh */)
+{
+    const double ex = e2[0], ey = e2[1];
+    for (int l = 0; l < Nh; ++l) {
+        TreeAcc acc(10);
+        int cnt = 0;
+        for (int n = 0; n < N; ++n) {
+            if (labels[n] != l) continue;
+            double r[6][4];
+            haf_rows(aff[4 * n], aff[4 * n + 1], aff[4 * n + 2], aff[4 * n + 3],
+                     x1[n], y1[n], x2[n], y2[n], F, ex, ey, r);
+            double c[10];
+            int k = 0;
+            for (int i = 0; i < 4; ++i)
+                for (int j = i; j < 4; ++j) {
+                    double s = r[0][i] * r[0][j];
+                    for (int q = 1; q < 6; ++q) s = s + r[q][i] * r[q][j];
+                    c[k++] = s;
+                }
+            acc.add(n, c);
+            ++cnt;
+        }
+        if (counts_out) counts_out[l] = cnt;
+        if (cnt == 0) continue;
+        double u[10];
+        acc.finish(u);
+        double a[16], v[16], d[4];
+        int k = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i; j < 4; ++j) { a[i * 4 + j] = u[k]; a[j * 4 + i] = u[k]; ++k; }
+        jacobi_sym(4, a, v, d);
+        int jm = 0;
+        for (int j = 1; j < 4; ++j) if (d[j] < d[jm]) jm = j;
+        const double h6 = v[0 * 4 + jm], h7 = v[1 * 4 + jm], h8 = v[2 * 4 + jm], lam = v[3 * 4 + jm];
+        double* h = H + 9 * (size_t)l;
+        h[6] = h6; h[7] = h7; h[8] = h8;
+        h[3] = ey * h6 - lam * F[0];
+        h[4] = ey * h7 - lam * F[1];
+        h[5] = ey * h8 - lam * F[2];
+        h[0] = ex * h6 + lam * F[3];
+        h[1] = ex * h7 + lam * F[4];
+        h[2] = ex * h8 + lam * F[5];
+        // RefineHomographyHAF rescale, Homography_RefineHAFCallback.h:33-34
+        const double lam2 = (h[0] - ex * h[6]) / F[3];
+        const double inv = 1.0 / lam2;
+        for (int q = 0; q < 9; ++q) h[q] = h[q] * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 9. Hypothesis sampling + 4-point DLT      (north_star; no reference source)
+// ---------------------------------------------------------------------------
+static inline uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Four distinct point indices for hypothesis m: draw c = 0,1,2,... gives
+// r = splitmix64(seed + (m << 8) + c), idx = ((r >> 32) * N) >> 32; a draw equal
+// to an earlier member of the tuple is rejected (sampling without replacement
+// inside a tuple, as MultipleHomographies.h:118-125 does).  At most 64 draws.
+static void sample4(uint64_t seed, uint64_t m, uint32_t N, int out[4])
+{
+    int got = 0;
+    for (uint32_t c = 0; c < 64 && got < 4; ++c) {
+        const uint64_t r = splitmix64(seed + (m << 8) + c);
+        const int idx = (int)(((r >> 32) * (uint64_t)N) >> 32);
+        bool dup = false;
+        for (int k = 0; k < got; ++k) dup = dup || (out[k] == idx);
+        if (!dup) out[got++] = idx;
+    }
+    for (; got < 4; ++got) out[got] = out[0];   // unreachable for N >= 4
+}
+
+MHO_API void mho_sample4(unsigned long long seed, long long m0, int M, int N, int* idx /* M*4 */)
+{
+    for (int m = 0; m < M; ++m) sample4(seed, (uint64_t)(m0 + m), (uint32_t)N, idx + 4 * (size_t)m);
+}
+
+// Round-robin (circle method) schedule for 9 columns + 1 bye: 9 rounds of 4
+// disjoint pairs.  Disjoint pairs commute exactly, so a GPU wave rotating the 4
+// pairs of a round in parallel and this serial loop produce the same bits.
+static void rr_schedule(int sched[9][4][2])
+{
+    for (int r = 0; r < 9; ++r) {
+        int cnt = 0;
+        // players 0..8 on a circle, player 9 (bye) fixed
+        for (int k = 1; k <= 4; ++k) {
+            int a = (r + k) % 9, b = (r + 9 - k) % 9;
+            sched[r][cnt][0] = std::min(a, b);
+            sched[r][cnt][1] = std::max(a, b);
+            ++cnt;
+        }
+    }
+}
+
+MHO_API void mho_rr_schedule(int* out /* 9*4*2 */)
+{
+    int s[9][4][2];
+    rr_schedule(s);
+    memcpy(out, s, sizeof(s));
+}
+
+// One normalised DLT solve.  src/dst: 4 points each.  Returns H (row-major 9,
+// Frobenius norm 1, h[8] >= 0) and the ratio second-smallest/largest column
+// norm as a conditioning witness (tests mask degenerate samples with it).
+static void dlt4(const double sx[4], const double sy[4], const double dx[4], const double dy[4],
+                 double H[9], double* witness, int* sweeps_out)
+{
+    // Hartley normalisation (same recipe as NormalizePoints,
+    // Homography_Refine3PTCallback.h:236-271: centroid, mean distance -> sqrt 2)
+    double cx1 = ((sx[0] + sx[1]) + sx[2]) + sx[3], cy1 = ((sy[0] + sy[1]) + sy[2]) + sy[3];
+    double cx2 = ((dx[0] + dx[1]) + dx[2]) + dx[3], cy2 = ((dy[0] + dy[1]) + dy[2]) + dy[3];
+    cx1 = cx1 * 0.25; cy1 = cy1 * 0.25; cx2 = cx2 * 0.25; cy2 = cy2 * 0.25;
+    double d1 = 0.0, d2 = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        const double ax = sx[i] - cx1, ay = sy[i] - cy1, bx = dx[i] - cx2, by = dy[i] - cy2;
+        d1 = d1 + sqrt(ax * ax + ay * ay);
+        d2 = d2 + sqrt(bx * bx + by * by);
+    }
+    const double s1 = sqrt(2.0) / (d1 * 0.25), s2 = sqrt(2.0) / (d2 * 0.25);
+
+    // W = [A (8x9); V (9x9)] column pairs are rotated together.
+    double W[17][9];
+    for (int i = 0; i < 4; ++i) {
+        const double x = (sx[i] - cx1) * s1, y = (sy[i] - cy1) * s1;
+        const double u = (dx[i] - cx2) * s2, v = (dy[i] - cy2) * s2;
+        double* r0 = W[2 * i];
+        double* r1 = W[2 * i + 1];
+        r0[0] = -x; r0[1] = -y; r0[2] = -1.0; r0[3] = 0.0; r0[4] = 0.0; r0[5] = 0.0;
+        r0[6] = u * x; r0[7] = u * y; r0[8] = u;
+        r1[0] = 0.0; r1[1] = 0.0; r1[2] = 0.0; r1[3] = -x; r1[4] = -y; r1[5] = -1.0;
+        r1[6] = v * x; r1[7] = v * y; r1[8] = v;
+    }
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) W[8 + i][j] = (i == j) ? 1.0 : 0.0;
+
+    int sched[9][4][2];
+    rr_schedule(sched);
+    int sweeps = 0;
+    for (; sweeps < 30; ++sweeps) {
+        int rotated = 0;
+        for (int r = 0; r < 9; ++r)
+            for (int k = 0; k < 4; ++k) {
+                const int p = sched[r][k][0], q = sched[r][k][1];
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = 0; i < 8; ++i) {
+                    alpha = alpha + W[i][p] * W[i][p];
+                    beta = beta + W[i][q] * W[i][q];
+                    gamma = gamma + W[i][p] * W[i][q];
+                }
+                // rotate only if |gamma| > 1e-15*sqrt(alpha*beta) and neither column has
+                // already vanished (norm < 1e-14; the data is Hartley-normalised so an
+                // absolute floor is meaningful).  Written so that NaN never rotates.
+                const bool rot = (gamma != 0.0) && (gamma * gamma > 1e-30 * (alpha * beta)) &&
+                                 (alpha >= 1e-28) && (beta >= 1e-28);
+                if (!rot) continue;
+                ++rotated;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t);
+                const double s = c * t;
+                for (int i = 0; i < 17; ++i) {
+                    const double wp = W[i][p], wq = W[i][q];
+                    W[i][p] = c * wp - s * wq;
+                    W[i][q] = s * wp + c * wq;
+                }
+            }
+        if (!rotated) break;
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    // null vector = V column of the smallest A-column norm
+    double nrm[9];
+    int jm = 0;
+    for (int j = 0; j < 9; ++j) {
+        double a = 0.0;
+        for (int i = 0; i < 8; ++i) a = a + W[i][j] * W[i][j];
+        nrm[j] = a;
+        if (a < nrm[jm]) jm = j;
+    }
+    if (witness) {
+        double second = -1.0, largest = 0.0;
+        for (int j = 0; j < 9; ++j) {
+            if (nrm[j] > largest) largest = nrm[j];
+            if (j != jm && (second < 0.0 || nrm[j] < second)) second = nrm[j];
+        }
+        *witness = (largest > 0.0) ? sqrt(second / largest) : 0.0;
+    }
+    double g[9];
+    for (int j = 0; j < 9; ++j) g[j] = W[8 + j][jm];
+    // H = T2^-1 * Hn * T1,  T1 = [s1 0 -s1*cx1; 0 s1 -s1*cy1; 0 0 1],
+    //                       T2^-1 = [1/s2 0 cx2; 0 1/s2 cy2; 0 0 1]
+    double A1[9];  // Hn * T1
+    for (int r = 0; r < 3; ++r) {
+        const double a = g[3 * r], b = g[3 * r + 1], c = g[3 * r + 2];
+        A1[3 * r] = a * s1;
+        A1[3 * r + 1] = b * s1;
+        A1[3 * r + 2] = (c - (a * s1) * cx1) - (b * s1) * cy1;
+    }
+    const double is2 = 1.0 / s2;
+    double Hh[9];
+    for (int j = 0; j < 3; ++j) {
+        Hh[j] = A1[j] * is2 + cx2 * A1[6 + j];
+        Hh[3 + j] = A1[3 + j] * is2 + cy2 * A1[6 + j];
+        Hh[6 + j] = A1[6 + j];
+    }
+    double fro = 0.0;
+    for (int j = 0; j < 9; ++j) fro = fro + Hh[j] * Hh[j];
+    double sc = 1.0 / sqrt(fro);
+    if (Hh[8] < 0.0) sc = -sc;
+    for (int j = 0; j < 9; ++j) H[j] = Hh[j] * sc;
+}
+
+MHO_API void mho_dlt4(const double* x1, const double* y1, const double* x2, const double* y2,
+                      const int* idx /* M*4 */, int M, double* H /* M*9 */,
+                      double* witness /* optional M */, int* sweeps /* optional M */)
+{
+    for (int m = 0; m < M; ++m) {
+        double sx[4], sy[4], dx[4], dy[4];
+        for (int k = 0; k < 4; ++k) {
+            const int i = idx[4 * (size_t)m + k];
+            sx[k] = x1[i]; sy[k] = y1[i]; dx[k] = x2[i]; dy[k] = y2[i];
+        }
+        dlt4(sx, sy, dx, dy, H + 9 * (size_t)m, witness ? witness + m : nullptr,
+             sweeps ? sweeps + m : nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 10. LabelingStep and the alternating loop              
+// ---------------------------------------------------------------------------
+// LabelingStep, M/MultiH.cpp:513-602: data cost -> expansion (warm start iff
+// !changed) -> labels shifted by -1 -> per-label HAF re-estimation.
+// labeling: in = previous labels (-1..Nh-1, used only if warm), out = new.
+MHO_API int mho_labeling_step(const double* x1, const double* y1, const double* x2,
+                              const double* y2, const double* aff, int N,
+                              double* H /* Nh*9 in/out */, int Nh, double lambda, double thr2,
+                              const int* hit_rowptr, const int* hit_col, int warm,
+                              const double* F, const double* e2, int* labeling, int* cycles_out)
+{
+    const int L = Nh + 1;
+    std::vector<int> cost((size_t)N * L);
+    mho_data_cost(x1, y1, x2, y2, N, H, Nh, lambda, thr2, cost.data());
+    std::vector<int> lab(N, 0);
+    if (warm) for (int i = 0; i < N; ++i) lab[i] = labeling[i] + 1;      // :525-529
+    const int energy = mho_expand(N, L, cost.data(), hit_rowptr, hit_col, mho_potts(lambda),
+                                  lab.data(), 1000, cycles_out, nullptr);
+    for (int i = 0; i < N; ++i) labeling[i] = lab[i] - 1;                // :547-568
+    mho_haf_reestimate(x1, y1, x2, y2, aff, N, labeling, Nh, F, e2, H, nullptr);
+    return energy;
+}
+
+MHO_API int mho_abi_version(void) { return 1; }

@@ -1,0 +1,228 @@
+"""ctypes bindings to the CPU oracle (oracle/_build/libmh_oracle.so) and, when
+present, to the reference's own alpha-expansion build (oracle/_ref/
+libmh_ref_gco.so).  TEST INFRASTRUCTURE: imported only from tests/, bench.py's
+cpu_baseline leg and __graft_entry__.smoke()."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libmh_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmh_ref_gco.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(ROOT, "oracle", "mh_oracle.cpp")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        _lib = C.CDLL(ORACLE_SO)
+        _lib.mho_labeling_energy.restype = C.c_longlong
+    return _lib
+
+
+def ref():
+    """The reference GCO build, or None when oracle/_ref was not built."""
+    global _ref
+    if _ref is None and os.path.exists(REF_SO):
+        _ref = C.CDLL(REF_SO)
+    return _ref
+
+
+def soa(src, dst):
+    src, dst = f64(src), f64(dst)
+    return f64(src[:, 0]), f64(src[:, 1]), f64(dst[:, 0]), f64(dst[:, 1])
+
+
+# ---- oracle entry points -------------------------------------------------
+
+def residual_matrix(src, dst, H):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    R = np.empty((H.shape[0], x1.size), dtype=np.float64)
+    lib().mho_residual_matrix(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], _d(R))
+    return R
+
+
+def score(src, dst, H, thr2, mask=None):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    cnt = np.empty(H.shape[0], dtype=np.int32)
+    mp = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        mp = mask.ctypes.data_as(C.POINTER(C.c_ubyte))
+    lib().mho_score(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], C.c_double(thr2), mp, _i(cnt))
+    return cnt
+
+
+def score_mt(src, dst, H, thr2):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    cnt = np.empty(H.shape[0], dtype=np.int32)
+    threads = lib().mho_score_mt(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], C.c_double(thr2), _i(cnt))
+    return cnt, int(threads)
+
+
+def data_cost(src, dst, H, lam, thr2):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    cost = np.empty((x1.size, H.shape[0] + 1), dtype=np.int32)
+    lib().mho_data_cost(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0],
+                        C.c_double(lam), C.c_double(thr2), _i(cost))
+    return cost
+
+
+def potts(lam):
+    return int(lib().mho_potts(C.c_double(lam)))
+
+
+def build_sym_graph(n, rowptr, col):
+    rowptr, col = i32(rowptr), i32(col)
+    nnz = lib().mho_build_sym_graph(n, _i(rowptr), _i(col), None, None, None)
+    rp = np.empty(n + 1, dtype=np.int32)
+    cl = np.empty(nnz, dtype=np.int32)
+    w = np.empty(nnz, dtype=np.int32)
+    lib().mho_build_sym_graph(n, _i(rowptr), _i(col), _i(rp), _i(cl), _i(w))
+    return rp, cl, w
+
+
+def expand(cost, rowptr, col, potts_v, init_labels=None, max_cycles=1000):
+    cost = i32(cost)
+    n, L = cost.shape
+    rowptr, col = i32(rowptr), i32(col)
+    labels = np.zeros(n, dtype=np.int32) if init_labels is None else i32(init_labels).copy()
+    cycles = C.c_int(0)
+    energies = np.zeros(max_cycles, dtype=np.int32)
+    e = lib().mho_expand(n, L, _i(cost), _i(rowptr), _i(col), int(potts_v), _i(labels), int(max_cycles),
+                         C.byref(cycles), _i(energies))
+    return labels, int(e), int(cycles.value), energies[:cycles.value].copy()
+
+
+def labeling_energy(cost, rowptr, col, potts_v, labels):
+    cost = i32(cost)
+    n, L = cost.shape
+    rowptr, col, labels = i32(rowptr), i32(col), i32(labels)
+    return int(lib().mho_labeling_energy(n, L, _i(cost), _i(rowptr), _i(col), int(potts_v), _i(labels)))
+
+
+def jacobi_sym(a):
+    a = f64(a)
+    n = a.shape[0]
+    v = np.empty((n, n))
+    d = np.empty(n)
+    lib().mho_jacobi_sym(n, _d(a), _d(v), _d(d))
+    return d, v
+
+
+def inlier_moments(src, dst, H, thr2):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    mo = np.empty((H.shape[0], 6))
+    me = np.empty(H.shape[0])
+    lib().mho_inlier_moments(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0],
+                             C.c_double(thr2), _d(mo), _d(me))
+    return mo, me
+
+
+def haf_reestimate(src, dst, aff, labels, H, F, e2):
+    x1, y1, x2, y2 = soa(src, dst)
+    aff, labels, F, e2 = f64(aff), i32(labels), f64(F), f64(e2)
+    H = f64(H).reshape(-1, 9).copy()
+    cnt = np.zeros(H.shape[0], dtype=np.int32)
+    lib().mho_haf_reestimate(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _i(labels),
+                             H.shape[0], _d(F), _d(e2), _d(H), _i(cnt))
+    return H, cnt
+
+
+def sample4(seed, m0, M, N):
+    idx = np.empty((M, 4), dtype=np.int32)
+    lib().mho_sample4(C.c_ulonglong(seed), C.c_longlong(m0), M, N, _i(idx))
+    return idx
+
+
+def rr_schedule():
+    s = np.empty((9, 4, 2), dtype=np.int32)
+    lib().mho_rr_schedule(_i(s))
+    return s
+
+
+def dlt4(src, dst, idx):
+    x1, y1, x2, y2 = soa(src, dst)
+    idx = i32(idx).reshape(-1, 4)
+    M = idx.shape[0]
+    H = np.empty((M, 9))
+    wit = np.empty(M)
+    sw = np.empty(M, dtype=np.int32)
+    lib().mho_dlt4(_d(x1), _d(y1), _d(x2), _d(y2), _i(idx), M, _d(H), _d(wit), _i(sw))
+    return H, wit, sw
+
+
+def labeling_step(src, dst, aff, H, lam, thr2, rowptr, col, warm, F, e2, labeling):
+    x1, y1, x2, y2 = soa(src, dst)
+    aff, F, e2 = f64(aff), f64(F), f64(e2)
+    H = f64(H).reshape(-1, 9).copy()
+    rowptr, col = i32(rowptr), i32(col)
+    lab = i32(labeling).copy()
+    cyc = C.c_int(0)
+    e = lib().mho_labeling_step(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(H), H.shape[0],
+                                C.c_double(lam), C.c_double(thr2), _i(rowptr), _i(col), int(bool(warm)),
+                                _d(F), _d(e2), _i(lab), C.byref(cyc))
+    return lab, H, int(e), int(cyc.value)
+
+
+# ---- reference GCO (oracle/_ref) -----------------------------------------
+
+def ref_expand_table(cost, rowptr, col, potts_v, init_labels=None):
+    r = ref()
+    cost = i32(cost)
+    n, L = cost.shape
+    rowptr, col = i32(rowptr), i32(col)
+    out = np.empty(n, dtype=np.int32)
+    init = None if init_labels is None else _i(i32(init_labels))
+    e = r.ref_gco_expand_table(n, L, _i(cost), _i(rowptr), _i(col), int(potts_v), init, _i(out))
+    return out, int(e)
+
+
+def ref_expand_formula(src, dst, H, lam, thr2, rowptr, col, init_labels=None):
+    r = ref()
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    rowptr, col = i32(rowptr), i32(col)
+    out = np.empty(x1.size, dtype=np.int32)
+    init = None if init_labels is None else _i(i32(init_labels))
+    e = r.ref_gco_expand_formula(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0],
+                                 C.c_double(lam), C.c_double(thr2), _i(rowptr), _i(col), init, _i(out))
+    return out, int(e)

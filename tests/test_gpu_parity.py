@@ -1,0 +1,255 @@
+"""GPU parity tests proper: every kernel called through the C ABI and compared
+with the CPU oracle on the same seeded inputs.  Integer results (counts, costs,
+labels, energies, sample indices) must be bit-exact; FP64 results of the
+reference's formulas (residuals) must be bit-exact too, because both sides
+round every operation once in the reference's order; homographies must agree
+to 1e-6 relative (north_star) — in practice they are bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THR = 2.2
+THR2 = THR * THR
+LAM = 0.5
+
+
+def _load(engine, sc, neighbours=True):
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.set_epipolar(sc.F, sc.e2)
+    if neighbours:
+        engine.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
+
+
+def _models(sc, rng, extra=5):
+    """Ground-truth planes plus perturbed copies (near-miss models make interesting costs)."""
+    H = [sc.H_true]
+    for _ in range(extra):
+        k = rng.integers(0, sc.H_true.shape[0])
+        H.append(sc.H_true[k:k + 1] * (1.0 + rng.normal(0, 2e-4, size=(1, 9))))
+    return np.concatenate(H, axis=0)
+
+
+@pytest.mark.parametrize("n,k,seed", [(1, 1, 5), (2, 1, 6), (129, 2, 1), (1000, 3, 2), (5000, 3, 1234), (4099, 4, 7)])
+def test_residual_matrix_and_counts_bit_exact(engine, synth, oracle, n, k, seed):
+    sc = synth.make_scene(n, k, seed=seed, with_neighbours=False)
+    rng = np.random.default_rng(seed)
+    H = _models(sc, rng, extra=17)          # 17+k models: exercises the partial last model chunk
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    R, cnt = engine.residual_matrix(THR2)
+    R_ref = oracle.residual_matrix(sc.src, sc.dst, H)
+    assert R.shape == R_ref.shape
+    assert np.array_equal(R.view(np.uint64), R_ref.view(np.uint64)), "residuals differ in the last bit somewhere"
+    assert np.array_equal(cnt, oracle.score(sc.src, sc.dst, H, THR2))
+    # fused score kernel (no matrix) gives the same counts
+    assert np.array_equal(engine.score(THR2), cnt)
+
+
+def test_residual_nonfinite_and_degenerate_models(engine, synth, oracle):
+    """Degenerate hypotheses (s == 0, huge/denormal scale) must round identically: inf/NaN
+    patterns are compared bitwise except NaN payloads (compared as NaN-ness)."""
+    sc = synth.make_scene(777, 2, seed=3, with_neighbours=False)
+    H = np.array([
+        [1, 0, 0, 0, 1, 0, 0, 0, 0],            # s == 0 everywhere -> inf/NaN
+        [1, 0, 0, 0, 1, 0, 1e-3, -1e-3, 0],      # s crosses zero
+        [1e-300, 0, 0, 0, 1e-300, 0, 0, 0, 1e-300],   # tiny scale
+        [1e150, 0, 0, 0, 1e150, 0, 0, 0, 1e150],      # huge scale
+        [0, 0, 0, 0, 0, 0, 0, 0, 1],
+    ], dtype=np.float64)
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    with np.errstate(all="ignore"):
+        R, cnt = engine.residual_matrix(THR2)
+        R_ref = oracle.residual_matrix(sc.src, sc.dst, H)
+    nan = np.isnan(R_ref)
+    assert np.array_equal(np.isnan(R), nan)
+    assert np.array_equal(R[~nan].view(np.uint64), R_ref[~nan].view(np.uint64))
+    assert np.array_equal(cnt, oracle.score(sc.src, sc.dst, H, THR2))
+
+
+def test_score_with_point_mask(engine, synth, oracle):
+    sc = synth.make_scene(3001, 3, seed=11, with_neighbours=False)
+    rng = np.random.default_rng(0)
+    H = _models(sc, rng, extra=30)
+    mask = (rng.random(sc.n) < 0.6).astype(np.uint8)
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    assert np.array_equal(engine.score(THR2, mask=mask), oracle.score(sc.src, sc.dst, H, THR2, mask=mask))
+    assert np.array_equal(engine.score(THR2, mask=np.zeros(sc.n, np.uint8)), np.zeros(H.shape[0], np.int32))
+
+
+def test_inliers_of_model(engine, synth, oracle):
+    sc = synth.make_scene(2000, 3, seed=4, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    engine.set_models(sc.H_true)
+    lab0 = np.full(sc.n, -1, dtype=np.int32)
+    got = engine.inliers_of_model(1, THR2, 0, lab0)
+    d2 = oracle.residual_matrix(sc.src, sc.dst, sc.H_true[1:2])[0]
+    assert np.array_equal(got, np.where(d2 < THR2, 0, -1))
+
+
+@pytest.mark.parametrize("n,k,seed", [(64, 3, 1), (1000, 3, 2), (5000, 10, 3)])
+def test_data_cost_bit_exact(engine, synth, oracle, n, k, seed):
+    sc = synth.make_scene(n, k, seed=seed, with_neighbours=False)
+    H = _models(sc, np.random.default_rng(seed))
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    cost = engine.data_cost()
+    assert np.array_equal(cost, oracle.data_cost(sc.src, sc.dst, H, LAM, THR2))
+    # known-answer constants of the harness defaults
+    assert (cost[:, 0] == 4901).all()
+    assert set(np.unique(cost[:, 1:])).issubset(set(range(0, 201)) | {9802})
+
+
+@pytest.mark.parametrize("n,m,seed", [(50, 64, 1), (5000, 1000, 1234), (777, 333, 9)])
+def test_sampling_and_dlt4(engine, synth, oracle, n, m, seed):
+    sc = synth.make_scene(n, 3, seed=seed, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    engine.propose_dlt4(seed, 10, m)
+    idx = engine.get_samples()
+    assert np.array_equal(idx, oracle.sample4(seed, 10, m, n)), "counter RNG tuples differ"
+    assert all(len(set(t)) == 4 for t in idx.tolist())
+    H = engine.get_models()
+    H_ref, wit, _ = oracle.dlt4(sc.src, sc.dst, idx)
+    good = wit > 1e-6                         # conditioning witness: skip (near-)degenerate samples
+    assert good.sum() > 0.5 * m
+    # north_star tolerance: 1e-6 relative (H has unit Frobenius norm, so absolute == relative)
+    assert np.max(np.abs(H[good] - H_ref[good])) <= 1e-6
+    # in practice both sides execute the same rounded operations
+    assert np.array_equal(H[good].view(np.uint64), H_ref[good].view(np.uint64))
+    # the homography maps its own 4 sample points exactly (size-independent property)
+    for t in np.flatnonzero(good)[:50]:
+        p = synth.apply_h(H[t], sc.src[idx[t]])
+        assert np.max(np.abs(p - sc.dst[idx[t]])) < 1e-6 * 1000
+
+
+def test_moments_and_collinearity(engine, synth, oracle):
+    sc = synth.make_scene(3000, 3, seed=5, with_neighbours=False)
+    H = _models(sc, np.random.default_rng(1))
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    mo, me = engine.inlier_moments(THR2)
+    mo_ref, me_ref = oracle.inlier_moments(sc.src, sc.dst, H, THR2)
+    assert np.array_equal(mo.view(np.uint64), mo_ref.view(np.uint64))
+    assert np.allclose(me, me_ref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,k,seed", [(300, 3, 1), (5000, 3, 1234), (2000, 10, 8)])
+def test_reestimate(engine, synth, oracle, n, k, seed):
+    sc = synth.make_scene(n, k, seed=seed, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    H0 = sc.H_true.copy()
+    engine.set_models(H0)
+    labels = sc.gt_label.copy()
+    labels[labels == k - 1] = -1              # leave the last label empty: its H must survive untouched
+    H = engine.reestimate(labels)
+    H_ref, cnt = oracle.haf_reestimate(sc.src, sc.dst, sc.aff, labels, H0, sc.F, sc.e2)
+    assert cnt[k - 1] == 0 and np.array_equal(H[k - 1], H0[k - 1])
+    scale = np.max(np.abs(H_ref), axis=1, keepdims=True)
+    assert np.max(np.abs(H - H_ref) / scale) <= 1e-6
+    assert np.array_equal(H.view(np.uint64), H_ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("n,k,seed,sym", [(64, 2, 1, True), (300, 3, 1, True), (1000, 3, 2, False),
+                                          (3000, 5, 3, True), (5000, 3, 1234, True)])
+def test_expand_labels_bit_exact(engine, synth, oracle, n, k, seed, sym):
+    sc = synth.make_scene(n, k, seed=seed, symmetric=sym)
+    H = _models(sc, np.random.default_rng(seed), extra=3)
+    _load(engine, sc)
+    engine.set_models(H)
+    cost = engine.data_cost()
+    labels, energy, cycles = engine.expand()
+    lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM))
+    assert energy == e_ref
+    assert np.array_equal(labels, lab_ref)
+    assert cycles == cyc_ref
+    # warm start from a different labeling
+    init = (sc.gt_label + 1).astype(np.int32)
+    labels_w, energy_w, _ = engine.expand(init)
+    lab_w_ref, e_w_ref, _, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM), init_labels=init)
+    assert energy_w == e_w_ref and np.array_equal(labels_w, lab_w_ref)
+
+
+def test_expand_without_neighbours_is_argmin(engine, synth, oracle):
+    sc = synth.make_scene(500, 3, seed=2, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    engine.set_neighbors_csr(np.zeros(sc.n + 1, np.int32), np.zeros(0, np.int32))
+    engine.set_models(sc.H_true)
+    cost = engine.data_cost()
+    labels, energy, _ = engine.expand()
+    assert np.array_equal(labels, np.argmin(cost, axis=1))
+    assert energy == int(cost.min(axis=1).sum())
+
+
+def test_sym_graph_matches_oracle(engine, synth, oracle):
+    sc = synth.make_scene(1500, 3, seed=6, symmetric=False)
+    _load(engine, sc)
+    rp, col, w = engine.get_sym_graph()
+    rp_r, col_r, w_r = oracle.build_sym_graph(sc.n, sc.hit_rowptr, sc.hit_col)
+    assert np.array_equal(rp, rp_r) and np.array_equal(col, col_r) and np.array_equal(w, w_r)
+    assert set(np.unique(w)) == {1, 2}       # one-way and mutual kNN hits (SURVEY A-2)
+
+
+@pytest.mark.parametrize("n,k,seed", [(1000, 3, 2), (5000, 3, 1234)])
+def test_labeling_step_and_loop(engine, synth, oracle, n, k, seed):
+    """LabelingStep (cost -> expand -> shift -> re-estimate), iterated like the reference's
+    alternating loop with warm starts: labels and energies bit-exact at every iteration."""
+    sc = synth.make_scene(n, k, seed=seed)
+    _load(engine, sc)
+    H = sc.H_true * (1.0 + np.random.default_rng(seed).normal(0, 1e-4, size=sc.H_true.shape))
+    engine.set_models(H)
+    lab = np.full(sc.n, -1, dtype=np.int32)
+    lab_ref, H_ref = lab.copy(), H.copy()
+    for it in range(4):
+        warm = it > 0
+        lab, energy, cycles = engine.labeling_step(warm, lab)
+        lab_ref, H_ref, e_ref, cyc_ref = oracle.labeling_step(sc.src, sc.dst, sc.aff, H_ref, LAM, THR2,
+                                                              sc.hit_rowptr, sc.hit_col, warm, sc.F, sc.e2, lab_ref)
+        assert energy == e_ref, f"iteration {it}"
+        assert np.array_equal(lab, lab_ref), f"iteration {it}"
+        Hg = engine.get_models()
+        scale = np.max(np.abs(H_ref), axis=1, keepdims=True)
+        assert np.max(np.abs(Hg - H_ref) / scale) <= 1e-6
+        assert np.array_equal(Hg.view(np.uint64), H_ref.view(np.uint64)), f"iteration {it}"
+
+
+def test_knn_builder(engine, synth):
+    sc = synth.make_scene(2000, 3, seed=12, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    engine.build_neighbors_knn(8)
+    rp, col, w = engine.get_sym_graph()
+    # brute force in float32 with the kernel's association order and tie rule
+    pv = np.concatenate([sc.src, sc.dst], axis=1).astype(np.float32)
+    d = np.zeros((sc.n, sc.n), dtype=np.float32)
+    diff = pv[:, None, :] - pv[None, :, :]
+    sq = diff * diff
+    d = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]) + sq[..., 3]
+    np.fill_diagonal(d, np.inf)
+    order = np.lexsort((np.broadcast_to(np.arange(sc.n), d.shape), d), axis=1)[:, :8]
+    hits = np.zeros((sc.n, sc.n), dtype=np.int32)
+    rows = np.repeat(np.arange(sc.n), 8)
+    np.add.at(hits, (rows, order.reshape(-1)), 1)
+    mult = hits + hits.T
+    for i in range(0, sc.n, 97):
+        js = col[rp[i]:rp[i + 1]]
+        assert np.array_equal(js, np.flatnonzero(mult[i]))
+        assert np.array_equal(w[rp[i]:rp[i + 1]], mult[i][js])
+
+
+def test_fp64_division_and_sqrt_are_ieee(engine, synth, oracle):
+    """The bit-exactness argument rests on the device's FP64 divide being correctly rounded.
+    Stress it through the residual kernel with adversarial magnitudes."""
+    rng = np.random.default_rng(99)
+    n = 4096
+    src = rng.uniform(-1e3, 1e3, size=(n, 2)) * 10.0 ** rng.integers(-3, 4, size=(n, 1))
+    dst = rng.uniform(-1e3, 1e3, size=(n, 2))
+    H = rng.normal(size=(64, 9)) * 10.0 ** rng.integers(-6, 7, size=(64, 9))
+    engine.set_correspondences(src, dst)
+    engine.set_models(H)
+    with np.errstate(all="ignore"):
+        R, _ = engine.residual_matrix(THR2, fetch_counts=False)
+        R_ref = oracle.residual_matrix(src, dst, H)
+    nan = np.isnan(R_ref)
+    assert np.array_equal(np.isnan(R), nan)
+    assert np.array_equal(R[~nan].view(np.uint64), R_ref[~nan].view(np.uint64))
