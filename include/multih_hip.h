@@ -104,6 +104,9 @@ MH_API int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, 
  * written to HBM by one kernel that also produces the inlier counts.  R_host (nullable)
  * receives a host copy — leave NULL to keep the matrix on the device only. */
 MH_API int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts);
+/* Copy rows [first, first+count) of the resident residual matrix (valid after
+ * mh_residual_matrix) to the host, tightly packed count x n doubles. */
+MH_API int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host);
 /* Label points with the single model idx where inlier (ComputeInliersOfHomography,
  * M/MultiH.cpp:743-768): labels[i] = label_value if d2 < thr2, else unchanged. */
 MH_API int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int* labels /* in/out n */);

@@ -68,7 +68,7 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """C++ host mirror of the reference class (no HIP in these files; g++)."""
-    srcs = [os.path.join(HOST, f) for f in ("MultiH.cpp", "mean_shift.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("MultiH.cpp", "merge_step.cpp")]
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "multih_hip.h"))
     cxx = os.environ.get("CXX", "g++")

@@ -24,7 +24,7 @@ SYMBOLS = [
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
     "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_score",
-    "mh_residual_matrix", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
@@ -186,6 +186,11 @@ class Engine:
                                                 _p(R, C.c_double) if fetch_R else None,
                                                 _p(cnt, C.c_int) if fetch_counts else None))
         return R, cnt
+
+    def get_residual_rows(self, first: int, count: int):
+        rows = np.empty((count, self.n), dtype=np.float64)
+        self._check(self.lib.mh_get_residual_rows(self._h, int(first), int(count), _p(rows, C.c_double)))
+        return rows
 
     def inliers_of_model(self, idx: int, thr2: float, label_value: int, labels):
         labels = _i32(labels).copy()

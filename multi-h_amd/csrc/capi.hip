@@ -90,6 +90,7 @@ struct mh_engine {
     bool profiling = false;
     KernelTimer timers[MH_K_COUNT_];
     int tune_residual_variant = 0;
+    int tune_score_variant = 0;
     ExpandStats last_expand{};
 
     Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n }; }
@@ -537,7 +538,7 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
     }
     {
         ScopedTimer t(e, MH_K_SCORE);
-        HIPCHK(launch_score(e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p, e->stream));
+        HIPCHK(launch_score(e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p, e->tune_score_variant, e->stream));
     }
     if (counts) {
         HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
@@ -564,6 +565,20 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     if (counts)
         HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
     if (R_host || counts) HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
+{
+    int rc = require_models(e);
+    if (rc) return rc;
+    if (!e->R.p || e->ldr <= 0) return fail(MH_ERR_NOT_SET, "residual matrix has not been computed");
+    if (first < 0 || count <= 0 || first + count > e->m || !rows_host)
+        return fail(MH_ERR_INVALID, "row range out of bounds or null output");
+    HIPCHK(hipMemcpy2DAsync(rows_host, sizeof(double) * e->n, e->R.p + (size_t)first * e->ldr,
+                            sizeof(double) * e->ldr, sizeof(double) * e->n, count,
+                            hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
 }
 
@@ -737,6 +752,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
 {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
+    if (key == 1) { e->tune_score_variant = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
 }
 

@@ -19,6 +19,62 @@ __device__ __forceinline__ double fwd_d2(double h0, double h1, double h2, double
     return dx * dx + dy * dy;
 }
 
+// Two correctly rounded FP64 quotients n1/s, n2/s that share the denominator.
+//
+// hipcc lowers an IEEE f64 division to
+//     v_div_scale x2, v_rcp_f64, 4 fma (two Newton steps), mul, fma, v_div_fmas, v_div_fixup
+// and the three v_div_* helpers plus v_rcp_f64 issue at a fraction of the FMA rate, which made
+// the residual sweep VALU-bound at half the HBM roofline.  When the denominator and both
+// numerators are normal numbers with unbiased exponents in [-255, 256], v_div_scale returns its
+// operands unscaled with VCC = 0, v_div_fmas is a plain fma and v_div_fixup passes the quotient
+// through, so the SAME rounded operations can be issued directly — and the refined reciprocal,
+// which depends on the denominator only, is computed once for both quotients.  The result is
+// bit-identical to `n1 / s` and `n2 / s`; lanes outside the exponent window (zeros, denormals,
+// infinities, NaNs, huge/tiny magnitudes) take the compiler's full IEEE division.
+__device__ __forceinline__ void div2_shared(double n1, double n2, double s, double& u, double& v)
+{
+    const unsigned int hs = (unsigned int)__double2hiint(s);
+    const unsigned int h1 = (unsigned int)__double2hiint(n1);
+    const unsigned int h2 = (unsigned int)__double2hiint(n2);
+    constexpr unsigned int LO = 768u << 21;          // biased exponent 768, sign shifted out
+    // (h << 1) - LO < 2^30  <=>  biased exponent in [768, 1279]
+    const unsigned int t = ((hs << 1) - LO) | ((h1 << 1) - LO) | ((h2 << 1) - LO);
+    if (__builtin_expect(t < 0x40000000u, 1)) {
+        double r = __builtin_amdgcn_rcp(s);
+        double e = __builtin_fma(-s, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-s, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        double q = n1 * r;
+        double d = __builtin_fma(-s, q, n1);
+        u = __builtin_fma(d, r, q);
+        q = n2 * r;
+        d = __builtin_fma(-s, q, n2);
+        v = __builtin_fma(d, r, q);
+    } else {
+        // The empty volatile asm keeps hipcc from if-converting this branch into
+        // "compute both paths and select", which costs more than the plain division.
+        asm volatile("; div2_shared: IEEE path");
+        u = n1 / s;
+        v = n2 / s;
+    }
+}
+
+// fwd_d2 with the shared-reciprocal division; bit-identical to fwd_d2.
+__device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, double h3,
+                                              double h4, double h5, double h6, double h7,
+                                              double h8, double x, double y, double x2, double y2)
+{
+    const double s = h6 * x + h7 * y + h8;
+    const double nx = h0 * x + h1 * y + h2;
+    const double ny = h3 * x + h4 * y + h5;
+    double u, v;
+    div2_shared(nx, ny, s, u, v);
+    const double dx = x2 - u;
+    const double dy = y2 - v;
+    return dx * dx + dy * dy;
+}
+
 // Cyclic Jacobi eigen-solver for a small symmetric matrix (n <= 4), run by a
 // single thread.  Stands where the reference calls cv::eigen on 3x3 / 4x4
 // matrices (M/MultiH.cpp:459, :973).  a: n*n row-major (destroyed);

@@ -35,7 +35,7 @@ inline long long residual_ld(int n) { return ((long long)n + 15) & ~15ll; }
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s);
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
-                        const unsigned char* mask, int* counts, hipStream_t s);
+                        const unsigned char* mask, int* counts, int variant, hipStream_t s);
 hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
                                    int label_value, int* labels, hipStream_t s);
 hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,

@@ -30,8 +30,8 @@ namespace mh {
 
 // PPL = points per lane (even), MC = models per workgroup.
 // WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
-// NT: non-temporal stores for the R stream.
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT>
+// NT: non-temporal stores for the R stream.  FAST: shared-reciprocal division (mh_device.hpp).
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -103,10 +103,21 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                 int c_m = 0;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    const double d0 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
-                                             py[2 * c], qx[2 * c], qy[2 * c]);
-                    const double d1 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
-                                             py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
+                    if (CALIB) {       // store-bandwidth calibration build: no residual arithmetic
+                        const int n = wbase + c * 128 + lane * 2;
+                        if (n + 1 < N)
+                            *reinterpret_cast<double2*>(R + (size_t)m * ldr + n) =
+                                make_double2(px[2 * c] + h0, py[2 * c] + h0);
+                        continue;
+                    }
+                    const double d0 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                                         py[2 * c], qx[2 * c], qy[2 * c])
+                                           : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                                    py[2 * c], qx[2 * c], qy[2 * c]);
+                    const double d1 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                                         py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1])
+                                           : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                                    py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
                     if (WRITE_R) {
                         const int n = wbase + c * 128 + lane * 2;
                         double* dstp = R + (size_t)m * ldr + n;
@@ -121,8 +132,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                             dstp[0] = d0;
                         }
                     }
-                    c_m += __popcll(__ballot(ok[2 * c] && d0 < thr2));
-                    c_m += __popcll(__ballot(ok[2 * c + 1] && d1 < thr2));
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c] && d0 < thr2));
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c + 1] && d1 < thr2));
                 }
                 cnt += (lane == mi) ? c_m : 0;
             }
@@ -140,7 +151,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     }
 }
 
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT>
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s)
 {
@@ -159,7 +170,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         if (e != hipSuccess) return e;
     }
     dim3 grid(gx, psplit);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit);
     return hipGetLastError();
 }
@@ -173,15 +184,28 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 3: return launch_rs<2, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     case 4: return launch_rs<2, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    default: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 7: return launch_rs<2, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration
+    case 8: return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration
+    case 9: return launch_rs<4, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);        // PPL4 + IEEE division
+    case 10: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);               // PPL4 + nt
+    case 11: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 12: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 6: return launch_rs<2, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // compiler IEEE division
+    case 13: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    default: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, nt stores
     }
 }
 
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
-                        const unsigned char* mask, int* counts, hipStream_t s)
+                        const unsigned char* mask, int* counts, int variant, hipStream_t s)
 {
     if (mask) return launch_rs<2, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
-    return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    switch (variant) {
+    case 1: return launch_rs<2, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    case 2: return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    case 3: return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    default: return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    }
 }
 
 // ComputeInliersOfHomography, M/MultiH.cpp:743-768.

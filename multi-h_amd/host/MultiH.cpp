@@ -1,0 +1,392 @@
+// MultiH.cpp — the reference's orchestrator (M/MultiH.cpp) re-created over the
+// gfx950 engine's C ABI.  Every heavy step is one mh_* call; this file holds the
+// control flow of Process / ClusterMergingAndLabeling / MergingStep /
+// LabelingStep with the reference's stop rules and conventions.
+#include "MultiH.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+
+#include "merge_step.h"
+#include "multih_hip.h"
+
+namespace {
+
+cv::Mat MatFrom9(const double* h)
+{
+    cv::Mat m(3, 3, CV_64F);
+    double* p = reinterpret_cast<double*>(m.data);
+    for (int i = 0; i < 9; ++i) p[i] = h[i];
+    return m;
+}
+
+bool Check(int rc, const char* what)
+{
+    if (rc == MH_OK) return true;
+    std::cerr << "[Multi-H] engine error in " << what << ": " << mh_last_error() << "\n";
+    return false;
+}
+
+} // namespace
+
+MultiH::MultiH(double _thr_fund_mat, double _thr_hom, double _locality, double _lambda,
+               int _minimum_inlier_number)
+    : minimum_inlier_number(_minimum_inlier_number),
+      threshold_fundamental_matrix(_thr_fund_mat),
+      threshold_homography(_thr_hom),
+      sqr_threshold_homography(_thr_hom * _thr_hom),
+      locality_lambda(_locality),
+      energy_lambda(_lambda),
+      affine_threshold(DEFAULT_AFFINE_THRESHOLD),
+      straightness_threshold(DEFAULT_LINENESS_THRESHOLD)
+{
+    for (double& f : fundamental_matrix) f = 0.0;
+    epipole_2[0] = epipole_2[1] = 0.0;
+}
+
+MultiH::~MultiH() { Release(); }
+
+void MultiH::Release()
+{
+    if (engine) { mh_destroy(engine); engine = nullptr; }
+}
+
+void MultiH::SetEpipolarGeometry(const double F[9], const double e2[2])
+{
+    for (int i = 0; i < 9; ++i) fundamental_matrix[i] = F[i];
+    epipole_2[0] = e2[0];
+    epipole_2[1] = e2[1];
+    have_epipolar = true;
+}
+
+void MultiH::SetNeighbours(const std::vector<std::vector<int>>& hits) { neighbours = hits; }
+
+void MultiH::SetInitialHomographies(const std::vector<cv::Mat>& Hs)
+{
+    initial_homographies.clear();
+    for (const cv::Mat& h : Hs) initial_homographies.push_back(h.clone());
+}
+
+void MultiH::SetProposal(uint64_t seed, int hypotheses, int max_models)
+{
+    proposal_seed = seed;
+    proposal_hypotheses = hypotheses;
+    proposal_max_models = max_models;
+}
+
+bool MultiH::Process(std::vector<cv::Point2d> _srcPoints, std::vector<cv::Point2d> _dstPoints,
+                     std::vector<cv::Mat> _affines)
+{
+    printf("[Multi-H] Processing has been started.\n");
+    src_points_original = _srcPoints;
+    dst_points_original = _dstPoints;
+    affinities_original = _affines;
+    return Process();
+}
+
+bool MultiH::EnsureEngine()
+{
+    if (!engine && !Check(mh_create(&engine, device), "mh_create")) return false;
+    return Check(mh_set_params(engine, threshold_fundamental_matrix, threshold_homography,
+                               locality_lambda, energy_lambda, minimum_inlier_number),
+                 "mh_set_params");
+}
+
+bool MultiH::Process()
+{
+    if (src_points_original.size() < 8 || dst_points_original.size() != src_points_original.size() ||
+        affinities_original.size() != src_points_original.size()) {
+        std::cerr << "Error: Features are not set!\n";                       // M/MultiH.cpp:48
+        return false;
+    }
+    if (!EnsureEngine()) return false;
+
+    // The reference filters/refines the input with F here (GetFundamentalMatrixAndRefineData,
+    // M/MultiH.cpp:52, :770-848; §8(f) row 4).  That stage is upstream of this class now: the
+    // points are taken as already refined and F / e2 come from SetEpipolarGeometry.  Without
+    // them the case is "degenerate" exactly as when the reference cannot estimate F (:55-58).
+    src_points = src_points_original;
+    dst_points = dst_points_original;
+    affinities = affinities_original;
+    degenerate_case = !have_epipolar;
+    cluster_homographies.clear();
+    labeling.clear();
+
+    const int N = static_cast<int>(src_points.size());
+    std::vector<double> s(2 * (size_t)N), d(2 * (size_t)N), a(4 * (size_t)N);
+    for (int i = 0; i < N; ++i) {
+        s[2 * i] = src_points[i].x; s[2 * i + 1] = src_points[i].y;
+        d[2 * i] = dst_points[i].x; d[2 * i + 1] = dst_points[i].y;
+        const cv::Mat& A = affinities[i];
+        a[4 * i] = A.at<double>(0, 0); a[4 * i + 1] = A.at<double>(0, 1);
+        a[4 * i + 2] = A.at<double>(1, 0); a[4 * i + 3] = A.at<double>(1, 1);
+    }
+    if (!Check(mh_set_correspondences(engine, s.data(), d.data(), a.data(), N), "mh_set_correspondences"))
+        return false;
+
+    if (degenerate_case) {
+        HandleDegenerateCase();
+        return true;
+    }
+    if (!Check(mh_set_epipolar(engine, fundamental_matrix, epipole_2), "mh_set_epipolar")) return false;
+
+    if (!initial_homographies.empty()) {
+        for (const cv::Mat& h : initial_homographies) cluster_homographies.push_back(h.clone());
+    } else if (!ProposeInitialModels()) {
+        return false;
+    }
+
+    ClusterMergingAndLabeling();
+
+    if (cluster_homographies.size() > 1) HomographyCompatibilityCheck();     // :78-86 (no-op, §8(f) row 3)
+
+    if (cluster_homographies.size() <= 1) {                                  // :88-94
+        labeling.clear();
+        labeling.resize(src_points.size(), -1);
+        cluster_homographies.resize(0);
+        HandleDegenerateCase();
+    }
+    return true;
+}
+
+bool MultiH::UploadModels()
+{
+    const int nh = static_cast<int>(cluster_homographies.size());
+    std::vector<double> H(9 * (size_t)nh);
+    for (int i = 0; i < nh; ++i) {
+        const double* p = reinterpret_cast<const double*>(cluster_homographies[i].data);
+        for (int k = 0; k < 9; ++k) H[9 * (size_t)i + k] = p[k];
+    }
+    return Check(mh_set_models(engine, H.data(), nh), "mh_set_models");
+}
+
+bool MultiH::DownloadModels(int count)
+{
+    std::vector<double> H(9 * (size_t)count);
+    if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
+    cluster_homographies.clear();
+    for (int i = 0; i < count; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
+    return true;
+}
+
+// north_star "propose": a batch of minimal-sample DLT hypotheses scored against all points,
+// then greedy selection — take the best-supported hypothesis, remove its inliers from the
+// support mask, re-score, repeat (the sequential-RANSAC scheme of the dead
+// M/MultipleHomographies.h:146-175, where points already claimed are skipped via usabilityMask).
+bool MultiH::ProposeInitialModels()
+{
+    const int N = static_cast<int>(src_points.size());
+    const int M = proposal_hypotheses;
+    const int need = std::max(minimum_inlier_number, 8);
+    if (!Check(mh_propose_dlt4(engine, proposal_seed, 0, M), "mh_propose_dlt4")) return false;
+    std::vector<double> H(9 * (size_t)M);
+    if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
+    std::vector<int> counts(M);
+    std::vector<unsigned char> mask(N, 1);
+    std::vector<int> lab(N);
+    for (int round = 0; round < proposal_max_models; ++round) {
+        if (!Check(mh_score(engine, sqr_threshold_homography, round ? mask.data() : nullptr, counts.data()),
+                   "mh_score"))
+            return false;
+        const int best = static_cast<int>(std::max_element(counts.begin(), counts.end()) - counts.begin());
+        if (counts[best] < need) break;
+        cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)best]));
+        std::fill(lab.begin(), lab.end(), -1);
+        if (!Check(mh_inliers_of_model(engine, best, sqr_threshold_homography, 0, lab.data()),
+                   "mh_inliers_of_model"))
+            return false;
+        for (int i = 0; i < N; ++i) if (lab[i] == 0) mask[i] = 0;
+    }
+    if (log_to_console)
+        printf("[Multi-H] Proposed %d models from %d DLT hypotheses\n", (int)cluster_homographies.size(), M);
+    return true;
+}
+
+void MultiH::ClusterMergingAndLabeling()
+{
+    auto start = std::chrono::system_clock::now();
+    const int N = static_cast<int>(src_points.size());
+
+    // Neighbourhood (M/MultiH.cpp:233-253).  Given hits are used as they are; otherwise the
+    // engine builds exact k-NN hits in the same float32 (x1,y1,x2,y2) space (deviation
+    // from FLANN's approximate radius search).
+    bool ok;
+    if (!neighbours.empty()) {
+        std::vector<int> rowptr(N + 1, 0), col;
+        for (int i = 0; i < N; ++i) {
+            if (i < (int)neighbours.size()) col.insert(col.end(), neighbours[i].begin(), neighbours[i].end());
+            rowptr[i + 1] = static_cast<int>(col.size());
+        }
+        ok = Check(mh_set_neighbors_csr(engine, rowptr.data(), col.data(), N), "mh_set_neighbors_csr");
+    } else {
+        ok = Check(mh_build_neighbors_knn(engine, std::min(knn, N - 1)), "mh_build_neighbors_knn");
+    }
+    std::chrono::duration<double> el = std::chrono::system_clock::now() - start;
+    printf("[Multi-H] Adjacency-matrix calculation time = %f secs\n", el.count());      // :258
+    if (!ok) { cluster_homographies.clear(); return; }
+
+    start = std::chrono::system_clock::now();
+    int iteration_number = 0;
+    labeling.resize(N, -1);                                                             // :263
+    double lastEnergy = INT_MAX;
+    int not_changed_number = 0;
+
+    while (iteration_number++ < MAX_ITERATION_NUMBER) {                                 // :267
+        bool changed = false;
+        if (!MergingStep(changed)) break;
+        if (changed) not_changed_number = 0;
+        else ++not_changed_number;
+
+        if (cluster_homographies.size() == 1) {                                         // :280-285
+            labeling.resize(N, -1);
+            ComputeInliersOfHomography(0);
+            break;
+        } else if (cluster_homographies.size() == 0)
+            break;
+
+        double energy;
+        if (!LabelingStep(energy, changed)) break;
+        if (log_to_console)
+            printf("Iteration %d.   Number of clusters = %d   Energy = %f\n", iteration_number,
+                   (int)cluster_homographies.size(), energy);
+
+        if ((!changed && std::abs(lastEnergy - energy) < CONVERGENCE_THRESHOLD) || not_changed_number > 10 ||
+            (fixed_iterations > 0 && iteration_number >= fixed_iterations)) {           // :295
+            final_energy = energy;
+            break;
+        }
+        lastEnergy = energy;
+    }
+    printf("[Multi-H] Optimization started... Iteration %d\n", iteration_number);       // :305
+    el = std::chrono::system_clock::now() - start;
+    loop_seconds = el.count();
+    printf("[Multi-H] Alternating optimization time = %f secs\n", el.count());          // :310
+    final_iteration_number = iteration_number - 1;                                      // :311
+}
+
+// MergingStep, M/MultiH.cpp:352-471: models -> 6-D features -> mean-shift modes -> one
+// homography per mode -> inlier scoring + collinearity filter -> `changed` iff the count changed.
+// Mode -> homography uses the linear part of GetHomography3PT (:995-1050); the LM refinement
+// (:1052) is not reproduced (DESIGN.md "deviations").  The N x modes scoring and the 3x3 scatter
+// eigen test (:430-463) run on the GPU (mh_inlier_moments).
+bool MultiH::MergingStep(bool& changed)
+{
+    const int nh = static_cast<int>(cluster_homographies.size());
+    changed = false;
+    if (nh == 0) return true;
+    std::vector<double> H(9 * (size_t)nh), feat(6 * (size_t)nh);
+    for (int i = 0; i < nh; ++i) {
+        const double* p = reinterpret_cast<const double*>(cluster_homographies[i].data);
+        for (int k = 0; k < 9; ++k) H[9 * (size_t)i + k] = p[k];
+    }
+    multih::HomographyFeatures(H.data(), nh, feat.data());
+    multih::MeanShiftResult ms;
+    uint64_t draws = 0;
+    multih::MeanShiftCluster(feat.data(), nh, 6, threshold_homography, proposal_seed ^ 0x4d53u ^ (merge_rng_counter << 20),
+                             ms, &draws);
+    ++merge_rng_counter;
+
+    const int k = static_cast<int>(ms.members.size());
+    std::vector<double> cand;
+    const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                        // :408
+    for (int i = 0; i < k; ++i) {
+        double Hc[9];
+        if (multih::Homography3PTLinear(pts1, &ms.modes[6 * (size_t)i], 3, fundamental_matrix, Hc))
+            cand.insert(cand.end(), Hc, Hc + 9);
+    }
+    const int nc = static_cast<int>(cand.size() / 9);
+    std::vector<cv::Mat> kept;
+    if (nc > 0) {
+        if (!Check(mh_set_models(engine, cand.data(), nc), "mh_set_models")) return false;
+        std::vector<double> mom(6 * (size_t)nc), mineig(nc);
+        if (!Check(mh_inlier_moments(engine, sqr_threshold_homography, mom.data(), mineig.data()),
+                   "mh_inlier_moments"))
+            return false;
+        for (int i = 0; i < nc; ++i) {
+            const int inl = static_cast<int>(mom[6 * (size_t)i]);
+            if (mineig[i] < straightness_threshold || inl < 3) continue;               // :462
+            kept.push_back(MatFrom9(&cand[9 * (size_t)i]));
+        }
+    }
+    changed = kept.size() != cluster_homographies.size();                               // :468
+    if (changed) cluster_homographies = kept;                                           // :469-470
+    return true;
+}
+
+bool MultiH::LabelingStep(double& energy, bool changed)
+{
+    energy = 0;
+    if (!UploadModels()) return false;
+    int cycles = 0;
+    if (!Check(mh_labeling_step(engine, changed ? 0 : 1, labeling.data(), &energy, &cycles), "mh_labeling_step"))
+        return false;
+    return DownloadModels(static_cast<int>(cluster_homographies.size()));
+}
+
+void MultiH::ComputeInliersOfHomography(int idx)
+{
+    if (!UploadModels()) return;
+    Check(mh_inliers_of_model(engine, idx, sqr_threshold_homography, idx, labeling.data()), "mh_inliers_of_model");
+}
+
+// HandleDegenerateCase (M/MultiH.cpp:719-741) calls cv::findHomography(RANSAC) on the ORIGINAL
+// points and labels its inliers 0.  Here: best-supported of `proposal_hypotheses` DLT hypotheses.
+void MultiH::HandleDegenerateCase()
+{
+    const int N = static_cast<int>(src_points_original.size());
+    labeling.assign(N, -1);
+    const int M = std::max(proposal_hypotheses, 1000);
+    if (!Check(mh_propose_dlt4(engine, proposal_seed ^ 0xdeadull, 0, M), "mh_propose_dlt4")) return;
+    std::vector<int> counts(M);
+    if (!Check(mh_score(engine, sqr_threshold_homography, nullptr, counts.data()), "mh_score")) return;
+    const int best = static_cast<int>(std::max_element(counts.begin(), counts.end()) - counts.begin());
+    std::vector<double> H(9 * (size_t)M);
+    if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return;
+    if (!Check(mh_inliers_of_model(engine, best, sqr_threshold_homography, 0, labeling.data()), "mh_inliers_of_model"))
+        return;
+    cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)best]));
+}
+
+// ---- C hook for the GPU-side integration test (ctypes; plain arrays in/out) ----------------
+extern "C" __attribute__((visibility("default")))
+int mhh_run_process(const double* src_xy, const double* dst_xy, const double* aff, int n,
+                    const double* F, const double* e2, double thr_F, double thr_H, double locality,
+                    double lambda, int min_inliers, unsigned long long seed, int hypotheses,
+                    int max_models, int fixed_iterations, const double* init_H, int n_init,
+                    int* labels_out, double* H_out, int max_H, int* iterations, double* energy,
+                    double* loop_seconds)
+{
+    std::vector<cv::Point2d> s(n), d(n);
+    std::vector<cv::Mat> a(n);
+    for (int i = 0; i < n; ++i) {
+        s[i] = cv::Point2d(src_xy[2 * i], src_xy[2 * i + 1]);
+        d[i] = cv::Point2d(dst_xy[2 * i], dst_xy[2 * i + 1]);
+        a[i] = cv::Mat(2, 2, CV_64F, aff + 4 * (size_t)i);
+    }
+    MultiH mh(thr_F, thr_H, locality, lambda, min_inliers);
+    if (F && e2) mh.SetEpipolarGeometry(F, e2);
+    mh.SetProposal(seed, hypotheses, max_models);
+    mh.SetFixedIterations(fixed_iterations);
+    if (init_H && n_init > 0) {
+        std::vector<cv::Mat> hs;
+        for (int i = 0; i < n_init; ++i) hs.push_back(cv::Mat(3, 3, CV_64F, init_H + 9 * (size_t)i));
+        mh.SetInitialHomographies(hs);
+    }
+    if (!mh.Process(s, d, a)) return -1;
+    std::vector<int> lab;
+    mh.GetLabels(lab);
+    for (size_t i = 0; i < lab.size() && i < (size_t)n; ++i) labels_out[i] = lab[i];
+    const int k = mh.GetClusterNumber();
+    for (int i = 1; i <= k && i <= max_H; ++i) {
+        cv::Mat h = mh.GetHomography(i);
+        for (int q = 0; q < 9; ++q) H_out[9 * (size_t)(i - 1) + q] = reinterpret_cast<double*>(h.data)[q];
+    }
+    if (iterations) *iterations = mh.GetIterationNumber();
+    if (energy) *energy = mh.GetEnergy();
+    if (loop_seconds) *loop_seconds = mh.GetLastLoopSeconds();
+    return k;
+}

@@ -1,0 +1,126 @@
+// MultiH.h — host-side mirror of the reference's class `MultiH`
+// (M/MultiH.h:20-149, M/ = /root/reference/MultiH/MultiH/) implemented over the
+// C ABI of the gfx950 engine (include/multih_hip.h).  Same class name, same
+// public signatures, same defaults, same label / index conventions, same error
+// behaviour (Process() returns false and writes "Error: Features are not set!"
+// to stderr, M/MultiH.cpp:44-50), so `ApplyMultiH` (M/main.cpp:232-311) can
+// construct it, call Process and read the getters unchanged.
+//
+// Scope: Process() runs the propose-score-label hot loop
+// (ClusterMergingAndLabeling, M/MultiH.cpp:224-312) on the GPU.  The OpenCV-bound
+// front half of the reference's Process() — findFundamentalMat, Hartley-Sturm
+// correction, affine consistency, per-point HAF, stable-set initialisation
+// (M/MultiH.cpp:770-848, 696-717, 604-694) — is §8(f) row 4 ("next") and is NOT
+// re-implemented: its outputs are supplied through the Set* extension methods
+// below (F + epipole, optional neighbour hits, optional initial models).  When no
+// initial models are given the engine proposes them itself from random minimal
+// samples with the batched 4-point DLT (north_star).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "cv_shim.h"
+
+#define DEFAULT_THRESHOLD_FUNDAMENTAL_MATRIX 3.0    // M/MultiH.h:7
+#define DEFAULT_THRESHOLD_HOMOGRAPHY 2.5            // :8
+#define DEFAULT_LOCALITY 0.002                      // :9
+#define DEFAULT_LAMBDA 0.5                          // :10
+#define DEFAULT_AFFINE_THRESHOLD 1.0                // :12
+#define DEFAULT_LINENESS_THRESHOLD 0.005            // :13
+#define MAX_ITERATION_NUMBER 500                    // :14
+#define CONVERGENCE_THRESHOLD 1e-5                  // :15
+
+struct mh_engine;
+
+class MultiH {
+public:
+    MultiH(double _thr_fund_mat = DEFAULT_THRESHOLD_FUNDAMENTAL_MATRIX,
+           double _thr_hom = DEFAULT_THRESHOLD_HOMOGRAPHY, double _locality = DEFAULT_LOCALITY,
+           double _lambda = DEFAULT_LAMBDA, int _minimum_inlier_number = 0);
+    ~MultiH();
+    void Release();
+
+    // M/MultiH.h:58-59.  Arguments by value, copied into *_original (M/MultiH.cpp:32-40).
+    bool Process(std::vector<cv::Point2d> _srcPoints, std::vector<cv::Point2d> _dstPoints,
+                 std::vector<cv::Mat> _affines);
+    bool Process();
+
+    // M/MultiH.h:61-75
+    int GetLabel(int idx) { return labeling[idx]; }
+    void GetLabels(std::vector<int>& _labeling) { _labeling = labeling; }
+    void GetSourcePoints(std::vector<cv::Point2d>& _src_points) { _src_points = src_points; }
+    // The reference returns the SOURCE points here (M/MultiH.h:64, SURVEY A-9); result files
+    // written by the harness therefore carry x2,y2 = x1,y1.  Reproduced for drop-in parity.
+    void GetDestinationPoints(std::vector<cv::Point2d>& _dst_points) { _dst_points = src_points; }
+    void GetAffinities(std::vector<cv::Mat>& _affinities) { _affinities = affinities; }
+    int GetPointNumber() { return static_cast<int>(labeling.size()); }
+    int GetClusterNumber() { return static_cast<int>(cluster_homographies.size()); }
+    int GetIterationNumber() { return final_iteration_number; }
+    cv::Mat GetHomography(int idx) { return cluster_homographies[idx - 1]; }   // 1-based, :69
+    double GetEnergy() { return final_energy; }
+    double GetHomographyThreshold() { return threshold_homography; }
+    // Post-filter of the reference (M/MultiH.cpp:100-222): §8(f) row 3, not part of the hot loop.
+    void HomographyCompatibilityCheck() {}
+
+    // ---- extension points: outputs of the reference's OpenCV front half ----
+    // fundamental_matrix (row-major) and epipole_2 = (x, y, 1) (M/MultiH.cpp:775-799).
+    void SetEpipolarGeometry(const double F[9], const double e2[2]);
+    // `neighbours` (M/MultiH.cpp:252-253): per query the hit indices (self allowed).
+    // Without it Process() builds exact k-NN hits on the GPU (k = knn, default 16).
+    void SetNeighbours(const std::vector<std::vector<int>>& hits);
+    void SetNeighbourK(int k) { knn = k; }
+    // Initial cluster_homographies (what EstablishStablePointSets hands to the loop).
+    void SetInitialHomographies(const std::vector<cv::Mat>& Hs);
+    // Propose step used when no initial models are given: `hypotheses` random 4-tuples ->
+    // DLT -> greedy selection of at most `max_models` models with >= max(min inliers, 8).
+    void SetProposal(uint64_t seed, int hypotheses, int max_models);
+    // north_star C5 runs a fixed number of propose-expand iterations instead of the
+    // convergence test; 0 restores the reference's stop rule (:295).
+    void SetFixedIterations(int n) { fixed_iterations = n; }
+    void SetDevice(int d) { device = d; }
+    void SetVerbose(bool v) { log_to_console = v; }
+    double GetLastLoopSeconds() const { return loop_seconds; }
+
+protected:
+    std::vector<cv::Point2d> src_points_original, dst_points_original;   // M/MultiH.h:78
+    std::vector<cv::Point2d> src_points, dst_points;                     // :79
+    std::vector<cv::Mat> affinities_original, affinities;                // :80
+    double fundamental_matrix[9];
+    double epipole_2[2];
+    bool have_epipolar = false;
+    bool log_to_console = false;
+    bool degenerate_case = false;
+    double final_energy = 0.0;
+    std::vector<std::vector<int>> neighbours;                            // :86 (trainIdx only)
+    std::vector<cv::Mat> cluster_homographies;                           // :87
+    std::vector<int> labeling;                                           // :88
+    int minimum_inlier_number;
+    double threshold_fundamental_matrix;
+    double threshold_homography, sqr_threshold_homography;
+    double locality_lambda, energy_lambda;
+    double affine_threshold, straightness_threshold;
+    int final_iteration_number = 0;
+
+    // engine state
+    mh_engine* engine = nullptr;
+    int device = 0;
+    int knn = 16;
+    uint64_t proposal_seed = 1234;
+    int proposal_hypotheses = 10000;
+    int proposal_max_models = 32;
+    int fixed_iterations = 0;
+    uint64_t merge_rng_counter = 0;
+    double loop_seconds = 0.0;
+    std::vector<cv::Mat> initial_homographies;
+
+    bool EnsureEngine();
+    bool UploadModels();
+    bool DownloadModels(int count);
+    bool ProposeInitialModels();          // north_star propose: DLT batch + greedy selection
+    void ClusterMergingAndLabeling();     // M/MultiH.cpp:224-312
+    bool MergingStep(bool& changed);      // :352-471
+    bool LabelingStep(double& energy, bool changed);   // :513-602
+    void ComputeInliersOfHomography(int idx);          // :743-768
+    void HandleDegenerateCase();                       // :719-741 (single best DLT model)
+};

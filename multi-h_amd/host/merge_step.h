@@ -1,0 +1,38 @@
+// merge_step.h — host-side pieces of MergingStep (M/MultiH.cpp:352-471): the 6-D
+// feature map, the mean-shift mode seeker and the 3-point homography from a mode.
+// Nh (number of models) is tens to hundreds, so these run on the host; the
+// N x Nh scoring they feed is done by the GPU engine.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace multih {
+
+// Images of (0,0), (1,0), (0,1) under H (M/MultiH.cpp:364-387): 6 doubles per model.
+void HomographyFeatures(const double* H /* nh x 9 */, int nh, double* feat /* nh x 6 */);
+
+struct MeanShiftResult {
+    int dim = 0;
+    std::vector<double> modes;                 // k x dim
+    std::vector<std::vector<int>> members;     // per mode: row indices voted to it
+};
+
+// MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157): flat kernel, membership
+// test  sum_j sqrt(d_j^2) < bandWidth^2  (an L1 ball, quirk A-8), stop when the mean moves less
+// than 1e-3*bandWidth, merge modes closer than bandWidth/2, assign rows by votes.  The
+// reference draws seeds with the unseeded C rand() (:54-56); here draw number c uses
+// u = (splitmix64(seed + c) >> 11) * 2^-53, so runs are reproducible.  `draws` returns the
+// number of draws consumed.  A shift that captures no row (the reference would spin forever
+// on a NaN mean) ends that seed's climb.
+void MeanShiftCluster(const double* data, int num_pts, int num_dim, double band_width,
+                      uint64_t seed, MeanShiftResult& out, uint64_t* draws = nullptr);
+
+// GetHomography3PT (M/MultiH.cpp:995-1055) WITHOUT the LM refinement (:1052-1053): Hartley
+// normalisation of both point sets (Homography_Refine3PTCallback.h:146-272), normalised F and
+// epipole (:1009-1017), the 2n x 3 least-squares system (:1019-1038), H rows (:1040-1050),
+// de-normalisation (:1054).  n >= 3 points; pts are x,y pairs.  Returns false when the
+// normal equations are singular.
+bool Homography3PTLinear(const double* pts1, const double* pts2, int n, const double F[9],
+                         double H[9]);
+
+} // namespace multih

@@ -1,0 +1,71 @@
+"""Hypothesis sharding across the GPUs of one node.
+
+Hypotheses are independent, so the propose+score stage shards with no data-path
+collective: correspondences (32 B/point) are replicated, rank r owns the RNG
+counters [first_r, first_r + m_r) of the global batch, and the only exchange is
+one all-gather of the per-model int32 inlier scores (4*M bytes in total,
+latency-bound on xGMI) after which every rank runs the same selection on the
+same array.  One process per GPU, `torch.distributed` (backend "nccl" = RCCL on
+ROCm, "gloo" in the CPU tests).
+
+The functions here are device-agnostic tensor plumbing; the scoring itself is
+the engine's kernel (or, in the CPU tests only, the oracle standing in for it).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_counts(total: int, world: int) -> list[int]:
+    """Sizes of the `world` contiguous shards of `total` hypotheses (first shards one longer)."""
+    base, rem = divmod(int(total), int(world))
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
+def shard_range(total: int, world: int, rank: int) -> tuple[int, int]:
+    """(first, count) of rank's shard inside a global batch of `total` hypotheses."""
+    sizes = shard_counts(total, world)
+    return sum(sizes[:rank]), sizes[rank]
+
+
+def batch_first(step: int, world: int, rank: int, per_rank: int) -> int:
+    """Weak scaling: every (step, rank) owns a disjoint block of `per_rank` RNG counters."""
+    return (int(step) * int(world) + int(rank)) * int(per_rank)
+
+
+def gather_scores(local: torch.Tensor, world: int, out: torch.Tensor | None = None,
+                  sizes: list[int] | None = None) -> torch.Tensor:
+    """All-gather the per-model scores of every rank into one flat int32 tensor, rank order.
+
+    Equal shard sizes use all_gather_into_tensor (one RCCL call, no copies); ragged shards
+    (strong scaling with world not dividing M) pad to the longest shard and strip the padding."""
+    if world == 1:
+        return local
+    if sizes is None or len(set(sizes)) == 1:
+        if out is None:
+            out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    longest = max(sizes)
+    padded = torch.full((longest,), -1, dtype=local.dtype, device=local.device)
+    padded[: local.numel()] = local
+    buf = torch.empty(world * longest, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded)
+    return torch.cat([buf[r * longest: r * longest + sizes[r]] for r in range(world)])
+
+
+def select_best(scores: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Index (into the gathered array) and score of the best-supported model; first maximum wins,
+    so every rank picks the same model from the same gathered array."""
+    best = torch.argmax(scores)
+    return best, scores[best]
+
+
+def global_model_index(flat_index: int, sizes: list[int]) -> tuple[int, int]:
+    """(rank, local index) of an index into the gathered score array."""
+    r = 0
+    while flat_index >= sizes[r]:
+        flat_index -= sizes[r]
+        r += 1
+    return r, flat_index

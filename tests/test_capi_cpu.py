@@ -1,0 +1,74 @@
+"""CPU tests of the drop-in boundary: the library loads, exports exactly what
+include/multih_hip.h declares, refuses to run without a GPU (no CPU fallback), and the
+product tree never reaches into oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "multih_hip.h")).read()
+    return re.findall(r"^MH_API\s+[\w\s\*]+?\b(mh_\w+)\s*\(", text, flags=re.M)
+
+
+def test_header_symbols_match_binding_and_library(mh, engine_lib):
+    declared = _declared()
+    assert len(declared) == len(set(declared)) >= 30
+    assert sorted(declared) == sorted(mh.SYMBOLS), "capi.SYMBOLS out of sync with the header"
+    for s in declared:
+        assert hasattr(engine_lib, s), f"{s} declared in the header but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", mh.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (mh_\w+)", out))
+    assert exported == set(declared), "library exports symbols the header does not declare (or vice versa)"
+
+
+def test_abi_version_and_error_string(engine_lib):
+    assert engine_lib.mh_abi_version() == 1
+    assert isinstance(engine_lib.mh_last_error(), (bytes, type(None)))
+    assert engine_lib.mh_device_count() >= 0
+
+
+def test_no_cpu_fallback(mh, engine_lib):
+    if engine_lib.mh_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(mh.MultiHError) as ei:
+        mh.Engine()
+    assert ei.value.code == -1 and "no CPU fallback" in str(ei.value)
+    # null-handle calls fail with a status, they never crash or compute
+    assert engine_lib.mh_score(None, ctypes.c_double(1.0), None, None) == -2
+    assert engine_lib.mh_data_cost(None, None) == -2
+
+
+def test_host_library_exports_class_hooks(mh, engine_lib):
+    host = os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so")
+    assert os.path.exists(host), "host layer not built"
+    lib = ctypes.CDLL(host)
+    for s in ("mhh_run_process", "mhh_mean_shift", "mhh_homography_3pt", "mhh_homography_features"):
+        assert hasattr(lib, s)
+    out = subprocess.run(["nm", "-DC", "--defined-only", host], capture_output=True, text=True).stdout
+    for method in ("MultiH::Process(", "MultiH::MultiH(", "MultiH::Release()"):
+        assert method in out
+
+
+def test_product_tree_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under multi-h_amd/ or include/ may import,
+    link or dlopen it (a product path through the oracle would void every parity claim)."""
+    bad = []
+    for base in ("multi-h_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            if "_build" in dp or "__pycache__" in dp:
+                continue
+            for f in files:
+                if not f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    continue
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"oracle_lib|libmh_oracle|libmh_ref_gco|mho_\w+\(|#include\s+\"[^\"]*oracle", text):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, f"product files reference the oracle: {bad}"
+    out = subprocess.run(["ldd", os.path.join(ROOT, "multi-h_amd", "libmultih_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -1,0 +1,127 @@
+"""CPU tests of the host-side MergingStep pieces (multi-h_amd/host/merge_step.cpp) against
+numpy restatements of the reference code they mirror."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_dp = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def host(mh, engine_lib):
+    return C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+
+
+def _splitmix64(z):
+    m = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def np_mean_shift(data, bw, seed):
+    """numpy restatement of MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157)
+    with the explicit seed RNG of merge_step.h."""
+    n, d = data.shape
+    band_sq, stop = bw * bw, 1e-3 * bw
+    visited = np.zeros(n, bool)
+    init = list(range(n))
+    cent, votes = [], []
+    c = 0
+    while init:
+        rnd = (_splitmix64(seed + c) >> 11) * (1.0 / 9007199254740992.0)
+        c += 1
+        st = init[int(np.floor(rnd * (len(init) - 1) + 0.5))]
+        mean = data[st].copy()
+        my = np.zeros(n, int)
+        while True:
+            old = mean.copy()
+            dist = np.sqrt((old[None, :] - data) ** 2).sum(axis=1)       # L1 via sqrt of squares
+            inl = dist < band_sq
+            my += inl
+            visited |= inl
+            if inl.sum() == 0:
+                visited[st] = True
+                break
+            acc = np.zeros(d)
+            for i in np.flatnonzero(inl):
+                acc = acc + data[i]
+            mean = acc * (1.0 / inl.sum())
+            if np.sqrt(((mean - old) ** 2).sum()) < stop:
+                mw = -1
+                for k, cc in enumerate(cent):
+                    if np.sqrt(((mean - cc) ** 2).sum()) < bw / 2:
+                        mw = k
+                        break
+                if mw >= 0:
+                    cent[mw] = 0.5 * (cent[mw] + mean)
+                    votes[mw] = votes[mw] + my
+                else:
+                    cent.append(mean)
+                    votes.append(my.copy())
+                break
+        init = [i for i in range(n) if not visited[i]]
+    best_v, best_i = np.zeros(n, int), np.full(n, -1)
+    for r, v in enumerate(votes):
+        upd = best_v < v
+        best_v[upd] = v[upd]
+        best_i[upd] = r
+    return np.array(cent), best_i, c
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_mean_shift_matches_numpy_restatement(host, seed):
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-50, 50, size=(4, 6))
+    data = np.concatenate([c + rng.normal(0, 0.15, size=(12, 6)) for c in centres] + [rng.uniform(-50, 50, size=(5, 6))])
+    data = np.ascontiguousarray(data)
+    n = data.shape[0]
+    modes = np.zeros((n, 6))
+    assign = np.zeros(n, dtype=np.int32)
+    draws = C.c_ulonglong(0)
+    k = host.mhh_mean_shift(data.ctypes.data_as(_dp), n, 6, C.c_double(2.2), C.c_ulonglong(seed),
+                            modes.ctypes.data_as(_dp), n, assign.ctypes.data_as(C.POINTER(C.c_int)), C.byref(draws))
+    cent, best_i, c = np_mean_shift(data, 2.2, seed)
+    assert k == len(cent) and draws.value == c
+    assert np.allclose(modes[:k], cent, rtol=0, atol=1e-12)
+    assert np.array_equal(assign, best_i)
+    # the four tight clusters are each one mode
+    for j in range(4):
+        assert len(set(assign[12 * j: 12 * (j + 1)])) == 1
+
+
+def test_homography_features(host):
+    rng = np.random.default_rng(0)
+    H = rng.normal(size=(5, 9))
+    feat = np.zeros((5, 6))
+    host.mhh_homography_features(H.ctypes.data_as(_dp), 5, feat.ctypes.data_as(_dp))
+    for i in range(5):
+        h = H[i].reshape(3, 3)
+        exp = []
+        for p in ([0, 0, 1], [1, 0, 1], [0, 1, 1]):
+            q = h @ np.array(p, float)
+            exp += [q[0] / q[2], q[1] / q[2]]
+        assert np.allclose(feat[i], exp, rtol=1e-13)
+
+
+def test_homography_3pt_linear(host, synth):
+    """GetHomography3PT's linear part (M/MultiH.cpp:995-1050): three exact correspondences of a
+    plane compatible with F reproduce that plane's homography."""
+    sc = synth.make_scene(50, 3, seed=4, noise=0.0, outlier_frac=0.0, with_neighbours=False)
+    pts1 = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])            # the canonical points of MergingStep
+    for k in range(3):
+        pts2 = np.ascontiguousarray(synth.apply_h(sc.H_true[k], pts1))
+        H = np.zeros(9)
+        F = np.ascontiguousarray(sc.F)
+        ok = host.mhh_homography_3pt(pts1.ctypes.data_as(_dp), pts2.ctypes.data_as(_dp), 3, F.ctypes.data_as(_dp),
+                                     H.ctypes.data_as(_dp))
+        assert ok == 1
+        a, b = H / H[8], sc.H_true[k] / sc.H_true[k][8]
+        assert np.max(np.abs(a - b) / np.maximum(1e-6, np.abs(b))) < 1e-6
+        # and it maps the scene's own points of that plane
+        m = sc.gt_label == k
+        assert np.max(np.abs(synth.apply_h(H, sc.src[m]) - sc.dst[m])) < 1e-6

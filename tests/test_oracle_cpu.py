@@ -1,0 +1,217 @@
+"""CPU tests of the ORACLE itself: golden fixtures (pinned by the reference's own GCO build
+and by known-answer constants), the live reference build when present, numpy cross-checks of
+the pieces the reference delegates to OpenCV, and size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+THR2 = 2.2 * 2.2
+LAM = 0.5
+
+
+def _g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+# ---- known answers of the harness defaults ----------------------------------
+def test_known_answer_constants(oracle):
+    T = THR2 * 81.0 / 16.0
+    assert T == 24.502500000000005
+    assert oracle.potts(LAM) == 50
+    src = np.array([[10.0, 20.0]])
+    ident = np.eye(3).reshape(1, 9)
+    # d2 = 0 -> 200 ; label 0 -> 4901
+    assert oracle.data_cost(src, src, ident, LAM, THR2).tolist() == [[4901, 200]]
+    # d2 = thr^2 -> 160
+    dst = src + np.array([[2.2, 0.0]])
+    assert oracle.data_cost(src, dst, ident, LAM, THR2)[0, 1] == 160
+    # beyond T -> 9802 ; just below T -> 0
+    assert oracle.data_cost(src, src + np.array([[5.0, 0.0]]), ident, LAM, THR2)[0, 1] == 9802
+    assert oracle.data_cost(src, src + np.array([[4.949, 0.0]]), ident, LAM, THR2)[0, 1] == 0
+    # strict '<' on the inlier threshold (M/MultiH.cpp:441)
+    on_thr = np.array([[3.0, 4.0]])            # d2 = 25 exactly with thr2 = 25
+    assert oracle.score(np.zeros((1, 2)), on_thr, ident, 25.0)[0] == 0
+    assert oracle.score(np.zeros((1, 2)), on_thr, ident, np.nextafter(25.0, 26.0))[0] == 1
+
+
+@pytest.mark.parametrize("tag", ["n64_k2", "n1000_k3", "n5000_k3"])
+def test_oracle_matches_golden_labeling(oracle, tag):
+    g = _g(f"labeling_{tag}.npz")
+    cost = oracle.data_cost(g["src"], g["dst"], g["H"], float(g["lam"]), float(g["thr"]) ** 2)
+    assert np.array_equal(cost, g["cost"])
+    lab, e, cyc, en = oracle.expand(cost, g["hit_rowptr"], g["hit_col"], int(g["potts"]))
+    assert e == int(g["energy_ref"]) and np.array_equal(lab, g["labels_ref"])      # pinned by reference GCO
+    assert cyc == int(g["cycles"]) and np.array_equal(en, g["cycle_energies"])
+    lab_w, e_w, _, _ = oracle.expand(cost, g["hit_rowptr"], g["hit_col"], int(g["potts"]), init_labels=g["init_warm"])
+    assert e_w == int(g["energy_warm"]) and np.array_equal(lab_w, g["labels_warm"])
+    H_re, cnt = oracle.haf_reestimate(g["src"], g["dst"], g["aff"], g["labels_ref"] - 1, g["H"], g["F"], g["e2"])
+    assert np.array_equal(cnt, g["label_counts"])
+    assert np.array_equal(H_re.view(np.uint64), g["H_reestimated"].view(np.uint64))
+    R = oracle.residual_matrix(g["src"][:64], g["dst"][:64], g["H"])
+    assert np.array_equal(R.view(np.uint64), g["residual_first64"].view(np.uint64))
+    assert np.array_equal(oracle.score(g["src"], g["dst"], g["H"], float(g["thr"]) ** 2), g["counts"])
+    # energy bookkeeping: reported energy == energy of the returned labeling
+    assert oracle.labeling_energy(cost, g["hit_rowptr"], g["hit_col"], int(g["potts"]), lab) == e
+
+
+def test_oracle_matches_golden_dlt(oracle):
+    g = _g("dlt_n500_m256.npz")
+    idx = oracle.sample4(int(g["seed"]), int(g["first"]), g["idx"].shape[0], g["src"].shape[0])
+    assert np.array_equal(idx, g["idx"])
+    H, wit, sw = oracle.dlt4(g["src"], g["dst"], idx)
+    assert np.array_equal(H.view(np.uint64), g["H"].view(np.uint64))
+    assert np.array_equal(sw, g["sweeps"])
+    assert np.array_equal(oracle.rr_schedule(), g["rr"])
+
+
+# ---- live comparison with the reference's compiled GCO (present in the build container) ----
+@pytest.mark.parametrize("n,k,seed,sym", [(200, 2, 11, True), (800, 4, 12, False), (2500, 6, 13, True)])
+def test_oracle_expand_vs_reference_gco(oracle, synth, n, k, seed, sym):
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libmh_ref_gco.so not built (needs /root/reference)")
+    sc = synth.make_scene(n, k, seed=seed, symmetric=sym)
+    rng = np.random.default_rng(seed)
+    H = sc.H_true * (1.0 + rng.normal(0, 1e-4, size=sc.H_true.shape))
+    cost = oracle.data_cost(sc.src, sc.dst, H, LAM, THR2)
+    lab, e, _, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, 50)
+    lab_r, e_r = oracle.ref_expand_formula(sc.src, sc.dst, H, LAM, THR2, sc.hit_rowptr, sc.hit_col)
+    assert e == e_r and np.array_equal(lab, lab_r)
+    # random integer costs, duplicate + self hits in the neighbour list (multiplicity, SURVEY A-2)
+    cost2 = rng.integers(0, 300, size=cost.shape).astype(np.int32)
+    rows = np.repeat(np.arange(n), np.diff(sc.hit_rowptr))
+    extra_r = rng.integers(0, n, size=200)
+    extra_c = np.concatenate([rng.integers(0, n, size=150), extra_r[:50]])       # 50 self hits
+    rr = np.concatenate([rows, extra_r, rows[:300]])
+    cc = np.concatenate([sc.hit_col, extra_c, sc.hit_col[:300]])                  # 300 duplicated hits
+    order = np.argsort(rr, kind="stable")
+    rr, cc = rr[order], cc[order].astype(np.int32)
+    rp = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rr, minlength=n), out=rp[1:])
+    for pv in (7, 50):
+        lab, e, _, _ = oracle.expand(cost2, rp, cc, pv)
+        lab_r, e_r = oracle.ref_expand_table(cost2, rp, cc, pv)
+        assert e == e_r and np.array_equal(lab, lab_r)
+
+
+def test_expand_special_case_no_neighbours(oracle):
+    rng = np.random.default_rng(3)
+    cost = rng.integers(0, 100, size=(50, 4)).astype(np.int32)
+    cost[7] = 5                                   # ties: first minimum wins (GCoptimization.cpp:474-482)
+    lab, e, _, _ = oracle.expand(cost, np.zeros(51, np.int32), np.zeros(0, np.int32), 50,
+                                 init_labels=np.full(50, 3, np.int32))
+    assert np.array_equal(lab, np.argmin(cost, axis=1)) and lab[7] == 0
+    assert e == int(cost.min(axis=1).sum())
+    if oracle.ref() is not None:
+        lab_r, e_r = oracle.ref_expand_table(cost, np.zeros(51, np.int32), np.zeros(0, np.int32), 50)
+        assert e == e_r and np.array_equal(lab, lab_r)
+
+
+def test_expand_properties(oracle, synth):
+    """alpha-expansion never increases the energy; result is a fixed point (idempotence)."""
+    sc = synth.make_scene(1500, 4, seed=21)
+    cost = oracle.data_cost(sc.src, sc.dst, sc.H_true, LAM, THR2)
+    e0 = oracle.labeling_energy(cost, sc.hit_rowptr, sc.hit_col, 50, np.zeros(sc.n, np.int32))
+    lab, e, cyc, en = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, 50)
+    assert e <= e0 and all(en[i + 1] <= en[i] for i in range(len(en) - 1)) and en[-1] == e
+    lab2, e2, cyc2, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, 50, init_labels=lab)
+    assert e2 == e and np.array_equal(lab2, lab) and cyc2 == 1
+
+
+# ---- numpy cross-checks of what the reference delegates to OpenCV --------------------------
+def test_jacobi_eig_vs_numpy(oracle):
+    rng = np.random.default_rng(5)
+    for n in (3, 4):
+        for _ in range(20):
+            a = rng.normal(size=(n, n))
+            a = a @ a.T
+            d, v = oracle.jacobi_sym(a)
+            w, _ = np.linalg.eigh(a)
+            assert np.allclose(np.sort(d), w, rtol=1e-12, atol=1e-12)
+            assert np.allclose(a @ v, v * d, atol=1e-10 * np.abs(w).max())
+
+
+def test_dlt_vs_numpy_svd(oracle, synth):
+    sc = synth.make_scene(800, 3, seed=9, with_neighbours=False)
+    idx = oracle.sample4(9, 0, 200, sc.n)
+    H, wit, _ = oracle.dlt4(sc.src, sc.dst, idx)
+
+    def np_dlt(s, d):
+        def norm(p):
+            c = p.mean(0)
+            q = p - c
+            r = np.sqrt(2) / np.mean(np.linalg.norm(q, axis=1))
+            return q * r, np.array([[r, 0, -r * c[0]], [0, r, -r * c[1]], [0, 0, 1]])
+        a, T1 = norm(s)
+        b, T2 = norm(d)
+        A = []
+        for (x, y), (u, v) in zip(a, b):
+            A.append([-x, -y, -1, 0, 0, 0, u * x, u * y, u])
+            A.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
+        h = np.linalg.svd(np.array(A))[2][-1].reshape(3, 3)
+        Hh = np.linalg.inv(T2) @ h @ T1
+        Hh /= np.linalg.norm(Hh)
+        return (Hh if Hh[2, 2] >= 0 else -Hh).reshape(9)
+    good = np.flatnonzero(wit > 1e-6)
+    assert good.size > 100
+    for t in good[:100]:
+        assert np.max(np.abs(np_dlt(sc.src[idx[t]], sc.dst[idx[t]]) - H[t])) < 1e-9
+
+
+def test_haf_reestimate_recovers_planes(oracle, synth):
+    sc = synth.make_scene(4000, 3, seed=31, noise=0.1, with_neighbours=False)
+    H, cnt = oracle.haf_reestimate(sc.src, sc.dst, sc.aff, sc.gt_label, sc.H_true, sc.F, sc.e2)
+    for k in range(3):
+        pts = sc.gt_label == k
+        d2 = oracle.residual_matrix(sc.src[pts], sc.dst[pts], H[k:k + 1])[0]
+        assert np.sqrt(np.median(d2)) < 0.5
+        # lambda == 1 after the rescale (Homography_RefineHAFCallback.h:33-34)
+        assert abs((H[k, 0] - sc.e2[0] * H[k, 6]) / sc.F[3] - 1.0) < 1e-9
+
+
+def test_moments_vs_numpy(oracle, synth):
+    sc = synth.make_scene(2000, 3, seed=2, with_neighbours=False)
+    mo, me = oracle.inlier_moments(sc.src, sc.dst, sc.H_true, THR2)
+    for k in range(3):
+        d2 = oracle.residual_matrix(sc.src, sc.dst, sc.H_true[k:k + 1])[0]
+        inl = d2 < THR2
+        x, y = sc.src[inl, 0], sc.src[inl, 1]
+        ref = np.array([inl.sum(), x.sum(), y.sum(), (x * x).sum(), (x * y).sum(), (y * y).sum()])
+        assert np.allclose(mo[k], ref, rtol=1e-12)
+        S = np.array([[ref[3], ref[4], ref[1]], [ref[4], ref[5], ref[2]], [ref[1], ref[2], ref[0]]])
+        assert np.isclose(me[k], np.linalg.eigvalsh(S)[0], rtol=1e-8)
+    # collinear inliers -> smallest eigenvalue ~ 0 < 0.005 (M/MultiH.cpp:462)
+    t = np.linspace(0, 100, 50)
+    line = np.stack([t, 2 * t + 1], axis=1)
+    mo, me = oracle.inlier_moments(line, line, np.eye(3).reshape(1, 9), THR2)
+    assert mo[0, 0] == 50 and me[0] < 0.005
+
+
+# ---- the reference's only checked-in data ---------------------------------------------------
+def test_barrsmith_fixture_plausibility(oracle):
+    """Format + label histogram of the reference's result file, and that the oracle's forward
+    residual agrees with those labels: per labelled plane a DLT fit to its points must make most
+    of them inliers at the harness threshold (plausibility level)."""
+    g = _g("barrsmith.npz")
+    pts, res = g["points"], g["result"]
+    assert pts.shape == (2903, 8) and res.shape == (1094, 9)
+    labels = res[:, 8].astype(int)
+    assert dict(zip(*np.unique(labels, return_counts=True))) == {-1: 182, 0: 33, 1: 514, 2: 128, 3: 83, 4: 154}
+    assert np.array_equal(res[:, 2:4], res[:, 0:2])          # GetDestinationPoints bug, SURVEY A-9
+    # join result rows to input rows on (x1, y1) to recover the true destination points
+    key = {(round(a, 3), round(b, 3)): i for i, (a, b) in enumerate(pts[:, :2])}
+    rows = np.array([key.get((round(a, 3), round(b, 3)), -1) for a, b in res[:, :2]])
+    assert (rows >= 0).mean() > 0.99
+    ok = rows >= 0
+    src, dst, lab = pts[rows[ok], 0:2], pts[rows[ok], 2:4], labels[ok]
+    for k in range(5):
+        m = lab == k
+        s, d = src[m], dst[m]
+        A = []
+        for (x, y), (u, v) in zip(s, d):
+            A.append([-x, -y, -1, 0, 0, 0, u * x, u * y, u])
+            A.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
+        H = np.linalg.svd(np.array(A))[2][-1].reshape(1, 9)
+        d2 = oracle.residual_matrix(s, d, H)[0]
+        assert np.median(np.sqrt(d2)) < 2.2, f"plane {k}"

@@ -1,0 +1,91 @@
+"""World-size-2 (and 3, ragged) test of the multi-GPU plumbing on CPU with the gloo backend:
+hypothesis sharding, the all-gather of per-model scores and the replicated selection
+(multi-h_amd/sharding.py — the same functions bench.py runs over RCCL).  The scoring kernel is
+replaced by the oracle here (tests only); what is under test is the partition + exchange."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    mh = importlib.import_module("multi-h_amd")
+    sh = importlib.import_module("multi-h_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = mh.synth.make_scene(600, 3, seed=5, with_neighbours=False)      # replicated on every rank
+        if mode == "strong":
+            sizes = sh.shard_counts(total, world)
+            first, m = sh.shard_range(total, world, rank)
+        else:
+            sizes = [total] * world
+            first, m = sh.batch_first(0, world, rank, total), total
+        idx = O.sample4(99, first, m, sc.n)
+        H, _, _ = O.dlt4(sc.src, sc.dst, idx)
+        local = torch.from_numpy(O.score(sc.src, sc.dst, H, 2.2 ** 2))
+        scores = sh.gather_scores(local, world, sizes=sizes)
+        best, val = sh.select_best(scores)
+        q.put((rank, scores.numpy().copy(), int(best), int(val), sizes))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,mode", [(2, 128, "strong"), (3, 100, "strong"), (2, 64, "weak")])
+def test_sharded_scores_equal_single_process(oracle, synth, mh, world, total, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort(key=lambda r: r[0])
+    # single-process reference over the same global RNG counters
+    sc = synth.make_scene(600, 3, seed=5, with_neighbours=False)
+    n_global = total if mode == "strong" else total * world
+    idx = oracle.sample4(99, 0, n_global, sc.n)
+    H, _, _ = oracle.dlt4(sc.src, sc.dst, idx)
+    ref = oracle.score(sc.src, sc.dst, H, 2.2 ** 2)
+    for rank, scores, best, val, sizes in results:
+        assert np.array_equal(scores, ref), f"rank {rank}: gathered scores differ from the unsharded batch"
+        assert best == int(np.argmax(ref)) and val == int(ref.max())
+        assert sum(sizes) == n_global
+
+
+def test_shard_arithmetic(mh):
+    sh = importlib.import_module("multi-h_amd.sharding")
+    assert sh.shard_counts(100000, 8) == [12500] * 8
+    assert sh.shard_counts(10, 4) == [3, 3, 2, 2]
+    assert [sh.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert sh.batch_first(2, 8, 3, 100000) == (2 * 8 + 3) * 100000
+    assert sh.global_model_index(7, [3, 3, 2, 2]) == (2, 1)
+    covered = []
+    for r in range(7):
+        f, c = sh.shard_range(1000, 7, r)
+        covered += list(range(f, f + c))
+    assert covered == list(range(1000))
