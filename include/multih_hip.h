@@ -57,8 +57,9 @@ MH_API void mh_destroy(mh_engine* e);
 /* thr_F, thr_H, locality, lambda, min_inliers: the ctor arguments (defaults 3.0, 2.5, 0.002, 0.5, 0). */
 MH_API int mh_set_params(mh_engine* e, double thr_fund_mat, double thr_hom, double locality,
                   double lambda, int min_inliers);
-/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the engine's own. */
-MH_API int mh_set_stream(mh_engine* e, void* hip_stream);
+/* external != 0: launch on the caller's hipStream_t `hip_stream` (e.g. torch's current stream;
+ * NULL is the HIP default stream).  external == 0: back to the engine's own stream. */
+MH_API int mh_set_stream(mh_engine* e, void* hip_stream, int external);
 MH_API int mh_synchronize(mh_engine* e);
 
 /* ---- inputs ------------------------------------------------------------ */

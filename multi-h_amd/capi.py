@@ -107,8 +107,10 @@ class Engine:
                                            C.c_double(locality), C.c_double(lam), int(min_inliers)))
         self.thr_hom, self.lam = float(thr_hom), float(lam)
 
-    def set_stream(self, stream_ptr: int | None):
-        self._check(self.lib.mh_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+    def set_stream(self, stream_ptr: int | None, external: bool = True):
+        """Launch on the caller's hipStream_t (0 / None = the HIP default stream); external=False
+        returns to the engine's own stream."""
+        self._check(self.lib.mh_set_stream(self._h, C.c_void_p(stream_ptr or 0), int(bool(external))))
 
     def synchronize(self):
         self._check(self.lib.mh_synchronize(self._h))

@@ -368,11 +368,12 @@ int mh_set_params(mh_engine* e, double thr_F, double thr_H, double locality, dou
     return MH_OK;
 }
 
-int mh_set_stream(mh_engine* e, void* hip_stream)
+int mh_set_stream(mh_engine* e, void* hip_stream, int external)
 {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    resolve_timers(e);
+    e->stream = external ? (hipStream_t)hip_stream : e->own_stream;
     return MH_OK;
 }
 

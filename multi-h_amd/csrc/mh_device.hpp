@@ -19,60 +19,82 @@ __device__ __forceinline__ double fwd_d2(double h0, double h1, double h2, double
     return dx * dx + dy * dy;
 }
 
-// Two correctly rounded FP64 quotients n1/s, n2/s that share the denominator.
+// ---------------------------------------------------------------------------
+// Shared-reciprocal division for the residual sweep.
 //
-// hipcc lowers an IEEE f64 division to
-//     v_div_scale x2, v_rcp_f64, 4 fma (two Newton steps), mul, fma, v_div_fmas, v_div_fixup
-// and the three v_div_* helpers plus v_rcp_f64 issue at a fraction of the FMA rate, which made
-// the residual sweep VALU-bound at half the HBM roofline.  When the denominator and both
-// numerators are normal numbers with unbiased exponents in [-255, 256], v_div_scale returns its
-// operands unscaled with VCC = 0, v_div_fmas is a plain fma and v_div_fixup passes the quotient
-// through, so the SAME rounded operations can be issued directly — and the refined reciprocal,
-// which depends on the denominator only, is computed once for both quotients.  The result is
-// bit-identical to `n1 / s` and `n2 / s`; lanes outside the exponent window (zeros, denormals,
-// infinities, NaNs, huge/tiny magnitudes) take the compiler's full IEEE division.
-__device__ __forceinline__ void div2_shared(double n1, double n2, double s, double& u, double& v)
+// hipcc lowers an IEEE f64 division n/s to
+//     v_div_scale(s), v_div_scale(n), v_rcp_f64, 4 fma (two Newton steps on the reciprocal),
+//     v_mul, v_fma (remainder), v_div_fmas, v_div_fixup
+// The sweep needs two quotients with the SAME denominator per (point, model) pair and is
+// FP64-VALU bound, so the reciprocal refinement is done once and the v_div_* helpers are
+// dropped where they are provably no-ops:
+//   * If s is a normal number with unbiased exponent in [-255, 256] and the numerator n is a
+//     normal number with exponent in [-766, 767], v_div_scale returns both operands unscaled
+//     with VCC = 0 (none of its triggers fires: exponent difference < 768, no denormal operand,
+//     1/s and n/s normal, exponent(n) > 53), v_div_fmas is then a plain fma and v_div_fixup
+//     passes the quotient through.  The sequence below issues exactly the remaining rounded
+//     operations, so its result is bit-identical to `n / s`.
+//   * n == +-0 gives +-0 on both paths (the sign of a zero quotient cannot reach d2).
+// What is NOT covered by the window is detected without looking at the numerators:
+//   * s outside the window                         -> `s_ok` false (2 integer ops);
+//   * |n| >= 2^768, n = inf/NaN                    -> |u| >= 2^511 or NaN, hence d2 is NaN, inf or
+//                                                     >= 2^1000: caught by !(d2 < 2^1000);
+//   * 0 < |n| < 2^-766 (incl. denormals)           -> |u| < 2^-510 on BOTH paths; x2 - u rounds to
+//                                                     x2 on both unless |x2| < 2^-450, which is a
+//                                                     per-POINT property checked once per tile
+//                                                     (`pt_ok`, hoisted out of the model loop).
+// Any lane failing a check recomputes the pair with the compiler's full IEEE division.
+// ---------------------------------------------------------------------------
+
+// true iff the biased exponent of v lies in [768, 1279]  (unbiased [-255, 256])
+__device__ __forceinline__ bool exp_in_window(double v)
 {
-    const unsigned int hs = (unsigned int)__double2hiint(s);
-    const unsigned int h1 = (unsigned int)__double2hiint(n1);
-    const unsigned int h2 = (unsigned int)__double2hiint(n2);
-    constexpr unsigned int LO = 768u << 21;          // biased exponent 768, sign shifted out
-    // (h << 1) - LO < 2^30  <=>  biased exponent in [768, 1279]
-    const unsigned int t = ((hs << 1) - LO) | ((h1 << 1) - LO) | ((h2 << 1) - LO);
-    if (__builtin_expect(t < 0x40000000u, 1)) {
-        double r = __builtin_amdgcn_rcp(s);
-        double e = __builtin_fma(-s, r, 1.0);
-        r = __builtin_fma(r, e, r);
-        e = __builtin_fma(-s, r, 1.0);
-        r = __builtin_fma(r, e, r);
-        double q = n1 * r;
-        double d = __builtin_fma(-s, q, n1);
-        u = __builtin_fma(d, r, q);
-        q = n2 * r;
-        d = __builtin_fma(-s, q, n2);
-        v = __builtin_fma(d, r, q);
-    } else {
-        // The empty volatile asm keeps hipcc from if-converting this branch into
-        // "compute both paths and select", which costs more than the plain division.
-        asm volatile("; div2_shared: IEEE path");
-        u = n1 / s;
-        v = n2 / s;
-    }
+    const unsigned int h = (unsigned int)__double2hiint(v);
+    return ((h << 1) - (768u << 21)) < 0x40000000u;
 }
 
-// fwd_d2 with the shared-reciprocal division; bit-identical to fwd_d2.
+// true iff |v| >= 2^-450 and finite-or-anything-large (only smallness matters for pt_ok)
+__device__ __forceinline__ bool not_tiny(double v)
+{
+    const unsigned int h = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+    return h >= ((1023u - 450u) << 20);
+}
+
 __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, double h3,
                                               double h4, double h5, double h6, double h7,
-                                              double h8, double x, double y, double x2, double y2)
+                                              double h8, double x, double y, double x2, double y2,
+                                              bool pt_ok)
 {
     const double s = h6 * x + h7 * y + h8;
     const double nx = h0 * x + h1 * y + h2;
     const double ny = h3 * x + h4 * y + h5;
-    double u, v;
-    div2_shared(nx, ny, s, u, v);
+    double r = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = nx * r;
+    double d = __builtin_fma(-s, q, nx);
+    const double u = __builtin_fma(d, r, q);
+    q = ny * r;
+    d = __builtin_fma(-s, q, ny);
+    const double v = __builtin_fma(d, r, q);
     const double dx = x2 - u;
     const double dy = y2 - v;
-    return dx * dx + dy * dy;
+    double d2 = dx * dx + dy * dy;
+    // bitwise, not short-circuit: three lane masks and-ed on the scalar unit, one branch
+    const int ok = (int)pt_ok & (int)exp_in_window(s) & (int)(d2 < 0x1p1000);
+    if (__builtin_expect(!ok, 0)) {
+        // The empty volatile asm keeps hipcc from if-converting this branch into
+        // "compute both and select", which would put the IEEE sequence back on the hot path.
+        asm volatile("; fwd_d2_fast: IEEE path");
+        const double ui = nx / s;
+        const double vi = ny / s;
+        const double dxi = x2 - ui;
+        const double dyi = y2 - vi;
+        d2 = dxi * dxi + dyi * dyi;
+    }
+    return d2;
 }
 
 // Cyclic Jacobi eigen-solver for a small symmetric matrix (n <= 4), run by a

@@ -61,7 +61,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 
     for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
         double px[PPL], py[PPL], qx[PPL], qy[PPL];
-        bool ok[PPL];
+        bool ok[PPL], pok[PPL];
         const int wbase = base + wave * WAVE_PTS;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -89,6 +89,9 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                 if (ok[2 * c]) ok[2 * c] = mask[n] != 0;
                 if (ok[2 * c + 1]) ok[2 * c + 1] = mask[n + 1] != 0;
             }
+            // per-point precondition of the shared-reciprocal division (see mh_device.hpp)
+            pok[2 * c] = not_tiny(qx[2 * c]) && not_tiny(qy[2 * c]);
+            pok[2 * c + 1] = not_tiny(qx[2 * c + 1]) && not_tiny(qy[2 * c + 1]);
         }
 
         // Not unrolled on purpose: an unrolled model loop lets LICM hoist all MC*9
@@ -111,11 +114,11 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                         continue;
                     }
                     const double d0 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
-                                                         py[2 * c], qx[2 * c], qy[2 * c])
+                                                         py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c])
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
                                                     py[2 * c], qx[2 * c], qy[2 * c]);
                     const double d1 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
-                                                         py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1])
+                                                         py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1])
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
                                                     py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
                     if (WRITE_R) {
