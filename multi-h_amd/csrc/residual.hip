@@ -156,7 +156,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
-                            long long ldr, int* counts, const unsigned char* mask, hipStream_t s)
+                            long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
+                            int force_psplit = 0)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     const int gx = (M + MC - 1) / MC;
@@ -168,6 +169,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         if (psplit > ntiles) psplit = ntiles;
         if (psplit < 1) psplit = 1;
     }
+    if (force_psplit > 0) psplit = force_psplit < ntiles ? force_psplit : ntiles;
     if (psplit > 1) {
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
         if (e != hipSuccess) return e;
@@ -181,6 +183,9 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s)
 {
+    if (variant >= 100) {       // 100 + psplit: default kernel with a forced point split (tuning)
+        return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 100);
+    }
     switch (variant) {
     case 1: return launch_rs<2, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     case 2: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
@@ -195,7 +200,8 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 12: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     case 6: return launch_rs<2, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // compiler IEEE division
     case 13: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    default: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, nt stores
+    case 14: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, nt stores
+    default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // PPL 4, plain 16-B stores
     }
 }
 
