@@ -25,7 +25,7 @@ SYMBOLS = [
     "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_score",
     "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
-    "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
+    "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
 
@@ -222,6 +222,11 @@ class Engine:
         energy, cycles = C.c_int(0), C.c_int(0)
         self._check(self.lib.mh_expand(self._h, ip, _p(labels, C.c_int), C.byref(energy), C.byref(cycles)))
         return labels, energy.value, cycles.value
+
+    def expand_stats(self):
+        st = (C.c_longlong * 6)()
+        self._check(self.lib.mh_get_expand_stats(self._h, st))
+        return dict(zip(("cycles", "moves", "accepted", "pr_launches", "bfs_launches", "host_syncs"), list(st)))
 
     def reestimate(self, labels):
         labels = _i32(labels)

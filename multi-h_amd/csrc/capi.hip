@@ -82,15 +82,19 @@ struct mh_engine {
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
     DevBuf<int> ew_label, ew_cur, ew_cap, ew_excess, ew_sink, ew_height, ew_flags;
+    int cu_count = 256;
     DevBuf<long long> ew_acc;
     int* h_flags = nullptr;
     long long* h_acc = nullptr;
+    int* h_flags_dev = nullptr;
+    long long* h_acc_dev = nullptr;
     DevBuf<int> knn_tmp;
 
     bool profiling = false;
     KernelTimer timers[MH_K_COUNT_];
     int tune_residual_variant = 0;
     int tune_score_variant = 0;
+    int tune_expand[4] = { 8, 3, 16, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
     ExpandStats last_expand{};
 
     Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n }; }
@@ -134,9 +138,19 @@ void resolve_timers(mh_engine* e)
     }
 }
 
-int require_points(mh_engine* e)
+// Every entry point runs on the engine's device, whatever the calling thread's current HIP
+// device is (a host that drives several engines, or torch, may have switched it).
+int enter(mh_engine* e)
 {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    return MH_OK;
+}
+
+int require_points(mh_engine* e)
+{
+    int rc = enter(e);
+    if (rc) return rc;
     if (e->n <= 0) return fail(MH_ERR_NOT_SET, "correspondences are not set");
     return MH_OK;
 }
@@ -236,8 +250,14 @@ int ensure_expand_work(mh_engine* e)
     HIPCHK(e->ew_height.reserve(n));
     HIPCHK(e->ew_flags.reserve(16));
     HIPCHK(e->ew_acc.reserve(8));
-    if (!e->h_flags) HIPCHK(hipHostMalloc((void**)&e->h_flags, sizeof(int) * 16));
-    if (!e->h_acc) HIPCHK(hipHostMalloc((void**)&e->h_acc, sizeof(long long) * 8));
+    if (!e->h_flags) {
+        HIPCHK(hipHostMalloc((void**)&e->h_flags, sizeof(int) * 16, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_flags_dev, e->h_flags, 0));
+    }
+    if (!e->h_acc) {
+        HIPCHK(hipHostMalloc((void**)&e->h_acc, sizeof(long long) * 8, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_acc_dev, e->h_acc, 0));
+    }
     return MH_OK;
 }
 
@@ -262,7 +282,8 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     if (rc) return rc;
     Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size() };
     ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_excess.p, e->ew_sink.p,
-                  e->ew_height.p, e->ew_flags.p, e->ew_acc.p, e->h_flags, e->h_acc };
+                  e->ew_height.p, e->ew_flags.p, e->ew_acc.p, e->h_flags, e->h_acc, e->h_flags_dev,
+                  e->h_acc_dev, e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], e->tune_expand[3] };
     const int potts = (int)std::round(100.0 * e->lambda);     // M/MultiH.h:41, MultiH.cpp:510
     ExpandStats st{};
     {
@@ -330,6 +351,7 @@ int mh_create(mh_engine** out, int device)
     mh_engine* e = new (std::nothrow) mh_engine();
     if (!e) return fail(MH_ERR_INVALID, "out of host memory");
     e->device = device;
+    e->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete e; return fail(MH_ERR_HIP, hipGetErrorString(he)); }
     e->stream = e->own_stream;
@@ -370,7 +392,8 @@ int mh_set_params(mh_engine* e, double thr_F, double thr_H, double locality, dou
 
 int mh_set_stream(mh_engine* e, void* hip_stream, int external)
 {
-    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    int rc0 = enter(e);
+    if (rc0) return rc0;
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     e->stream = external ? (hipStream_t)hip_stream : e->own_stream;
@@ -379,7 +402,8 @@ int mh_set_stream(mh_engine* e, void* hip_stream, int external)
 
 int mh_synchronize(mh_engine* e)
 {
-    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    int rc0 = enter(e);
+    if (rc0) return rc0;
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     return MH_OK;
@@ -388,9 +412,9 @@ int mh_synchronize(mh_engine* e)
 int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst_xy,
                            const double* affines, int n)
 {
-    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    int rc0 = enter(e);
+    if (rc0) return rc0;
     if (!src_xy || !dst_xy || n <= 0) return fail(MH_ERR_INVALID, "src/dst must be non-null and n > 0");
-    HIPCHK(hipSetDevice(e->device));
     // +1 element of slack: the 16-B vector loads of the residual sweep never cross the end,
     // but keep the allocation even-sized for them.
     const size_t cap = (size_t)n + 2;
@@ -491,6 +515,7 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int 
 int mh_set_models(mh_engine* e, const double* H, int m)
 {
     if (!e || !H || m <= 0) return fail(MH_ERR_INVALID, "null argument or m <= 0");
+    HIPCHK(hipSetDevice(e->device));
     HIPCHK(e->H.reserve((size_t)m * 9));
     HIPCHK(e->counts.reserve(m));
     HIPCHK(hipMemcpyAsync(e->H.p, H, sizeof(double) * 9 * m, hipMemcpyHostToDevice, e->stream));
@@ -504,6 +529,7 @@ int mh_set_models(mh_engine* e, const double* H, int m)
 int mh_get_models(mh_engine* e, double* H)
 {
     if (!e || !H) return fail(MH_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
     if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
     HIPCHK(hipMemcpyAsync(H, e->H.p, sizeof(double) * 9 * e->m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -520,6 +546,7 @@ int mh_get_model_count(mh_engine* e, int* m)
 int mh_get_samples(mh_engine* e, int* idx)
 {
     if (!e || !idx) return fail(MH_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
     if (!e->have_samples) return fail(MH_ERR_NOT_SET, "no sampled batch; call mh_propose_dlt4");
     HIPCHK(hipMemcpyAsync(idx, e->samples.p, sizeof(int) * 4 * e->m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -648,6 +675,18 @@ int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy
     return MH_OK;
 }
 
+int mh_get_expand_stats(mh_engine* e, long long stats[6])
+{
+    if (!e || !stats) return fail(MH_ERR_INVALID, "null argument");
+    stats[0] = e->last_expand.cycles;
+    stats[1] = e->last_expand.moves;
+    stats[2] = e->last_expand.accepted;
+    stats[3] = e->last_expand.pr_launches;
+    stats[4] = e->last_expand.bfs_launches;
+    stats[5] = e->last_expand.host_syncs;
+    return MH_OK;
+}
+
 int mh_reestimate(mh_engine* e, const int* labels, double* H_out)
 {
     int rc = require_models(e);
@@ -732,7 +771,8 @@ int mh_profile_enable(mh_engine* e, int on)
 
 int mh_profile_reset(mh_engine* e)
 {
-    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    int rc0 = enter(e);
+    if (rc0) return rc0;
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     for (int k = 0; k < MH_K_COUNT_; ++k) { e->timers[k].launches = 0; e->timers[k].total_ms = 0.0; }
@@ -742,6 +782,7 @@ int mh_profile_reset(mh_engine* e)
 int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms)
 {
     if (!e || kernel < 0 || kernel >= MH_K_COUNT_) return fail(MH_ERR_INVALID, "bad kernel id");
+    HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     if (launches) *launches = e->timers[kernel].launches;
@@ -754,6 +795,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
     if (key == 1) { e->tune_score_variant = value; return MH_OK; }
+    if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
 }
 

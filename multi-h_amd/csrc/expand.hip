@@ -81,25 +81,55 @@ k_argmin_labels(const int* __restrict__ cost, int L, int n, int* __restrict__ la
     if (threadIdx.x == 0) atomicAdd((unsigned long long*)&acc[A_ENERGY], (unsigned long long)s[0]);
 }
 
+// ---------------------------------------------------------------------------
+// Site-parallel kernels.  A site's arcs are contiguous in the CSR, so LPN = 16 consecutive lanes
+// (one DPP row; four sites per wavefront) scan them together: coalesced 64-B reads of col/cap,
+// one or two dependent load latencies per pass instead of one per arc, and width-16 shuffles for
+// the reductions.  With one thread per site these kernels took ~40 us each at N = 50k (eighteen
+// serialised uncached loads per thread at <1 wave per SIMD); the lane-parallel form is what
+// makes a move cost milliseconds.  All lanes of a site keep identical copies of the site's
+// scalars (height, excess, sink capacity); lane 0 alone writes.
+// ---------------------------------------------------------------------------
+constexpr int LPN = 16;
+constexpr int SITES_PER_BLOCK = 256 / LPN;
+
+__device__ __forceinline__ int row_min(int v)
+{
+#pragma unroll
+    for (int m = LPN / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, LPN); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ long long row_min64(long long v)
+{
+#pragma unroll
+    for (int m = LPN / 2; m >= 1; m >>= 1) { const long long o = __shfl_xor(v, m, LPN); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ long long row_sum64(long long v)
+{
+#pragma unroll
+    for (int m = LPN / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPN);
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
              const int* __restrict__ label, const int* __restrict__ cur_cost,
              int* __restrict__ cap, int* __restrict__ excess, int* __restrict__ sink_cap,
              int* __restrict__ flags, long long* __restrict__ acc)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int sub = threadIdx.x % LPN;
     if (i >= g.n) return;
     const int li = label[i];
     const int k0 = g.rowptr[i], k1 = g.rowptr[i + 1];
     if (li == alpha) {
-        excess[i] = 0;
-        sink_cap[i] = 0;
-        for (int k = k0; k < k1; ++k) cap[k] = 0;
+        if (sub == 0) { excess[i] = 0; sink_cap[i] = 0; }
+        for (int k = k0 + sub; k < k1; k += LPN) cap[k] = 0;
         return;
     }
-    long long S = cur_cost[i];
-    const long long K = cost[(size_t)i * L + alpha];
-    for (int k = k0; k < k1; ++k) {
+    long long S = 0;
+    for (int k = k0 + sub; k < k1; k += LPN) {
         const int j = g.col[k];
         const int wk = g.w[k] * potts;
         const int lj = label[j];
@@ -107,6 +137,9 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
         else if (j < i) { if (li != lj) S += wk; cap[k] = wk; }
         else { cap[k] = (li == lj) ? wk : 0; }
     }
+    S = row_sum64(S) + cur_cost[i];
+    if (sub != 0) return;
+    const long long K = cost[(size_t)i * L + alpha];
     const long long tr = S - K;
     if (tr > 0x7fffffffll || -tr > 0x7fffffffll) atomicExch(&flags[F_OVERFLOW], 1);
     const int ex = tr > 0 ? (int)tr : 0;
@@ -130,33 +163,36 @@ k_bfs_init(int n, int alpha, const int* __restrict__ label, const int* __restric
 // Chaotic min-relaxation towards exact residual distances to the sink.  Values are
 // always upper bounds realised by residual paths and only decrease, so any schedule
 // converges to the BFS distances; `changed` is raised when a launch lowered anything.
-template <int ROUNDS>
+// Residual capacities are constant while relaxation kernels run (plain loads); heights move
+// (agent-scope loads/stores, which bypass the per-CU L1).
 __global__ void __launch_bounds__(256)
 k_bfs_relax(Graph g, int alpha, const int* __restrict__ label, const int* __restrict__ cap,
-            int* height, int* __restrict__ flags)
+            int* height, int* __restrict__ flags, int ROUNDS)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int sub = threadIdx.x % LPN;
     if (u >= g.n) return;
     if (label[u] == alpha) return;
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
-    int hu = height[u];
+    int hu = LD(&height[u]);
     bool any = false;
     for (int r = 0; r < ROUNDS; ++r) {
         if (hu <= 1) break;
         int best = hu;
-        for (int k = k0; k < k1; ++k) {
+        for (int k = k0 + sub; k < k1; k += LPN) {
             if (cap[k] > 0) {
                 const int hv = LD(&height[g.col[k]]) + 1;
                 if (hv < best) best = hv;
             }
         }
-        if (best < hu) {
-            hu = best;
-            ST(&height[u], hu);
+        best = row_min(best);
+        if (best < hu) {                             // keep polling otherwise: a neighbour may still
+            hu = best;                               // drop inside this launch
+            if (sub == 0) ST(&height[u], hu);
             any = true;
         }
     }
-    if (any) flags[F_CHANGED] = 1;
+    if (any && sub == 0) flags[F_CHANGED] = 1;
 }
 
 __global__ void __launch_bounds__(256)
@@ -169,51 +205,61 @@ k_count_active(int n, const int* __restrict__ excess, const int* __restrict__ he
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&flags[F_ACTIVE], __popcll(b));
 }
 
-// Lock-free push-relabel (Hong's formulation): the owner thread of u is the only one
-// that lowers excess[u], lowers cap[u->*], touches sink_cap[u] or writes height[u]; other
-// threads only ADD to excess[u] and to cap[u->*] (reverse arcs of their pushes).
-template <int CYCLES>
+// Lock-free push-relabel (Hong's formulation): the owner (lane 0 of the site's row) is the only
+// one that lowers excess[u], lowers cap[u->*], touches sink_cap[u] or writes height[u]; other
+// sites only ADD to excess[u] and to cap[u->*] (reverse arcs of their pushes).
 __global__ void __launch_bounds__(256)
 k_push_relabel(Graph g, int alpha, const int* __restrict__ label, int* cap, int* excess,
-               int* __restrict__ sink_cap, int* height)
+               int* __restrict__ sink_cap, int* height, int CYCLES)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int sub = threadIdx.x % LPN;
     if (u >= g.n) return;
     if (label[u] == alpha) return;
     const int n = g.n;
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
-    int hu = height[u];
+    int hu = LD(&height[u]);
+    int sc = sink_cap[u];
     for (int cyc = 0; cyc < CYCLES; ++cyc) {
         if (hu >= n) break;
-        int e = LD(&excess[u]);
+        // lane 0 reads the excess and broadcasts it: all lanes of the row act on ONE value
+        int e = (sub == 0) ? LD(&excess[u]) : 0;
+        e = __shfl(e, 0, LPN);
         if (e <= 0) continue;
-        const int sc = sink_cap[u];
         if (sc > 0) {                               // t-link: h(t) = 0, h(u) = 1
             const int d = e < sc ? e : sc;
-            sink_cap[u] = sc - d;
-            atomicSub(&excess[u], d);
+            sc -= d;
+            if (sub == 0) { sink_cap[u] = sc; atomicSub(&excess[u], d); }
             e -= d;
             if (e == 0) continue;
         }
-        int hmin = 0x7fffffff, kmin = -1;
-        for (int k = k0; k < k1; ++k) {
+        long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
+        for (int k = k0 + sub; k < k1; k += LPN) {
             if (LD(&cap[k]) > 0) {
-                const int hv = LD(&height[g.col[k]]);
-                if (hv < hmin) { hmin = hv; kmin = k; }
+                const long long cand = ((long long)LD(&height[g.col[k]]) << 32) | (unsigned int)k;
+                if (cand < key) key = cand;
             }
         }
-        if (kmin < 0) { hu = n; ST(&height[u], hu); break; }     // no way out at all
+        key = row_min64(key);
+        if (key == 0x7fffffffffffffffll) {          // no way out at all
+            hu = n;
+            if (sub == 0) ST(&height[u], hu);
+            break;
+        }
+        const int hmin = (int)(key >> 32), kmin = (int)(key & 0xffffffffll);
         if (hu > hmin) {
-            const int c = LD(&cap[kmin]);
-            const int d = e < c ? e : c;
-            atomicSub(&cap[kmin], d);
-            atomicAdd(&cap[g.rev[kmin]], d);
-            atomicSub(&excess[u], d);
-            atomicAdd(&excess[g.col[kmin]], d);
+            if (sub == 0) {
+                const int c = LD(&cap[kmin]);
+                const int d = e < c ? e : c;
+                atomicSub(&cap[kmin], d);
+                atomicAdd(&cap[g.rev[kmin]], d);
+                atomicSub(&excess[u], d);
+                atomicAdd(&excess[g.col[kmin]], d);
+            }
         } else {
             hu = hmin + 1;
             if (hu > n) hu = n;
-            ST(&height[u], hu);
+            if (sub == 0) ST(&height[u], hu);
         }
     }
 }
@@ -224,13 +270,14 @@ k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
         const int* __restrict__ label, const int* __restrict__ cur_cost,
         const int* __restrict__ height, long long* __restrict__ acc)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int sub = threadIdx.x % LPN;
     long long mine = 0;
     if (i < g.n) {
         const int oi = label[i];
         const int ni = (oi != alpha && height[i] >= g.n) ? alpha : oi;
-        if (ni != oi) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
-        for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) {
+        if (sub == 0 && ni != oi) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
+        for (int k = g.rowptr[i] + sub; k < g.rowptr[i + 1]; k += LPN) {
             const int j = g.col[k];
             if (j < i) {
                 const int oj = label[j];
@@ -271,12 +318,13 @@ __global__ void __launch_bounds__(256)
 k_energy(Graph g, int potts, const int* __restrict__ label, const int* __restrict__ cur_cost,
          long long* __restrict__ acc)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int sub = threadIdx.x % LPN;
     long long mine = 0;
     if (i < g.n) {
-        mine = cur_cost[i];
+        if (sub == 0) mine = cur_cost[i];
         const int li = label[i];
-        for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) {
+        for (int k = g.rowptr[i] + sub; k < g.rowptr[i + 1]; k += LPN) {
             const int j = g.col[k];
             if (j < i && label[j] != li) mine += (long long)g.w[k] * potts;
         }
@@ -309,17 +357,31 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 
 #define RET_IF(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
+static long long g_syncs = 0;      // host synchronisations of the running expansion (stats only)
+
+// Control words travel to the host through device-mapped pinned memory: one 1-wave kernel copies
+// them (no hipMemcpy calls, which cost tens of microseconds each for 32 bytes), then the host
+// waits for the stream.
+__global__ void k_publish(const int* __restrict__ flags, const long long* __restrict__ acc,
+                          int* __restrict__ h_flags, long long* __restrict__ h_acc)
+{
+    const int t = threadIdx.x;
+    if (t < F_COUNT) h_flags[t] = flags[t];
+    if (t < A_COUNT) h_acc[t] = acc[t];
+}
+
 static hipError_t fetch(ExpandWork& w, hipStream_t s)
 {
-    RET_IF(hipMemcpyAsync(w.h_flags, w.flags, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
-    RET_IF(hipMemcpyAsync(w.h_acc, w.acc, sizeof(long long) * A_COUNT, hipMemcpyDeviceToHost, s));
+    ++g_syncs;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, w.flags, w.acc, w.h_flags_dev, w.h_acc_dev);
+    RET_IF(hipGetLastError());
     return hipStreamSynchronize(s);
 }
 
 static hipError_t total_energy(const Graph& g, int potts, ExpandWork& w, long long* out,
                                hipStream_t s)
 {
-    const dim3 grid((g.n + 255) / 256), blk(256);
+    const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK), blk(256);
     RET_IF(hipMemsetAsync(&w.acc[A_ENERGY], 0, sizeof(long long), s));
     hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.acc);
     RET_IF(hipGetLastError());
@@ -331,8 +393,10 @@ static hipError_t total_energy(const Graph& g, int potts, ExpandWork& w, long lo
 hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, ExpandWork& w,
                          int max_cycles, ExpandStats* st, hipStream_t s)
 {
-    const dim3 grid((g.n + 255) / 256), blk(256);
+    const dim3 grid1((g.n + 255) / 256), blk(256);                          // one thread per site
+    const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site
     ExpandStats stats = {};
+    g_syncs = 0;
     RET_IF(hipMemsetAsync(w.flags, 0, sizeof(int) * F_COUNT, s));
     RET_IF(hipMemsetAsync(w.acc, 0, sizeof(long long) * A_COUNT, s));
 
@@ -346,6 +410,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 
     long long energy = 0, old_energy = 0;
     RET_IF(total_energy(g, potts, w, &energy, s));     // :1036
+
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         old_energy = energy;
         for (int alpha = 0; alpha < L; ++alpha) {
@@ -366,35 +431,35 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 
             for (int round = 0; round < 100000; ++round) {
                 // exact global relabel
-                hipLaunchKernelGGL(k_bfs_init, grid, blk, 0, s, g.n, alpha, w.label, w.sink_cap,
+                hipLaunchKernelGGL(k_bfs_init, grid1, blk, 0, s, g.n, alpha, w.label, w.sink_cap,
                                    w.height);
+                // Batches of relaxation launches; the flag of the LAST launch of a batch decides
+                // (a launch that lowered nothing is a fixed point).  The active count is taken
+                // in the same batch: it is only trusted when that last launch changed nothing.
                 for (;;) {
-                    RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
-                    for (int b = 0; b < 4; ++b) {
-                        if (b == 3) RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
-                        hipLaunchKernelGGL((k_bfs_relax<4>), grid, blk, 0, s, g, alpha, w.label,
-                                           w.cap, w.height, w.flags);
+                    for (int b = 0; b < w.bfs_batch; ++b) {
+                        if (b == w.bfs_batch - 1) RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
+                        hipLaunchKernelGGL(k_bfs_relax, grid, blk, 0, s, g, alpha, w.label,
+                                           w.cap, w.height, w.flags, w.bfs_rounds);
                         ++stats.bfs_launches;
                     }
+                    RET_IF(hipMemsetAsync(&w.flags[F_ACTIVE], 0, sizeof(int), s));
+                    hipLaunchKernelGGL(k_count_active, grid1, blk, 0, s, g.n, w.excess, w.height, w.flags);
                     RET_IF(hipGetLastError());
                     RET_IF(fetch(w, s));
                     if (!w.h_flags[F_CHANGED]) break;
                 }
-                RET_IF(hipMemsetAsync(&w.flags[F_ACTIVE], 0, sizeof(int), s));
-                hipLaunchKernelGGL(k_count_active, grid, blk, 0, s, g.n, w.excess, w.height, w.flags);
-                RET_IF(hipGetLastError());
-                RET_IF(fetch(w, s));
                 if (w.h_flags[F_ACTIVE] == 0) break;
-                for (int b = 0; b < 8; ++b) {
-                    hipLaunchKernelGGL((k_push_relabel<8>), grid, blk, 0, s, g, alpha, w.label,
-                                       w.cap, w.excess, w.sink_cap, w.height);
+                for (int b = 0; b < w.pr_batch; ++b) {
+                    hipLaunchKernelGGL(k_push_relabel, grid, blk, 0, s, g, alpha, w.label,
+                                       w.cap, w.excess, w.sink_cap, w.height, w.pr_cycles);
                     ++stats.pr_launches;
                 }
                 RET_IF(hipGetLastError());
             }
             hipLaunchKernelGGL(k_delta, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
                                w.cur_cost, w.height, w.acc);
-            hipLaunchKernelGGL(k_apply, grid, blk, 0, s, g.n, cost, L, alpha, w.label, w.cur_cost,
+            hipLaunchKernelGGL(k_apply, grid1, blk, 0, s, g.n, cost, L, alpha, w.label, w.cur_cost,
                                w.height, w.acc, w.flags);
             RET_IF(hipGetLastError());
         }
@@ -403,6 +468,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
         if (energy == old_energy) break;               // :1045
     }
     stats.energy = energy;
+    stats.host_syncs = g_syncs;
     stats.accepted = w.h_flags[F_ACCEPTED];
     if (st) *st = stats;
     return hipSuccess;

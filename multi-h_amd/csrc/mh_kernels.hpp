@@ -71,15 +71,18 @@ struct ExpandWork {         // scratch owned by the engine
     int* height;            // n
     int* flags;             // device control words (see expand.hip)
     long long* acc;         // device 64-bit accumulators
-    int* h_flags;           // pinned host mirror of flags
-    long long* h_acc;       // pinned host mirror of acc
+    int* h_flags;           // pinned, device-mapped host mirror of flags (host address)
+    long long* h_acc;       // pinned, device-mapped host mirror of acc (host address)
+    int* h_flags_dev;       // device addresses of the two mirrors
+    long long* h_acc_dev;
+    int bfs_rounds, bfs_batch, pr_cycles, pr_batch;   // schedule knobs (see expand.hip)
 };
 
 struct ExpandStats {
     int cycles;
     long long energy;
     int moves, accepted;
-    long long pr_launches, bfs_launches;
+    long long pr_launches, bfs_launches, host_syncs;
 };
 
 hipError_t run_expansion(const Graph& g, const int* cost /* n x L */, int L, int potts,

@@ -31,7 +31,7 @@ namespace mh {
 // PPL = points per lane (even), MC = models per workgroup.
 // WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
 // NT: non-temporal stores for the R stream.  FAST: shared-reciprocal division (mh_device.hpp).
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false>
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -100,7 +100,9 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
         for (int mi = 0; mi < MC; ++mi) {
             const int m = m0 + mi;
             if (m < M) {                                   // wave-uniform
-                const double* h = s_h + 9 * mi;
+                // HSGPR: coefficients through the scalar unit (uniform address -> s_load), so the
+                // twelve linear-form operations read one operand from SGPRs instead of VGPRs.
+                const double* h = HSGPR ? (H + 9 * (size_t)m) : (s_h + 9 * mi);
                 const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5],
                              h6 = h[6], h7 = h[7], h8 = h[8];
                 int c_m = 0;
@@ -154,7 +156,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     }
 }
 
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false>
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0)
@@ -175,7 +177,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         if (e != hipSuccess) return e;
     }
     dim3 grid(gx, psplit);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit);
     return hipGetLastError();
 }
@@ -200,6 +202,8 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 12: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     case 6: return launch_rs<2, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // compiler IEEE division
     case 13: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    case 15: return launch_rs<4, 16, true, false, false, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // H in SGPRs
+    case 16: return launch_rs<2, 16, true, false, false, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     case 14: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, nt stores
     default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // PPL 4, plain 16-B stores
     }

@@ -17,7 +17,7 @@ lab = np.full(N, -1, np.int32)
 e.set_models(H)
 for it in range(3):
     t0 = time.time(); lab_g, en, cyc = e.labeling_step(it > 0, lab); tg = time.time() - t0
-    print(f"GPU labeling step {it}: {tg*1e3:.1f} ms, energy {int(en)}, cycles {cyc}")
+    print(f"GPU labeling step {it}: {tg*1e3:.1f} ms, energy {int(en)}, cycles {cyc}, stats {e.expand_stats()}")
     if it == 0: lab0, en0 = lab_g.copy(), en
     lab = lab_g
 if os.environ.get("CPU", "1") == "1":
