@@ -95,10 +95,18 @@ def main():
     sharding = importlib.import_module("multi-h_amd.sharding")
     if not torch.cuda.is_available() or mh.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # MH_BENCH_DEVICE / MH_BENCH_BACKEND exist only to rehearse the multi-rank path on a box with
+    # fewer GPUs than ranks (all ranks on one device, gloo); the driver never sets them.
+    if "MH_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MH_BENCH_DEVICE"])
+    backend = os.environ.get("MH_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     thr, lam = 2.2, 0.5                      # harness defaults, M/main.cpp:55-59
     thr2 = thr * thr

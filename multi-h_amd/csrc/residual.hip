@@ -188,36 +188,27 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     if (variant >= 100) {       // 100 + psplit: default kernel with a forced point split (tuning)
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 100);
     }
+    // Tuning variants kept for the A/B evidence in DESIGN.md §7 (bench.py --variant, tools/kernel_sweep.py).
     switch (variant) {
-    case 1: return launch_rs<2, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 2: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 3: return launch_rs<2, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 4: return launch_rs<2, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 7: return launch_rs<2, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration
-    case 8: return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration
-    case 9: return launch_rs<4, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);        // PPL4 + IEEE division
-    case 10: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);               // PPL4 + nt
-    case 11: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 12: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 6: return launch_rs<2, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // compiler IEEE division
-    case 13: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 15: return launch_rs<4, 16, true, false, false, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // H in SGPRs
-    case 16: return launch_rs<2, 16, true, false, false, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    case 14: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, nt stores
-    default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // PPL 4, plain 16-B stores
+    case 1: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 2
+    case 2: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // nt stores
+    case 3: return launch_rs<4, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // compiler IEEE division
+    case 4: return launch_rs<4, 16, true, false, false, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // coefficients in SGPRs
+    case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // MC 8
+    case 6: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // MC 32
+    case 7: return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);    // store-only calibration
+    default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);               // PPL 4, MC 16, plain 16-B stores
     }
 }
 
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
                         const unsigned char* mask, int* counts, int variant, hipStream_t s)
 {
-    if (mask) return launch_rs<2, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
+    if (mask) return launch_rs<4, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
     switch (variant) {
-    case 1: return launch_rs<2, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
-    case 2: return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
-    case 3: return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
-    default: return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    case 1: return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);           // PPL 2
+    case 3: return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);    // compiler IEEE division
+    default: return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
     }
 }
 

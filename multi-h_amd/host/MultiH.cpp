@@ -142,7 +142,14 @@ bool MultiH::Process()
 
     ClusterMergingAndLabeling();
 
-    if (cluster_homographies.size() > 1) HomographyCompatibilityCheck();     // :78-86 (no-op, §8(f) row 3)
+    if (cluster_homographies.size() > 1) {                                   // :78-86
+        const int before = static_cast<int>(cluster_homographies.size());
+        auto t0 = std::chrono::system_clock::now();
+        HomographyCompatibilityCheck();
+        std::chrono::duration<double> el = std::chrono::system_clock::now() - t0;
+        printf("[Multi-H] Compatibility check time = %f secs (%d clusters removed from %d)\n", el.count(),
+               before - (int)cluster_homographies.size(), before);
+    }
 
     if (cluster_homographies.size() <= 1) {                                  // :88-94
         labeling.clear();
@@ -151,6 +158,27 @@ bool MultiH::Process()
         HandleDegenerateCase();
     }
     return true;
+}
+
+void MultiH::HomographyCompatibilityCheck()
+{
+    const int N = static_cast<int>(src_points.size());
+    const int nh = static_cast<int>(cluster_homographies.size());
+    if (nh == 0 || (int)labeling.size() != N) return;
+    std::vector<double> s(2 * (size_t)N), d(2 * (size_t)N), H(9 * (size_t)nh);
+    for (int i = 0; i < N; ++i) {
+        s[2 * i] = src_points[i].x; s[2 * i + 1] = src_points[i].y;
+        d[2 * i] = dst_points[i].x; d[2 * i + 1] = dst_points[i].y;
+    }
+    for (int i = 0; i < nh; ++i) {
+        const double* p = reinterpret_cast<const double*>(cluster_homographies[i].data);
+        for (int k = 0; k < 9; ++k) H[9 * (size_t)i + k] = p[k];
+    }
+    const int kept = multih::CompatibilityCheck(s.data(), d.data(), N, labeling.data(), H.data(), nh,
+                                                fundamental_matrix, sqr_threshold_homography,
+                                                minimum_inlier_number, proposal_seed ^ 0xc0117a7ull);
+    cluster_homographies.clear();
+    for (int i = 0; i < kept; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
 }
 
 bool MultiH::UploadModels()
@@ -270,9 +298,9 @@ void MultiH::ClusterMergingAndLabeling()
 
 // MergingStep, M/MultiH.cpp:352-471: models -> 6-D features -> mean-shift modes -> one
 // homography per mode -> inlier scoring + collinearity filter -> `changed` iff the count changed.
-// Mode -> homography uses the linear part of GetHomography3PT (:995-1050); the LM refinement
-// (:1052) is not reproduced (DESIGN.md "deviations").  The N x modes scoring and the 3x3 scatter
-// eigen test (:430-463) run on the GPU (mh_inlier_moments).
+// Mode -> homography is GetHomography3PT with its LM refinement (:995-1055, multih::Homography3PT).
+// The N x modes scoring and the 3x3 scatter eigen test (:430-463) run on the GPU
+// (mh_inlier_moments).
 bool MultiH::MergingStep(bool& changed)
 {
     const int nh = static_cast<int>(cluster_homographies.size());
@@ -295,7 +323,7 @@ bool MultiH::MergingStep(bool& changed)
     const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                        // :408
     for (int i = 0; i < k; ++i) {
         double Hc[9];
-        if (multih::Homography3PTLinear(pts1, &ms.modes[6 * (size_t)i], 3, fundamental_matrix, Hc))
+        if (multih::Homography3PT(pts1, &ms.modes[6 * (size_t)i], 3, fundamental_matrix, Hc, true))   // :427
             cand.insert(cand.end(), Hc, Hc + 9);
     }
     const int nc = static_cast<int>(cand.size() / 9);

@@ -60,8 +60,8 @@ public:
     cv::Mat GetHomography(int idx) { return cluster_homographies[idx - 1]; }   // 1-based, :69
     double GetEnergy() { return final_energy; }
     double GetHomographyThreshold() { return threshold_homography; }
-    // Post-filter of the reference (M/MultiH.cpp:100-222): §8(f) row 3, not part of the hot loop.
-    void HomographyCompatibilityCheck() {}
+    // Post-filter of the reference (M/MultiH.cpp:100-222), host-side (multih::CompatibilityCheck).
+    void HomographyCompatibilityCheck();
 
     // ---- extension points: outputs of the reference's OpenCV front half ----
     // fundamental_matrix (row-major) and epipole_2 = (x, y, 1) (M/MultiH.cpp:775-799).

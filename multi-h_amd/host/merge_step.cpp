@@ -220,6 +220,244 @@ bool Homography3PTLinear(const double* pts1, const double* pts2, int n, const do
     return true;
 }
 
+// ---- LM refinement of the 3-point homography ------------------------------------------------
+namespace {
+
+struct Lm3 {
+    const double* p1; const double* p2; int n; const double* Fn; double e0, e1;
+    // Homography_Refine3PTCallback::compute (Homography_Refine3PTCallback.h:105-140)
+    void compute(const double h[3], std::vector<double>& err, std::vector<double>* J) const
+    {
+        err.resize(2 * (size_t)n);
+        if (J) J->resize(6 * (size_t)n);
+        const double h21 = e1 * h[0] - Fn[0], h22 = e1 * h[1] - Fn[1], h23 = e1 * h[2] - Fn[2];
+        const double h11 = e0 * h[0] + Fn[3], h12 = e0 * h[1] + Fn[4], h13 = e0 * h[2] + Fn[5];
+        for (int i = 0; i < n; ++i) {
+            const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+            double s = h[0] * x1 + h[1] * y1 + h[2];
+            s = std::fabs(s) > 2.220446049250313e-16 ? 1. / s : 0;
+            const double xi = (h11 * x1 + h12 * y1 + h13) * s;
+            const double yi = (h21 * x1 + h22 * y1 + h23) * s;
+            err[2 * i] = x2 - xi;
+            err[2 * i + 1] = y2 - yi;
+            if (J) {
+                double* j = &(*J)[6 * (size_t)i];
+                j[0] = e0 * s * x1; j[1] = e0 * s * y1; j[2] = e0 * s;
+                j[3] = e1 * s * x1; j[4] = e1 * s * y1; j[5] = e1 * s;
+            }
+        }
+    }
+};
+
+// x = pinv(A) b through the symmetric eigen-decomposition (cv::solve(..., DECOMP_EIG) /
+// cv::invert(..., DECOMP_EIG)): eigenvalues below 2*eps*sum|w| are dropped.
+void eig_pinv3(const double A[9], double P[9])
+{
+    double a[9], v[9], w[3];
+    std::memcpy(a, A, sizeof(a));
+    jacobi3(a, v, w);
+    const double thr = 2 * 2.220446049250313e-16 * (std::fabs(w[0]) + std::fabs(w[1]) + std::fabs(w[2]));
+    for (int i = 0; i < 9; ++i) P[i] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        if (!(std::fabs(w[k]) > thr)) continue;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) P[3 * i + j] += v[3 * i + k] * v[3 * j + k] / w[k];
+    }
+}
+
+void atA_atb(const std::vector<double>& J, const std::vector<double>& r, int rows, double A[9], double v[3])
+{
+    for (int i = 0; i < 9; ++i) A[i] = 0.0;
+    for (int i = 0; i < 3; ++i) v[i] = 0.0;
+    for (int q = 0; q < rows; ++q)
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) A[3 * a + b] += J[3 * (size_t)q + a] * J[3 * (size_t)q + b];
+            v[a] += J[3 * (size_t)q + a] * r[q];
+        }
+}
+
+double sumsq(const std::vector<double>& r) { double s = 0; for (double x : r) s += x * x; return s; }
+double maxabs(const double* x, size_t n) { double m = 0; for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); return m; }
+
+// LMSolverImpl::run, M/Utilities.hpp:762-869, for 3 parameters.
+int lm_run3(const Lm3& cb, double x[3], int max_iters)
+{
+    const double epsx = 1.1920928955078125e-07, epsf = 1.1920928955078125e-07;   // FLT_EPSILON (:758)
+    const double DEPS = 2.220446049250313e-16;
+    std::vector<double> r, rd, J;
+    cb.compute(x, r, &J);
+    double S = sumsq(r);
+    double A[9], v[3], D[3];
+    atA_atb(J, r, 2 * cb.n, A, v);
+    for (int i = 0; i < 3; ++i) D[i] = A[4 * i];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        double Ap[9], P[9], d[3], xd[3];
+        std::memcpy(Ap, A, sizeof(Ap));
+        for (int i = 0; i < 3; ++i) Ap[4 * i] += lambda * D[i];
+        eig_pinv3(Ap, P);
+        for (int i = 0; i < 3; ++i) d[i] = P[3 * i] * v[0] + P[3 * i + 1] * v[1] + P[3 * i + 2] * v[2];
+        for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
+        cb.compute(xd, rd, nullptr);
+        const double Sd = sumsq(rd);
+        double temp_d[3];
+        for (int i = 0; i < 3; ++i)
+            temp_d[i] = -(A[3 * i] * d[0] + A[3 * i + 1] * d[1] + A[3 * i + 2] * d[2]) + 2 * v[i];
+        const double dS = d[0] * temp_d[0] + d[1] * temp_d[1] + d[2] * temp_d[2];
+        const double R = (S - Sd) / (std::fabs(dS) > DEPS ? dS : 1);
+        if (R > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (R < Rlo) {
+            const double t = d[0] * v[0] + d[1] * v[1] + d[2] * v[2];
+            double nu = (Sd - S) / (std::fabs(t) > DEPS ? t : 1) + 2;
+            nu = std::min(std::max(nu, 2.), 10.);
+            if (lambda == 0) {
+                eig_pinv3(A, P);
+                double maxval = DEPS;
+                for (int i = 0; i < 3; ++i) maxval = std::max(maxval, std::fabs(P[4 * i]));
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            for (int i = 0; i < 3; ++i) x[i] = xd[i];
+            cb.compute(x, r, &J);
+            atA_atb(J, r, 2 * cb.n, A, v);
+        }
+        ++iter;
+        const bool proceed = iter < max_iters && maxabs(d, 3) >= epsx && maxabs(r.data(), r.size()) >= epsf;
+        if (!proceed) break;
+    }
+    return iter;
+}
+
+} // namespace
+
+bool Homography3PT(const double* pts1, const double* pts2, int n, const double F[9], double H[9],
+                   bool do_numerical_refinement, int* iterations)
+{
+    if (iterations) *iterations = 0;
+    if (!do_numerical_refinement) return Homography3PTLinear(pts1, pts2, n, F, H);
+    // Same normalised system as Homography3PTLinear, kept so that the refinement runs where the
+    // reference runs it: on norm_pts1/norm_pts2 with the normalised F and epipole (:1052-1054).
+    std::vector<double> p1, p2;
+    double T1[9], T1i[9], T2[9], T2i[9];
+    normalize_points(pts1, n, p1, T1, T1i);
+    normalize_points(pts2, n, p2, T2, T2i);
+    double T2it[9], tmp[9], Fn[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2it[3 * i + j] = T2i[3 * j + i];
+    mat3_mul(T2it, F, tmp);
+    mat3_mul(tmp, T1i, Fn);
+    double FFt[9], Fnt[9], v[9], dd[3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fnt[3 * i + j] = Fn[3 * j + i];
+    mat3_mul(Fn, Fnt, FFt);
+    jacobi3(FFt, v, dd);
+    int jm = 0;
+    for (int j = 1; j < 3; ++j) if (dd[j] < dd[jm]) jm = j;
+    const double e0 = v[0 * 3 + jm] / v[2 * 3 + jm], e1 = v[1 * 3 + jm] / v[2 * 3 + jm];
+    // linear start: de-normalised result of the linear solver, pulled back to the normalised frame
+    double Hl[9];
+    if (!Homography3PTLinear(pts1, pts2, n, F, Hl)) return false;
+    double Hn[9];
+    mat3_mul(T2, Hl, tmp);
+    mat3_mul(tmp, T1i, Hn);
+    double h3[3] = { Hn[6], Hn[7], Hn[8] };
+    Lm3 cb{ p1.data(), p2.data(), n, Fn, e0, e1 };
+    const int it = lm_run3(cb, h3, 1000);
+    if (iterations) *iterations = it;
+    double Hr[9];
+    Hr[6] = h3[0]; Hr[7] = h3[1]; Hr[8] = h3[2];
+    Hr[3] = e1 * h3[0] - Fn[0]; Hr[4] = e1 * h3[1] - Fn[1]; Hr[5] = e1 * h3[2] - Fn[2];   // 3PTCallback.h:46-51
+    Hr[0] = e0 * h3[0] + Fn[3]; Hr[1] = e0 * h3[1] + Fn[4]; Hr[2] = e0 * h3[2] + Fn[5];
+    mat3_mul(T2i, Hr, tmp);
+    mat3_mul(tmp, T1, H);
+    for (int i = 0; i < 9; ++i) if (!std::isfinite(H[i])) return false;
+    return true;
+}
+
+// ---- HomographyCompatibilityCheck ----------------------------------------------------------
+int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
+                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed)
+{
+    std::vector<std::vector<double>> src(nh), dst(nh);
+    for (int i = 0; i < n; ++i) {
+        const int l = labels[i];
+        if (l > -1 && l < nh) {
+            src[l].push_back(src_xy[2 * i]); src[l].push_back(src_xy[2 * i + 1]);
+            dst[l].push_back(dst_xy[2 * i]); dst[l].push_back(dst_xy[2 * i + 1]);
+        }
+    }
+    std::vector<char> remove(nh, 0);
+    uint64_t counter = 0;
+    const int trials = 501;                                    // MAX(501, MIN(501, ...)), :128
+    for (int c = 0; c < nh; ++c) {
+        std::vector<double>& s = src[c];
+        std::vector<double>& d = dst[c];
+        const int N = (int)(s.size() / 2);
+        if (N >= std::max(min_inliers, 4)) {
+            std::vector<double> distances(trials), dist(N, 0.0), sorted;
+            for (int t = 0; t < trials; ++t) {
+                double ms[6], md[6];
+                for (int j = 0; j < 3; ++j) {
+                    const double u = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
+                    const int cur = (int)(s.size() / 2);
+                    const int idx = (int)((cur - 1) * u);                     // :142
+                    ms[2 * j] = s[2 * idx]; ms[2 * j + 1] = s[2 * idx + 1];
+                    md[2 * j] = d[2 * idx]; md[2 * j + 1] = d[2 * idx + 1];
+                    s.erase(s.begin() + 2 * idx, s.begin() + 2 * idx + 2);   // :149-150
+                    d.erase(d.begin() + 2 * idx, d.begin() + 2 * idx + 2);
+                }
+                double Hc[9];
+                const bool ok = Homography3PTLinear(ms, md, 3, F, Hc);        // do_numerical_refinement = false, :154
+                const int rest = N - 3;
+                for (int j = 0; j < rest; ++j) {
+                    double d2 = std::nan("");
+                    if (ok) {
+                        const double ox = s[2 * j], oy = s[2 * j + 1];
+                        const double ss = Hc[6] * ox + Hc[7] * oy + Hc[8];
+                        const double x1 = (Hc[0] * ox + Hc[1] * oy + Hc[2]) / ss;
+                        const double y1 = (Hc[3] * ox + Hc[4] * oy + Hc[5]) / ss;
+                        const double dx = d[2 * j] - x1, dy = d[2 * j + 1] - y1;
+                        d2 = dx * dx + dy * dy;
+                    }
+                    dist[j] = std::isnan(d2) ? 1e300 : d2;
+                }
+                std::sort(dist.begin(), dist.end());                          // all N entries, 3 of them stale (:175)
+                distances[t] = (rest % 2) ? dist[rest / 2] : 0.5 * (dist[rest / 2] + dist[rest / 2 + 1]);   // :176
+                s.resize(2 * (size_t)N);
+                d.resize(2 * (size_t)N);
+                for (int j = 0; j < 3; ++j) {                                 // :180-189
+                    const int p2 = N - j - 1;
+                    s[2 * p2] = ms[2 * j]; s[2 * p2 + 1] = ms[2 * j + 1];
+                    d[2 * p2] = md[2 * j]; d[2 * p2 + 1] = md[2 * j + 1];
+                }
+            }
+            std::sort(distances.begin(), distances.end());
+            const double median = trials % 2 ? distances[trials / 2]
+                                             : 0.5 * (distances[trials / 2] + distances[trials / 2 + 1]);
+            remove[c] = median > sqr_thr * 81.0 / 16.0;                       // :195
+        } else if (N < min_inliers) {
+            remove[c] = 1;                                                    // :199-200
+        }
+    }
+    int kept = nh;
+    for (int c = nh - 1; c >= 0; --c) {                                       // :208-221
+        if (!remove[c]) continue;
+        for (int j = 0; j < n; ++j) {
+            if (labels[j] == c) labels[j] = -1;
+            else if (labels[j] > c) --labels[j];
+        }
+        for (int q = c; q + 1 < kept; ++q) std::memcpy(H + 9 * (size_t)q, H + 9 * (size_t)(q + 1), 9 * sizeof(double));
+        --kept;
+    }
+    return kept;
+}
+
 } // namespace multih
 
 // ---- C hooks for the CPU-side tests (no GPU needed) ----------------------------
@@ -251,6 +489,20 @@ __attribute__((visibility("default")))
 int mhh_homography_3pt(const double* pts1, const double* pts2, int n, const double* F, double* H)
 {
     return multih::Homography3PTLinear(pts1, pts2, n, F, H) ? 1 : 0;
+}
+
+__attribute__((visibility("default")))
+int mhh_homography_3pt_refined(const double* pts1, const double* pts2, int n, const double* F, double* H,
+                               int* iterations)
+{
+    return multih::Homography3PT(pts1, pts2, n, F, H, true, iterations) ? 1 : 0;
+}
+
+__attribute__((visibility("default")))
+int mhh_compatibility_check(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
+                            const double* F, double sqr_thr, int min_inliers, unsigned long long seed)
+{
+    return multih::CompatibilityCheck(src_xy, dst_xy, n, labels, H, nh, F, sqr_thr, min_inliers, seed);
 }
 
 }

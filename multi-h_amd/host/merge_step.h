@@ -35,4 +35,24 @@ void MeanShiftCluster(const double* data, int num_pts, int num_dim, double band_
 bool Homography3PTLinear(const double* pts1, const double* pts2, int n, const double F[9],
                          double H[9]);
 
+// GetHomography3PT including RefineHomography3PT (Homography_Refine3PTCallback.h:7-143): the third
+// row of H is refined on the NORMALISED data by Levenberg-Marquardt — a restatement of the
+// reference's copy of OpenCV's LMSolverImpl::run (M/Utilities.hpp:750-869: lambda/lc schedule,
+// 1000 iterations, eps = FLT_EPSILON, DECOMP_EIG solves done with a Jacobi eigen-decomposition) with
+// the callback's residual x2 - xi and its (approximate) Jacobian ex*s*[x1 y1 1], ey*s*[x1 y1 1].
+// `iterations` (optional) returns the LM iteration count.
+bool Homography3PT(const double* pts1, const double* pts2, int n, const double F[9], double H[9],
+                   bool do_numerical_refinement, int* iterations = nullptr);
+
+// HomographyCompatibilityCheck (M/MultiH.cpp:100-222): per cluster 501 trials of {3 random cluster
+// points -> GetHomography3PT without refinement -> median squared transfer error of the remaining
+// points}; a cluster whose median-of-medians exceeds thr^2*81/16, or that has fewer than
+// min_inliers points, is removed and the labels are compacted.  The reference's quirks are kept:
+// the even-length "median" averages elements size/2 and size/2+1 (:176,:193), and the distance
+// buffer keeps N entries, the last three of them stale from the previous trial (:136,:175).
+// rand() (:142) is replaced by the engine's splitmix64 counter RNG.
+// labels: in/out (-1..nh-1); H: nh x 9 in, compacted in place; returns the new model count.
+int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
+                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed);
+
 } // namespace multih

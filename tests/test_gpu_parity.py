@@ -398,3 +398,27 @@ def test_barrsmith_real_data_end_to_end(mh, engine_lib):
     dom = ours[ref_lab == 1]                             # the reference's largest plane (514 points)
     vals, cnts = np.unique(dom[dom >= 0], return_counts=True)
     assert cnts.max() > 0.8 * dom.size
+
+
+def test_harness_file_formats(mh, synth, tmp_path):
+    """multih_harness: the reference's cached-correspondence format in (8 numbers per line,
+    M/main.cpp:380-396) and its result format out (9 numbers per line, :429-446)."""
+    import subprocess
+    sc = synth.make_scene(1500, 3, seed=21, with_neighbours=False)
+    inp, out, epi = tmp_path / "corr.txt", tmp_path / "result.txt", tmp_path / "epi.txt"
+    np.savetxt(inp, np.concatenate([sc.src, sc.dst, sc.aff], axis=1), fmt="%.10g")
+    np.savetxt(epi, np.concatenate([sc.F, sc.e2])[None, :], fmt="%.17g")
+    exe = os.path.join(os.path.dirname(mh.LIB_PATH), "multih_harness")
+    r = subprocess.run([exe, str(inp), str(out), "--epipolar", str(epi), "--hypotheses", "5000"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "[Multi-H] Processing has been started." in r.stdout
+    res = np.loadtxt(out)
+    assert res.shape == (1500, 9)
+    assert np.allclose(res[:, :2], sc.src, rtol=1e-5)
+    labels = res[:, 8].astype(int)
+    assert labels.min() >= -1 and labels.max() >= 2
+    # too few correspondences: the reference's error path
+    np.savetxt(inp, np.concatenate([sc.src, sc.dst, sc.aff], axis=1)[:5], fmt="%.10g")
+    r = subprocess.run([exe, str(inp), str(out)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "Features are not set" in r.stderr

@@ -125,3 +125,64 @@ def test_homography_3pt_linear(host, synth):
         # and it maps the scene's own points of that plane
         m = sc.gt_label == k
         assert np.max(np.abs(synth.apply_h(H, sc.src[m]) - sc.dst[m])) < 1e-6
+
+
+def _h3pt(host, fn, pts1, pts2, F):
+    H = np.zeros(9)
+    it = C.c_int(0)
+    pts1, pts2, F = (np.ascontiguousarray(a, dtype=np.float64) for a in (pts1, pts2, F))
+    if fn == "lin":
+        ok = host.mhh_homography_3pt(pts1.ctypes.data_as(_dp), pts2.ctypes.data_as(_dp), len(pts1),
+                                     F.ctypes.data_as(_dp), H.ctypes.data_as(_dp))
+    else:
+        ok = host.mhh_homography_3pt_refined(pts1.ctypes.data_as(_dp), pts2.ctypes.data_as(_dp), len(pts1),
+                                             F.ctypes.data_as(_dp), H.ctypes.data_as(_dp), C.byref(it))
+    assert ok == 1
+    return H, it.value
+
+
+def test_homography_3pt_lm_refinement(host, synth):
+    """RefineHomography3PT (LM on the third row of H, Homography_Refine3PTCallback.h + M/Utilities.hpp
+    LMSolverImpl): on exact data it must leave the linear solution in place; on noisy data it must
+    not increase the reprojection error it minimises."""
+    sc = synth.make_scene(400, 2, seed=8, noise=0.0, outlier_frac=0.0, with_neighbours=False)
+    canon = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    H_lin, _ = _h3pt(host, "lin", canon, synth.apply_h(sc.H_true[0], canon), sc.F)
+    H_ref, it = _h3pt(host, "ref", canon, synth.apply_h(sc.H_true[0], canon), sc.F)
+    assert it >= 1
+    assert np.max(np.abs(H_ref / H_ref[8] - H_lin / H_lin[8])) < 1e-6
+    rng = np.random.default_rng(0)
+    m = sc.gt_label == 1
+    src = sc.src[m][:40]
+    dst = sc.dst[m][:40] + rng.normal(0, 0.7, size=(40, 2))
+    H_lin, _ = _h3pt(host, "lin", src, dst, sc.F)
+    H_ref, it = _h3pt(host, "ref", src, dst, sc.F)
+    sse = lambda H: float(((synth.apply_h(H, src) - dst) ** 2).sum())
+    assert sse(H_ref) <= sse(H_lin) * (1 + 1e-9)
+    assert sse(H_ref) < 40 * 2 * 0.7 ** 2 * 3        # about the noise level
+
+
+def test_compatibility_check(host, synth):
+    """HomographyCompatibilityCheck (M/MultiH.cpp:100-222): a cluster that is one plane survives, a
+    cluster of scrambled matches and a cluster below min_inliers are removed, labels are compacted."""
+    sc = synth.make_scene(3000, 3, seed=3, noise=0.3, outlier_frac=0.0, with_neighbours=False)
+    labels = sc.gt_label.copy().astype(np.int32)          # clusters 0,1,2 = planes
+    # cluster 3: 300 points whose destination is scrambled (no single homography explains them)
+    rng = np.random.default_rng(1)
+    pick = np.flatnonzero((labels == 0) | (labels == 1))
+    mixed = rng.choice(pick, size=300, replace=False)
+    labels[mixed] = 3
+    sc.dst[mixed] = rng.uniform(0, 1000, size=(300, 2))
+    # cluster 4: too small (5 < min_inliers)
+    labels[np.flatnonzero(labels == 2)[:5]] = 4
+    H = np.concatenate([sc.H_true, sc.H_true[:1], sc.H_true[1:2]], axis=0).copy()
+    src, dst, F = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.F))
+    lab = labels.copy()
+    kept = host.mhh_compatibility_check(src.ctypes.data_as(_dp), dst.ctypes.data_as(_dp), sc.n,
+                                        lab.ctypes.data_as(C.POINTER(C.c_int)), H.ctypes.data_as(_dp), 5,
+                                        F.ctypes.data_as(_dp), C.c_double(2.2 ** 2), 20, C.c_ulonglong(7))
+    assert kept == 3
+    assert np.array_equal(H[:3], sc.H_true)
+    assert (lab[labels == 3] == -1).all() and (lab[labels == 4] == -1).all()
+    for k in range(3):
+        assert (lab[labels == k] == k).all()
