@@ -422,3 +422,84 @@ def test_harness_file_formats(mh, synth, tmp_path):
     np.savetxt(inp, np.concatenate([sc.src, sc.dst, sc.aff], axis=1)[:5], fmt="%.10g")
     r = subprocess.run([exe, str(inp), str(out)], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "Features are not set" in r.stderr
+
+
+# ---- error behaviour and edge cases of the C ABI ---------------------------------------------
+def test_capi_error_paths(mh, engine, synth):
+    sc = synth.make_scene(100, 2, seed=1)
+    with pytest.raises(mh.MultiHError) as ei:              # nothing set yet
+        engine.score(THR2)
+    assert ei.value.code == -4
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    with pytest.raises(mh.MultiHError) as ei:              # no models yet
+        engine.data_cost()
+    assert ei.value.code == -4
+    engine.set_models(sc.H_true)
+    with pytest.raises(mh.MultiHError) as ei:              # expansion without a neighbour graph
+        engine.data_cost(); engine.expand()
+    assert ei.value.code == -4
+    with pytest.raises(mh.MultiHError) as ei:              # re-estimation without F
+        engine.reestimate(np.zeros(sc.n, np.int32))
+    assert ei.value.code == -4
+    engine.set_epipolar(sc.F, sc.e2)
+    engine.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
+    with pytest.raises(mh.MultiHError) as ei:              # label outside 0..Nh
+        engine.data_cost(); engine.expand(np.full(sc.n, 7, np.int32))
+    assert ei.value.code == -2
+    with pytest.raises(mh.MultiHError) as ei:              # neighbour index out of range
+        engine.set_neighbors_csr(sc.hit_rowptr, np.full_like(sc.hit_col, sc.n + 5))
+    assert ei.value.code == -2
+    with pytest.raises(mh.MultiHError):
+        engine.inliers_of_model(99, THR2, 0, np.zeros(sc.n, np.int32))
+    with pytest.raises(mh.MultiHError):
+        engine.build_neighbors_knn(64)
+    with pytest.raises(mh.MultiHError) as ei:              # stale cost after the model set changed
+        engine.set_neighbors_csr(sc.hit_rowptr, sc.hit_col); engine.data_cost(); engine.set_models(sc.H_true[:1]); engine.expand()
+    assert ei.value.code == -4
+    with pytest.raises(mh.MultiHError):
+        mh.Engine(device=99)
+
+
+def test_tiny_and_ragged_inputs(engine, synth, oracle):
+    # 4 correspondences are enough to propose; one model; counts of an empty mask
+    sc = synth.make_scene(4, 1, seed=3, outlier_frac=0.0, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst)
+    engine.propose_dlt4(5, 0, 3)
+    assert np.array_equal(engine.get_samples(), oracle.sample4(5, 0, 3, 4))
+    assert sorted(engine.get_samples()[0].tolist()) == [0, 1, 2, 3]
+    R, cnt = engine.residual_matrix(THR2)
+    assert R.shape == (3, 4)
+    # sizes around the tile boundaries of the sweep (256*PPL points, 16 models)
+    for n, m in ((1023, 15), (1024, 16), (1025, 17), (2049, 33)):
+        sc = synth.make_scene(n, 2, seed=n, with_neighbours=False)
+        H = np.random.default_rng(n).normal(size=(m, 9)) * 0.01 + np.eye(3).reshape(9)
+        engine.set_correspondences(sc.src, sc.dst)
+        engine.set_models(H)
+        with np.errstate(all="ignore"):
+            R, cnt = engine.residual_matrix(THR2)
+            Rr = oracle.residual_matrix(sc.src, sc.dst, H)
+        nan = np.isnan(Rr)
+        assert np.array_equal(R[~nan].view(np.uint64), Rr[~nan].view(np.uint64))
+        assert np.array_equal(cnt, oracle.score(sc.src, sc.dst, H, THR2))
+        assert np.array_equal(engine.score(THR2), cnt)
+
+
+def test_two_engines_and_reuse(mh, engine_lib, synth, oracle):
+    """Two engines on the same device do not share state; an engine can be re-targeted to a new
+    correspondence set (buffers grow/shrink correctly)."""
+    a = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+    b = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+    try:
+        s1 = synth.make_scene(700, 2, seed=1, with_neighbours=False)
+        s2 = synth.make_scene(3000, 3, seed=2, with_neighbours=False)
+        a.set_correspondences(s1.src, s1.dst); b.set_correspondences(s2.src, s2.dst)
+        a.set_models(s1.H_true); b.set_models(s2.H_true)
+        ca, cb = a.score(THR2), b.score(THR2)
+        assert np.array_equal(ca, oracle.score(s1.src, s1.dst, s1.H_true, THR2))
+        assert np.array_equal(cb, oracle.score(s2.src, s2.dst, s2.H_true, THR2))
+        a.set_correspondences(s2.src, s2.dst); a.set_models(s2.H_true)          # grow
+        assert np.array_equal(a.score(THR2), cb)
+        b.set_correspondences(s1.src, s1.dst); b.set_models(s1.H_true)          # shrink
+        assert np.array_equal(b.score(THR2), ca)
+    finally:
+        a.close(); b.close()
