@@ -96,6 +96,13 @@ MH_API int mh_get_model_count(mh_engine* e, int* m);
 MH_API int mh_get_samples(mh_engine* e, int* idx /* m x 4, valid after mh_propose_dlt4 */);
 
 /* ---- score -------------------------------------------------------------- */
+/* Residual definition used by mh_score / mh_residual_matrix / mh_get_residual_rows:
+ *   MH_RESIDUAL_FORWARD   d2 = |H p1 - p2|^2 — the reference's formula (M/MultiH.cpp:434-441), default;
+ *   MH_RESIDUAL_SYMMETRIC d2 = |H p1 - p2|^2 + |H^-1 p2 - p1|^2 — north_star's "symmetric transfer",
+ *                         an extension with no reference counterpart (H^-1 = adjugate, same rounding
+ *                         discipline).  Data cost / labeling always use the forward formula. */
+enum { MH_RESIDUAL_FORWARD = 0, MH_RESIDUAL_SYMMETRIC = 1 };
+MH_API int mh_set_residual_mode(mh_engine* e, int mode);
 /* Inlier count of every current model over all points, forward transfer error, strict
  * d2 < thr2 (M/MultiH.cpp:430-443).  point_mask (n bytes, nullable) restricts the count to
  * points with mask != 0.  counts (m ints, nullable) receives a host copy; the counts also

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
     "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_dlt4",
-    "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_score",
+    "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
@@ -171,6 +171,9 @@ class Engine:
         return idx
 
     # -- score --------------------------------------------------------------
+    def set_residual_mode(self, symmetric: bool):
+        self._check(self.lib.mh_set_residual_mode(self._h, 1 if symmetric else 0))
+
     def score(self, thr2: float, mask=None, fetch: bool = True):
         cnt = np.empty(self.model_count, dtype=np.int32) if fetch else None
         mp = None

@@ -94,6 +94,7 @@ struct mh_engine {
     KernelTimer timers[MH_K_COUNT_];
     int tune_residual_variant = 0;
     int tune_score_variant = 0;
+    int residual_mode = MH_RESIDUAL_FORWARD;
     int tune_expand[4] = { 8, 3, 16, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
     ExpandStats last_expand{};
 
@@ -553,6 +554,14 @@ int mh_get_samples(mh_engine* e, int* idx)
     return MH_OK;
 }
 
+int mh_set_residual_mode(mh_engine* e, int mode)
+{
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (mode != MH_RESIDUAL_FORWARD && mode != MH_RESIDUAL_SYMMETRIC) return fail(MH_ERR_INVALID, "unknown residual mode");
+    e->residual_mode = mode;
+    return MH_OK;
+}
+
 int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* counts)
 {
     int rc = require_models(e);
@@ -566,7 +575,8 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
     }
     {
         ScopedTimer t(e, MH_K_SCORE);
-        HIPCHK(launch_score(e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p, e->tune_score_variant, e->stream));
+        HIPCHK(launch_score(e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p,
+                            e->residual_mode == MH_RESIDUAL_SYMMETRIC ? -1 : e->tune_score_variant, e->stream));
     }
     if (counts) {
         HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
@@ -585,7 +595,8 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     {
         ScopedTimer t(e, MH_K_RESIDUAL);
         HIPCHK(launch_residual(e->pts(), e->H.p, e->m, thr2, e->R.p, e->ldr, e->counts.p,
-                               e->tune_residual_variant, e->stream));
+                               e->residual_mode == MH_RESIDUAL_SYMMETRIC ? -1 : e->tune_residual_variant,
+                               e->stream));
     }
     if (R_host)
         HIPCHK(hipMemcpy2DAsync(R_host, sizeof(double) * e->n, e->R.p, sizeof(double) * e->ldr,

@@ -31,7 +31,8 @@ namespace mh {
 // PPL = points per lane (even), MC = models per workgroup.
 // WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
 // NT: non-temporal stores for the R stream.  FAST: shared-reciprocal division (mh_device.hpp).
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false>
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
+          bool SYM = false>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -50,18 +51,30 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     // back with wave-uniform (broadcast) ds_reads.  Keeping them in SGPRs instead
     // makes the compiler hoist 18*MC scalar registers out of the loop and spill.
     __shared__ double s_h[MC * 9];
+    __shared__ double s_a[SYM ? MC * 9 : 1];    // adj(H): the backward transfer of the symmetric mode
     for (int i = threadIdx.x; i < MC * 9; i += 256) {
         const size_t g = (size_t)m0 * 9 + i;
         s_h[i] = (g < (size_t)M * 9) ? H[g] : 0.0;
     }
     __syncthreads();
+    if (SYM) {
+        // H^-1 up to scale = adjugate; each entry is (mul, mul, sub), rounded once per operation
+        if (threadIdx.x < MC) {
+            const double* h = s_h + 9 * threadIdx.x;
+            double* a = s_a + 9 * threadIdx.x;
+            a[0] = h[4] * h[8] - h[5] * h[7]; a[1] = h[2] * h[7] - h[1] * h[8]; a[2] = h[1] * h[5] - h[2] * h[4];
+            a[3] = h[5] * h[6] - h[3] * h[8]; a[4] = h[0] * h[8] - h[2] * h[6]; a[5] = h[2] * h[3] - h[0] * h[5];
+            a[6] = h[3] * h[7] - h[4] * h[6]; a[7] = h[1] * h[6] - h[0] * h[7]; a[8] = h[0] * h[4] - h[1] * h[3];
+        }
+        __syncthreads();
+    }
 
     int cnt = 0;                                // lane mi of each wave counts model m0+mi
     static_assert(MC <= 64, "one counting lane per model");
 
     for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
         double px[PPL], py[PPL], qx[PPL], qy[PPL];
-        bool ok[PPL], pok[PPL];
+        bool ok[PPL], pok[PPL], pokb[SYM ? PPL : 1];
         const int wbase = base + wave * WAVE_PTS;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -92,6 +105,10 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
             // per-point precondition of the shared-reciprocal division (see mh_device.hpp)
             pok[2 * c] = not_tiny(qx[2 * c]) && not_tiny(qy[2 * c]);
             pok[2 * c + 1] = not_tiny(qx[2 * c + 1]) && not_tiny(qy[2 * c + 1]);
+            if (SYM) {
+                pokb[2 * c] = not_tiny(px[2 * c]) && not_tiny(py[2 * c]);
+                pokb[2 * c + 1] = not_tiny(px[2 * c + 1]) && not_tiny(py[2 * c + 1]);
+            }
         }
 
         // Not unrolled on purpose: an unrolled model loop lets LICM hoist all MC*9
@@ -115,6 +132,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                                 make_double2(px[2 * c] + h0, py[2 * c] + h0);
                         continue;
                     }
+                    double d0s, d1s;
                     const double d0 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
                                                          py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c])
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
@@ -123,22 +141,33 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                                                          py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1])
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
                                                     py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
+                    d0s = d0; d1s = d1;
+                    if (SYM) {       // + ||H^-1 p2 - p1||^2 (north_star's symmetric transfer; no reference oracle)
+                        const double* a = s_a + 9 * mi;
+                        const double b0 = fwd_d2_fast(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                                                      qx[2 * c], qy[2 * c], px[2 * c], py[2 * c], pokb[2 * c]);
+                        const double b1 = fwd_d2_fast(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                                                      qx[2 * c + 1], qy[2 * c + 1], px[2 * c + 1], py[2 * c + 1],
+                                                      pokb[2 * c + 1]);
+                        d0s = d0 + b0;
+                        d1s = d1 + b1;
+                    }
                     if (WRITE_R) {
                         const int n = wbase + c * 128 + lane * 2;
                         double* dstp = R + (size_t)m * ldr + n;
                         if (n + 1 < N) {
                             if (NT) {
-                                __builtin_nontemporal_store(d0, dstp);
-                                __builtin_nontemporal_store(d1, dstp + 1);
+                                __builtin_nontemporal_store(d0s, dstp);
+                                __builtin_nontemporal_store(d1s, dstp + 1);
                             } else {
-                                *reinterpret_cast<double2*>(dstp) = make_double2(d0, d1);
+                                *reinterpret_cast<double2*>(dstp) = make_double2(d0s, d1s);
                             }
                         } else if (n < N) {
-                            dstp[0] = d0;
+                            dstp[0] = d0s;
                         }
                     }
-                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c] && d0 < thr2));
-                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c + 1] && d1 < thr2));
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c] && d0s < thr2));
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c + 1] && d1s < thr2));
                 }
                 cnt += (lane == mi) ? c_m : 0;
             }
@@ -156,7 +185,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     }
 }
 
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false>
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
+          bool SYM = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0)
@@ -177,7 +207,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         if (e != hipSuccess) return e;
     }
     dim3 grid(gx, psplit);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit);
     return hipGetLastError();
 }
@@ -185,6 +215,8 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s)
 {
+    if (variant == -1)          // symmetric transfer error (north_star wording; extension)
+        return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     if (variant >= 100) {       // 100 + psplit: default kernel with a forced point split (tuning)
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 100);
     }
@@ -204,6 +236,10 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
                         const unsigned char* mask, int* counts, int variant, hipStream_t s)
 {
+    if (variant == -1) {
+        if (mask) return launch_rs<2, 16, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
+        return launch_rs<2, 16, false, false, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    }
     if (mask) return launch_rs<4, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
     switch (variant) {
     case 1: return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);           // PPL 2

@@ -73,6 +73,29 @@ MHO_API void mho_residual_matrix(const double* x1, const double* y1,
     }
 }
 
+// Symmetric transfer error (north_star wording; NO reference counterpart -> "parity unpinned"):
+//   d2 = |H p1 - p2|^2 + |adj(H) p2 - p1|^2, adj(H) = adjugate (H^-1 up to scale), every entry
+// (mul, mul, sub); both halves use fwd_d2's operation order.  The engine's optional mode.
+static inline void adjugate(const double* h, double* a)
+{
+    a[0] = h[4] * h[8] - h[5] * h[7]; a[1] = h[2] * h[7] - h[1] * h[8]; a[2] = h[1] * h[5] - h[2] * h[4];
+    a[3] = h[5] * h[6] - h[3] * h[8]; a[4] = h[0] * h[8] - h[2] * h[6]; a[5] = h[2] * h[3] - h[0] * h[5];
+    a[6] = h[3] * h[7] - h[4] * h[6]; a[7] = h[1] * h[6] - h[0] * h[7]; a[8] = h[0] * h[4] - h[1] * h[3];
+}
+
+MHO_API void mho_residual_matrix_sym(const double* x1, const double* y1, const double* x2,
+                                     const double* y2, int N, const double* H, int M, double* R)
+{
+    for (int m = 0; m < M; ++m) {
+        const double* h = H + 9 * (size_t)m;
+        double a[9];
+        adjugate(h, a);
+        double* r = R + (size_t)m * N;
+        for (int n = 0; n < N; ++n)
+            r[n] = fwd_d2(h, x1[n], y1[n], x2[n], y2[n]) + fwd_d2(a, x2[n], y2[n], x1[n], y1[n]);
+    }
+}
+
 // Inlier counts, strict '<' (M/MultiH.cpp:441; MultipleHomographies.h:166).
 // mask (optional, may be NULL): only points with mask[n] != 0 are counted.
 MHO_API void mho_score(const double* x1, const double* y1, const double* x2,

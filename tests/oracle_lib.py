@@ -76,6 +76,14 @@ def residual_matrix(src, dst, H):
     return R
 
 
+def residual_matrix_sym(src, dst, H):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    R = np.empty((H.shape[0], x1.size), dtype=np.float64)
+    lib().mho_residual_matrix_sym(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], _d(R))
+    return R
+
+
 def score(src, dst, H, thr2, mask=None):
     x1, y1, x2, y2 = soa(src, dst)
     H = f64(H).reshape(-1, 9)

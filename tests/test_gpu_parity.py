@@ -503,3 +503,23 @@ def test_two_engines_and_reuse(mh, engine_lib, synth, oracle):
         assert np.array_equal(b.score(THR2), ca)
     finally:
         a.close(); b.close()
+
+
+def test_symmetric_transfer_mode(engine, synth, oracle):
+    """north_star's symmetric-transfer residual (extension, no reference counterpart): bit-exact
+    against the oracle's definition; the default (forward, reference formula) is restored after."""
+    sc = synth.make_scene(3001, 3, seed=17, with_neighbours=False)
+    H = _models(sc, np.random.default_rng(2), extra=14)
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    R_fwd, c_fwd = engine.residual_matrix(THR2)
+    engine.set_residual_mode(True)
+    R, cnt = engine.residual_matrix(THR2)
+    R_ref = oracle.residual_matrix_sym(sc.src, sc.dst, H)
+    assert np.array_equal(R.view(np.uint64), R_ref.view(np.uint64))
+    assert np.array_equal(cnt, (R_ref < THR2).sum(axis=1))
+    assert np.array_equal(engine.score(THR2), cnt)
+    assert (R >= R_fwd).all()
+    engine.set_residual_mode(False)
+    R2, c2 = engine.residual_matrix(THR2)
+    assert np.array_equal(R2.view(np.uint64), R_fwd.view(np.uint64)) and np.array_equal(c2, c_fwd)
