@@ -207,17 +207,29 @@ bool MultiH::DownloadModels(int count)
 // M/MultipleHomographies.h:146-175, where points already claimed are skipped via usabilityMask).
 bool MultiH::ProposeInitialModels()
 {
+    std::vector<unsigned char> mask(src_points.size(), 1);
+    const bool ok = ProposeModels(proposal_seed, 0, proposal_hypotheses, proposal_max_models, mask);
+    if (ok && log_to_console)
+        printf("[Multi-H] Proposed %d models from %d DLT hypotheses\n", (int)cluster_homographies.size(),
+               proposal_hypotheses);
+    return ok;
+}
+
+// `mask`: 1 = point still unexplained (in/out).  Appends the selected models to cluster_homographies.
+bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models, std::vector<unsigned char>& mask)
+{
     const int N = static_cast<int>(src_points.size());
-    const int M = proposal_hypotheses;
     const int need = std::max(minimum_inlier_number, 8);
-    if (!Check(mh_propose_dlt4(engine, proposal_seed, 0, M), "mh_propose_dlt4")) return false;
+    if (M <= 0 || max_models <= 0) return true;
+    if (!Check(mh_propose_dlt4(engine, seed, first, M), "mh_propose_dlt4")) return false;
     std::vector<double> H(9 * (size_t)M);
     if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
     std::vector<int> counts(M);
-    std::vector<unsigned char> mask(N, 1);
     std::vector<int> lab(N);
-    for (int round = 0; round < proposal_max_models; ++round) {
-        if (!Check(mh_score(engine, sqr_threshold_homography, round ? mask.data() : nullptr, counts.data()),
+    bool any_masked = false;
+    for (unsigned char m : mask) any_masked = any_masked || (m == 0);
+    for (int round = 0; round < max_models; ++round) {
+        if (!Check(mh_score(engine, sqr_threshold_homography, any_masked ? mask.data() : nullptr, counts.data()),
                    "mh_score"))
             return false;
         const int best = static_cast<int>(std::max_element(counts.begin(), counts.end()) - counts.begin());
@@ -228,9 +240,8 @@ bool MultiH::ProposeInitialModels()
                    "mh_inliers_of_model"))
             return false;
         for (int i = 0; i < N; ++i) if (lab[i] == 0) mask[i] = 0;
+        any_masked = true;
     }
-    if (log_to_console)
-        printf("[Multi-H] Proposed %d models from %d DLT hypotheses\n", (int)cluster_homographies.size(), M);
     return true;
 }
 
@@ -266,6 +277,16 @@ void MultiH::ClusterMergingAndLabeling()
     while (iteration_number++ < MAX_ITERATION_NUMBER) {                                 // :267
         bool changed = false;
         if (!MergingStep(changed)) break;
+        if (iter_hypotheses > 0 && iteration_number > 1) {
+            // PEARL re-proposal on the points the current labeling leaves unexplained
+            std::vector<unsigned char> mask(N);
+            for (int i = 0; i < N; ++i) mask[i] = labeling[i] < 0 ? 1 : 0;
+            const size_t before = cluster_homographies.size();
+            if (!ProposeModels(proposal_seed, (long long)iteration_number * iter_hypotheses + proposal_hypotheses,
+                               iter_hypotheses, iter_max_new, mask))
+                break;
+            if (cluster_homographies.size() != before) changed = true;
+        }
         if (changed) not_changed_number = 0;
         else ++not_changed_number;
 
@@ -386,7 +407,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
                     double lambda, int min_inliers, unsigned long long seed, int hypotheses,
                     int max_models, int fixed_iterations, const double* init_H, int n_init,
                     int* labels_out, double* H_out, int max_H, int* iterations, double* energy,
-                    double* loop_seconds)
+                    double* loop_seconds, int iter_hypotheses, int iter_max_new)
 {
     std::vector<cv::Point2d> s(n), d(n);
     std::vector<cv::Mat> a(n);
@@ -399,6 +420,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     if (F && e2) mh.SetEpipolarGeometry(F, e2);
     mh.SetProposal(seed, hypotheses, max_models);
     mh.SetFixedIterations(fixed_iterations);
+    mh.SetIterativeProposal(iter_hypotheses, iter_max_new);
     if (init_H && n_init > 0) {
         std::vector<cv::Mat> hs;
         for (int i = 0; i < n_init; ++i) hs.push_back(cv::Mat(3, 3, CV_64F, init_H + 9 * (size_t)i));

@@ -78,6 +78,11 @@ public:
     // north_star C5 runs a fixed number of propose-expand iterations instead of the
     // convergence test; 0 restores the reference's stop rule (:295).
     void SetFixedIterations(int n) { fixed_iterations = n; }
+    // PEARL-style re-proposal (north_star "propose-expand iterations"; the reference proposes only
+    // once, before the loop): every iteration samples `hypotheses` fresh DLT hypotheses, scores them
+    // on the points currently labelled outlier and appends at most `max_new` models that gather
+    // >= max(min inliers, 8) of them.  0 hypotheses (default) keeps the reference's behaviour.
+    void SetIterativeProposal(int hypotheses, int max_new) { iter_hypotheses = hypotheses; iter_max_new = max_new; }
     void SetDevice(int d) { device = d; }
     void SetVerbose(bool v) { log_to_console = v; }
     double GetLastLoopSeconds() const { return loop_seconds; }
@@ -110,6 +115,7 @@ protected:
     int proposal_hypotheses = 10000;
     int proposal_max_models = 32;
     int fixed_iterations = 0;
+    int iter_hypotheses = 0, iter_max_new = 4;
     uint64_t merge_rng_counter = 0;
     double loop_seconds = 0.0;
     std::vector<cv::Mat> initial_homographies;
@@ -118,6 +124,8 @@ protected:
     bool UploadModels();
     bool DownloadModels(int count);
     bool ProposeInitialModels();          // north_star propose: DLT batch + greedy selection
+    bool ProposeModels(uint64_t seed, long long first, int hypotheses, int max_models,
+                       std::vector<unsigned char>& mask);
     void ClusterMergingAndLabeling();     // M/MultiH.cpp:224-312
     bool MergingStep(bool& changed);      // :352-471
     bool LabelingStep(double& energy, bool changed);   // :513-602

@@ -343,7 +343,7 @@ def test_host_multih_process_loop(mh, engine_lib, synth):
                              F.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2),
                              C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1234), 10000, 16, 0,
                              None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64,
-                             C.byref(it), C.byref(en), C.byref(secs))
+                             C.byref(it), C.byref(en), C.byref(secs), 0, 4)
     assert k >= 3, "the three planes must be found"
     assert labels.min() >= -1 and labels.max() < k
     assert 1 <= it.value <= 500
@@ -359,7 +359,7 @@ def test_host_multih_process_loop(mh, engine_lib, synth):
     k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), 7,
                              F.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2),
                              C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1), 100, 4, 0, None, 0,
-                             labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64, None, None, None)
+                             labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64, None, None, None, 0, 4)
     assert k == -1
 
 
@@ -387,7 +387,7 @@ def test_barrsmith_real_data_end_to_end(mh, engine_lib):
                              Fc.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2),
                              C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1234), 20000, 16, 0, None, 0,
                              labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64,
-                             C.byref(it), None, None)
+                             C.byref(it), None, None, 0, 4)
     assert 3 <= k <= 8                                   # the reference's result has 5 planes
     assert labels.min() >= -1 and labels.max() < k
     key = {(round(a, 3), round(b, 3)): i for i, (a, b) in enumerate(src)}

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 mh = importlib.import_module("multi-h_amd")
 N, K = int(os.environ.get("N", 50000)), int(os.environ.get("K", 10))
 ITERS, HYP = int(os.environ.get("ITERS", 20)), int(os.environ.get("HYP", 100000))
+ITER_HYP = int(os.environ.get("ITER_HYP", 0))
 host = C.CDLL(os.path.join(ROOT, "multi-h_amd", "libmultih_host.so"))
 sc = mh.synth.make_scene(N, K, seed=1234, with_neighbours=False)
 dp = C.POINTER(C.c_double)
@@ -20,7 +21,7 @@ k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.cty
                          F.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2),
                          C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1234), HYP, 32, ITERS,
                          None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256,
-                         C.byref(it), C.byref(en), C.byref(secs))
+                         C.byref(it), C.byref(en), C.byref(secs), ITER_HYP, 4)
 wall = time.time() - t0
 agree = 0
 for p in range(K):
