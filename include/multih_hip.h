@@ -83,6 +83,23 @@ MH_API int mh_build_neighbors_knn(mh_engine* e, int k);
  * query nnz only. */
 MH_API int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz);
 
+/* ---- epipolar front half --------------------------- */
+/* The reference estimates F inside Process() with cv::findFundamentalMat(RANSAC)
+ * (M/MultiH.cpp:775) and takes the epipole from F F^T (:786-793).  These entry points are the
+ * engine's own GPU version of that step (normalised 8-point hypotheses from counter-RNG 8-tuples,
+ * Sampson-distance scoring, least-squares refit on the inliers); results are inputs for
+ * mh_set_epipolar.  They do not touch the homography model set. */
+MH_API int mh_propose_fund8(mh_engine* e, unsigned long long seed, long long first, int m);
+MH_API int mh_get_fund_hypotheses(mh_engine* e, double* F /* m x 9 */, int* idx /* m x 8, nullable */);
+MH_API int mh_score_sampson(mh_engine* e, double thr2, int* counts /* m */);
+/* `iterations` rounds of {inliers of F (Sampson d < thr2) -> normalised LS 8-point -> rank 2}. */
+MH_API int mh_refit_fundamental(mh_engine* e, const double F_in[9], double thr2, int iterations,
+                         double F_out[9], unsigned char* inlier_mask /* n, nullable */, int* inliers);
+/* propose(hypotheses) -> score -> best -> 2 refits -> epipole e2 = null(F^T), third coordinate 1. */
+MH_API int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypotheses, double thr,
+                            double F[9], double e2[2], unsigned char* inlier_mask /* n, nullable */,
+                            int* inliers);
+
 /* ---- propose: hypothesis batch ----------------------------------------- */
 /* Sample `m` 4-tuples with the counter RNG (seed, first..first+m-1) and solve the normalised
  * 4-point DLT for each on the GPU (north_star; stands where the reference calls

@@ -22,7 +22,8 @@ K_DLT4, K_RESIDUAL, K_SCORE, K_DATACOST, K_EXPAND, K_REESTIMATE = 0, 1, 2, 3, 4,
 SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
-    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_dlt4",
+    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_fund8",
+    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
@@ -145,6 +146,41 @@ class Engine:
         w = np.empty(nnz.value, dtype=np.int32)
         self._check(self.lib.mh_get_sym_graph(self._h, _p(rp, C.c_int), _p(col, C.c_int), _p(w, C.c_int), None))
         return rp, col, w
+
+    # -- epipolar front half ---------------------------------------------------
+    def propose_fund8(self, seed: int, first: int, m: int):
+        self._check(self.lib.mh_propose_fund8(self._h, C.c_ulonglong(seed), C.c_longlong(first), int(m)))
+        self._fm = int(m)
+
+    def get_fund_hypotheses(self):
+        F = np.empty((self._fm, 9), dtype=np.float64)
+        idx = np.empty((self._fm, 8), dtype=np.int32)
+        self._check(self.lib.mh_get_fund_hypotheses(self._h, _p(F, C.c_double), _p(idx, C.c_int)))
+        return F, idx
+
+    def score_sampson(self, thr2: float):
+        cnt = np.empty(self._fm, dtype=np.int32)
+        self._check(self.lib.mh_score_sampson(self._h, C.c_double(thr2), _p(cnt, C.c_int)))
+        return cnt
+
+    def refit_fundamental(self, F, thr2: float, iterations: int = 1):
+        F = _f64(F).reshape(9)
+        out = np.empty(9, dtype=np.float64)
+        mask = np.empty(self.n, dtype=np.uint8)
+        inl = C.c_int(0)
+        self._check(self.lib.mh_refit_fundamental(self._h, _p(F, C.c_double), C.c_double(thr2), int(iterations),
+                                                  _p(out, C.c_double), _p(mask, C.c_ubyte), C.byref(inl)))
+        return out, mask, inl.value
+
+    def estimate_fundamental(self, seed: int, hypotheses: int, thr: float):
+        F = np.empty(9, dtype=np.float64)
+        e2 = np.empty(2, dtype=np.float64)
+        mask = np.empty(self.n, dtype=np.uint8)
+        inl = C.c_int(0)
+        self._check(self.lib.mh_estimate_fundamental(self._h, C.c_ulonglong(seed), int(hypotheses), C.c_double(thr),
+                                                     _p(F, C.c_double), _p(e2, C.c_double), _p(mask, C.c_ubyte),
+                                                     C.byref(inl)))
+        return F, e2, mask, inl.value
 
     # -- propose ------------------------------------------------------------
     def propose_dlt4(self, seed: int, first: int, m: int):

@@ -78,6 +78,12 @@ struct mh_engine {
     DevBuf<unsigned char> mask;
     DevBuf<double> moments, min_eig;
 
+    // epipolar front half
+    int fm = 0;
+    DevBuf<double> fund, fund_one;
+    DevBuf<int> fund_samples, fund_counts, fund_inl;
+    DevBuf<unsigned char> fund_mask;
+
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
@@ -303,6 +309,33 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     return MH_OK;
 }
 
+// cyclic Jacobi, 3x3 symmetric (host copy of the device solver's recurrence)
+void host_jacobi3(double* a, double* v, double* d)
+{
+    const int n = 3;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag = diag + a[i * n + i] * a[i * n + i];
+            for (int j = i + 1; j < n; ++j) off = off + a[i * n + j] * a[i * n + j];
+        }
+        if (off <= 1e-30 * diag) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) { const double x = a[k * n + p], y = a[k * n + q]; a[k * n + p] = c * x - s * y; a[k * n + q] = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = a[p * n + k], y = a[q * n + k]; a[p * n + k] = c * x - s * y; a[q * n + k] = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = v[k * n + p], y = v[k * n + q]; v[k * n + p] = c * x - s * y; v[k * n + q] = s * x + c * y; }
+            }
+    }
+    for (int i = 0; i < n; ++i) d[i] = a[i * n + i];
+}
+
 __global__ void k_shift_labels(int n, const int* in, int delta, int* out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -371,6 +404,8 @@ void mh_destroy(mh_engine* e)
     e->d_rowptr.release(); e->d_col.release(); e->d_w.release(); e->d_rev.release();
     e->H.release(); e->samples.release(); e->counts.release(); e->R.release(); e->mask.release();
     e->moments.release(); e->min_eig.release();
+    e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
+    e->fund_inl.release(); e->fund_mask.release();
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_flags.release(); e->ew_acc.release();
@@ -491,6 +526,103 @@ int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
     if (rowptr) std::copy(e->g_rowptr.begin(), e->g_rowptr.end(), rowptr);
     if (col) std::copy(e->g_col.begin(), e->g_col.end(), col);
     if (w) std::copy(e->g_w.begin(), e->g_w.end(), w);
+    return MH_OK;
+}
+
+int mh_propose_fund8(mh_engine* e, unsigned long long seed, long long first, int m)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (m <= 0) return fail(MH_ERR_INVALID, "m must be positive");
+    if (e->n < 8) return fail(MH_ERR_INVALID, "need at least 8 correspondences");
+    HIPCHK(e->fund.reserve((size_t)m * 9));
+    HIPCHK(e->fund_samples.reserve((size_t)m * 8));
+    HIPCHK(e->fund_counts.reserve(m));
+    HIPCHK(launch_fund8(e->pts(), seed, first, m, e->fund_samples.p, e->fund.p, e->stream));
+    e->fm = m;
+    return MH_OK;
+}
+
+int mh_get_fund_hypotheses(mh_engine* e, double* F, int* idx)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (e->fm <= 0) return fail(MH_ERR_NOT_SET, "no fundamental-matrix hypotheses; call mh_propose_fund8");
+    if (F) HIPCHK(hipMemcpyAsync(F, e->fund.p, sizeof(double) * 9 * e->fm, hipMemcpyDeviceToHost, e->stream));
+    if (idx) HIPCHK(hipMemcpyAsync(idx, e->fund_samples.p, sizeof(int) * 8 * e->fm, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_score_sampson(mh_engine* e, double thr2, int* counts)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (e->fm <= 0) return fail(MH_ERR_NOT_SET, "no fundamental-matrix hypotheses; call mh_propose_fund8");
+    HIPCHK(launch_sampson_score(e->pts(), e->fund.p, e->fm, thr2, e->fund_counts.p, e->stream));
+    if (counts) {
+        HIPCHK(hipMemcpyAsync(counts, e->fund_counts.p, sizeof(int) * e->fm, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return MH_OK;
+}
+
+int mh_refit_fundamental(mh_engine* e, const double F_in[9], double thr2, int iterations, double F_out[9],
+                         unsigned char* inlier_mask, int* inliers)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!F_in || !F_out || iterations < 1) return fail(MH_ERR_INVALID, "null F or iterations < 1");
+    HIPCHK(e->fund_one.reserve(18));
+    HIPCHK(e->fund_inl.reserve(1));
+    HIPCHK(e->fund_mask.reserve((size_t)e->n + 2));
+    HIPCHK(hipMemcpyAsync(e->fund_one.p, F_in, sizeof(double) * 9, hipMemcpyHostToDevice, e->stream));
+    for (int it = 0; it < iterations; ++it) {
+        double* in = e->fund_one.p + 9 * (it & 1);
+        double* out = e->fund_one.p + 9 * ((it + 1) & 1);
+        HIPCHK(launch_fund_refit(e->pts(), in, thr2, out, e->fund_mask.p, e->fund_inl.p, e->stream));
+    }
+    HIPCHK(hipMemcpyAsync(F_out, e->fund_one.p + 9 * (iterations & 1), sizeof(double) * 9, hipMemcpyDeviceToHost, e->stream));
+    if (inlier_mask) HIPCHK(hipMemcpyAsync(inlier_mask, e->fund_mask.p, e->n, hipMemcpyDeviceToHost, e->stream));
+    if (inliers) HIPCHK(hipMemcpyAsync(inliers, e->fund_inl.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypotheses, double thr, double F[9],
+                            double e2[2], unsigned char* inlier_mask, int* inliers)
+{
+    if (!F || !e2) return fail(MH_ERR_INVALID, "null output");
+    int rc = mh_propose_fund8(e, seed, 0, hypotheses);
+    if (rc) return rc;
+    std::vector<int> counts(hypotheses);
+    rc = mh_score_sampson(e, thr * thr, counts.data());
+    if (rc) return rc;
+    const int best = (int)(std::max_element(counts.begin(), counts.end()) - counts.begin());
+    double F0[9];
+    HIPCHK(hipMemcpyAsync(F0, e->fund.p + 9 * (size_t)best, sizeof(double) * 9, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // The mask/count reported are the inliers of the LAST refit's input; a final pass on the
+    // result makes them the inliers of the returned F.
+    rc = mh_refit_fundamental(e, F0, thr * thr, 2, F, nullptr, nullptr);
+    if (rc) return rc;
+    double Fdummy[9];
+    rc = mh_refit_fundamental(e, F, thr * thr, 1, Fdummy, inlier_mask, inliers);
+    if (rc) return rc;
+    // epipole in image 2: eigenvector of F F^T with the smallest eigenvalue, / third coordinate
+    // (M/MultiH.cpp:789-793)
+    double A[9], V[9], D[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 3; ++k) a = a + F[3 * i + k] * F[3 * j + k];
+            A[3 * i + j] = a;
+        }
+    host_jacobi3(A, V, D);
+    int jm = 0;
+    for (int j = 1; j < 3; ++j) if (D[j] < D[jm]) jm = j;
+    e2[0] = V[0 * 3 + jm] / V[2 * 3 + jm];
+    e2[1] = V[1 * 3 + jm] / V[2 * 3 + jm];
     return MH_OK;
 }
 

@@ -45,6 +45,16 @@ hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, 
 hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,
                        int* idx_out, double* H_out, hipStream_t s);
 
+hipError_t launch_fund8(const Points& p, unsigned long long seed, long long first, int M,
+                        int* idx_out /* M x 8 */, double* F_out, hipStream_t s);
+
+// --- fund.hip ---------------------------------------------------------------
+hipError_t launch_sampson_score(const Points& p, const double* F, int M, double thr2, int* counts,
+                                hipStream_t s);
+// Least-squares 8-point refit of F on the Sampson inliers of F_in (one workgroup).
+hipError_t launch_fund_refit(const Points& p, const double* F_in, double thr2, double* F_out,
+                             unsigned char* mask_out, int* count_out, hipStream_t s);
+
 // --- datacost.hip -----------------------------------------------------------
 hipError_t launch_data_cost(const Points& p, const double* H, int Nh, double lambda, double thr2,
                             int* cost, hipStream_t s);

@@ -105,14 +105,13 @@ bool MultiH::Process()
     }
     if (!EnsureEngine()) return false;
 
-    // The reference filters/refines the input with F here (GetFundamentalMatrixAndRefineData,
-    // M/MultiH.cpp:52, :770-848; §8(f) row 4).  That stage is upstream of this class now: the
-    // points are taken as already refined and F / e2 come from SetEpipolarGeometry.  Without
-    // them the case is "degenerate" exactly as when the reference cannot estimate F (:55-58).
+    // GetFundamentalMatrixAndRefineData (M/MultiH.cpp:52, :770-848; §8(f) row 4): with
+    // SetEpipolarGeometry the caller's F / e2 are used and the points are taken as already
+    // filtered; otherwise F is estimated on the GPU below.
     src_points = src_points_original;
     dst_points = dst_points_original;
     affinities = affinities_original;
-    degenerate_case = !have_epipolar;
+    degenerate_case = false;
     cluster_homographies.clear();
     labeling.clear();
 
@@ -127,6 +126,49 @@ bool MultiH::Process()
     }
     if (!Check(mh_set_correspondences(engine, s.data(), d.data(), a.data(), N), "mh_set_correspondences"))
         return false;
+
+    if (!have_epipolar) {
+        // GetFundamentalMatrixAndRefineData, first part (M/MultiH.cpp:775-799) on the GPU: RANSAC over
+        // normalised 8-point hypotheses with Sampson scoring, LS refit, epipole from F F^T.  The
+        // reference then also applies the Hartley-Sturm correction and the affine consistency filter
+        // (:807-838); those are not reproduced — F-inliers are kept as they are.
+        std::vector<unsigned char> mask(N, 0);
+        int inl = 0;
+        const bool ok = Check(mh_estimate_fundamental(engine, proposal_seed ^ 0xf00dull, fundamental_hypotheses,
+                                                      threshold_fundamental_matrix, fundamental_matrix, epipole_2,
+                                                      mask.data(), &inl),
+                              "mh_estimate_fundamental");
+        double nrm = 0.0;
+        for (double f : fundamental_matrix) nrm += f * f;
+        degenerate_case = !ok || !(std::sqrt(nrm) >= 1e-5) || !std::isfinite(epipole_2[0]) ||
+                          !std::isfinite(epipole_2[1]);                             // :779
+        if (degenerate_case) {
+            printf("[Multi-H] Degenerate case, the fundamental matrix cannot be estimated.\n");
+        } else {
+            std::vector<cv::Point2d> s2, d2;
+            std::vector<cv::Mat> a2;
+            for (int i = 0; i < N; ++i)
+                if (mask[i]) { s2.push_back(src_points[i]); d2.push_back(dst_points[i]); a2.push_back(affinities[i]); }
+            printf("[Multi-H] %d points kept from the initial %d after filtering.\n", (int)s2.size(), N);   // :840
+            if (s2.size() < 8) {
+                degenerate_case = true;
+                printf("[Multi-H] Degenerate case, not enough points remained.\n");                         // :845
+            } else {
+                src_points.swap(s2); dst_points.swap(d2); affinities.swap(a2);
+                const int K = static_cast<int>(src_points.size());
+                std::vector<double> ss(2 * (size_t)K), dd(2 * (size_t)K), aa(4 * (size_t)K);
+                for (int i = 0; i < K; ++i) {
+                    ss[2 * i] = src_points[i].x; ss[2 * i + 1] = src_points[i].y;
+                    dd[2 * i] = dst_points[i].x; dd[2 * i + 1] = dst_points[i].y;
+                    const cv::Mat& A = affinities[i];
+                    aa[4 * i] = A.at<double>(0, 0); aa[4 * i + 1] = A.at<double>(0, 1);
+                    aa[4 * i + 2] = A.at<double>(1, 0); aa[4 * i + 3] = A.at<double>(1, 1);
+                }
+                if (!Check(mh_set_correspondences(engine, ss.data(), dd.data(), aa.data(), K), "mh_set_correspondences"))
+                    return false;
+            }
+        }
+    }
 
     if (degenerate_case) {
         HandleDegenerateCase();

@@ -11,9 +11,10 @@
 // front half of the reference's Process() — findFundamentalMat, Hartley-Sturm
 // correction, affine consistency, per-point HAF, stable-set initialisation
 // (M/MultiH.cpp:770-848, 696-717, 604-694) — is §8(f) row 4 ("next") and is NOT
-// re-implemented: its outputs are supplied through the Set* extension methods
-// below (F + epipole, optional neighbour hits, optional initial models).  When no
-// initial models are given the engine proposes them itself from random minimal
+// fully re-implemented: F and the epipole are either supplied (SetEpipolarGeometry) or estimated on
+// the GPU (8-point RANSAC, Sampson scoring, LS refit); the Hartley-Sturm point correction and the
+// affine consistency filter are not reproduced.  Optional neighbour hits and initial models can be
+// supplied; when no initial models are given the engine proposes them itself from random minimal
 // samples with the batched 4-point DLT (north_star).
 #pragma once
 
@@ -83,6 +84,8 @@ public:
     // on the points currently labelled outlier and appends at most `max_new` models that gather
     // >= max(min inliers, 8) of them.  0 hypotheses (default) keeps the reference's behaviour.
     void SetIterativeProposal(int hypotheses, int max_new) { iter_hypotheses = hypotheses; iter_max_new = max_new; }
+    // Number of 8-point hypotheses of the GPU F estimation used when SetEpipolarGeometry was not called.
+    void SetFundamentalHypotheses(int n) { fundamental_hypotheses = n; }
     void SetDevice(int d) { device = d; }
     void SetVerbose(bool v) { log_to_console = v; }
     double GetLastLoopSeconds() const { return loop_seconds; }
@@ -116,6 +119,7 @@ protected:
     int proposal_max_models = 32;
     int fixed_iterations = 0;
     int iter_hypotheses = 0, iter_max_new = 4;
+    int fundamental_hypotheses = 4000;
     uint64_t merge_rng_counter = 0;
     double loop_seconds = 0.0;
     std::vector<cv::Mat> initial_homographies;

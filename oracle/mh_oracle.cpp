@@ -689,6 +689,21 @@ static inline uint64_t splitmix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
+// K distinct indices (K = 4: homography samples, K = 8: fundamental-matrix samples), same draw
+// scheme; at most `maxdraw` draws.
+static void sample_tuple(uint64_t seed, uint64_t m, uint32_t N, int K, int maxdraw, int* out)
+{
+    int got = 0;
+    for (uint32_t c = 0; c < (uint32_t)maxdraw && got < K; ++c) {
+        const uint64_t r = splitmix64(seed + (m << 8) + c);
+        const int idx = (int)(((r >> 32) * (uint64_t)N) >> 32);
+        bool dup = false;
+        for (int k = 0; k < got; ++k) dup = dup || (out[k] == idx);
+        if (!dup) out[got++] = idx;
+    }
+    for (; got < K; ++got) out[got] = out[0];
+}
+
 // Four distinct point indices for hypothesis m: draw c = 0,1,2,... gives
 // r = splitmix64(seed + (m << 8) + c), idx = ((r >> 32) * N) >> 32; a draw equal
 // to an earlier member of the tuple is rejected (sampling without replacement
@@ -858,6 +873,211 @@ MHO_API void mho_dlt4(const double* x1, const double* y1, const double* x2, cons
         dlt4(sx, sy, dx, dy, H + 9 * (size_t)m, witness ? witness + m : nullptr,
              sweeps ? sweeps + m : nullptr);
     }
+}
+
+// ---------------------------------------------------------------------------
+// 9b. Epipolar front half — own definition, "parity unpinned": the
+//     reference calls cv::findFundamentalMat(RANSAC) (M/MultiH.cpp:775), OpenCV 3.1.0 calib3d.
+// ---------------------------------------------------------------------------
+static inline double sampson_d(const double* f, double x, double y, double u, double v)
+{
+    const double a = f[0] * x + f[1] * y + f[2];
+    const double b = f[3] * x + f[4] * y + f[5];
+    const double c = f[6] * x + f[7] * y + f[8];
+    const double a2 = f[0] * u + f[3] * v + f[6];
+    const double b2 = f[1] * u + f[4] * v + f[7];
+    const double e = u * a + v * b + c;
+    return (e * e) / (a * a + b * b + a2 * a2 + b2 * b2);
+}
+
+// null vector g (normalised frame) -> rank-2 F in pixel coordinates, unit Frobenius, F[8] >= 0
+static void fund_finish(const double g[9], double cx1, double cy1, double s1, double cx2, double cy2,
+                        double s2, double F[9])
+{
+    double Mm[9], V[9], D[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 3; ++k) a = a + g[3 * k + i] * g[3 * k + j];
+            Mm[3 * i + j] = a;
+        }
+    jacobi_sym(3, Mm, V, D);
+    int jm = 0;
+    for (int j = 1; j < 3; ++j) if (D[j] < D[jm]) jm = j;
+    const double v0 = V[0 * 3 + jm], v1 = V[1 * 3 + jm], v2 = V[2 * 3 + jm];
+    double Fn[9];
+    for (int r = 0; r < 3; ++r) {
+        const double w = (g[3 * r] * v0 + g[3 * r + 1] * v1) + g[3 * r + 2] * v2;
+        Fn[3 * r] = g[3 * r] - w * v0;
+        Fn[3 * r + 1] = g[3 * r + 1] - w * v1;
+        Fn[3 * r + 2] = g[3 * r + 2] - w * v2;
+    }
+    double B[9];
+    for (int r = 0; r < 3; ++r) {
+        const double a = Fn[3 * r] * s1, b = Fn[3 * r + 1] * s1;
+        B[3 * r] = a; B[3 * r + 1] = b;
+        B[3 * r + 2] = (Fn[3 * r + 2] - a * cx1) - b * cy1;
+    }
+    double Fh[9];
+    const double tx = s2 * cx2, ty = s2 * cy2;
+    for (int j = 0; j < 3; ++j) {
+        Fh[j] = s2 * B[j];
+        Fh[3 + j] = s2 * B[3 + j];
+        Fh[6 + j] = (B[6 + j] - tx * B[j]) - ty * B[3 + j];
+    }
+    double fro = 0.0;
+    for (int j = 0; j < 9; ++j) fro = fro + Fh[j] * Fh[j];
+    double sc = 1.0 / sqrt(fro);
+    if (Fh[8] < 0.0) sc = -sc;
+    for (int j = 0; j < 9; ++j) F[j] = Fh[j] * sc;
+}
+
+// One-sided Jacobi null vector of W = [A (8x9); I9] in the round-robin order (shared with dlt4).
+static int null9(double W[17][9], double g[9])
+{
+    int sched[9][4][2];
+    rr_schedule(sched);
+    int sweeps = 0;
+    for (; sweeps < 30; ++sweeps) {
+        int rotated = 0;
+        for (int r = 0; r < 9; ++r)
+            for (int k = 0; k < 4; ++k) {
+                const int p = sched[r][k][0], q = sched[r][k][1];
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = 0; i < 8; ++i) {
+                    alpha = alpha + W[i][p] * W[i][p];
+                    beta = beta + W[i][q] * W[i][q];
+                    gamma = gamma + W[i][p] * W[i][q];
+                }
+                const bool rot = (gamma != 0.0) && (gamma * gamma > 1e-30 * (alpha * beta)) &&
+                                 (alpha >= 1e-28) && (beta >= 1e-28);
+                if (!rot) continue;
+                ++rotated;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t);
+                const double s = c * t;
+                for (int i = 0; i < 17; ++i) {
+                    const double wp = W[i][p], wq = W[i][q];
+                    W[i][p] = c * wp - s * wq;
+                    W[i][q] = s * wp + c * wq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int jm = 0;
+    double best = 0.0;
+    for (int j = 0; j < 9; ++j) {
+        double a = 0.0;
+        for (int i = 0; i < 8; ++i) a = a + W[i][j] * W[i][j];
+        if (j == 0 || a < best) { best = a; jm = j; }
+    }
+    for (int j = 0; j < 9; ++j) g[j] = W[8 + j][jm];
+    return sweeps;
+}
+
+MHO_API void mho_sample8(unsigned long long seed, long long m0, int M, int N, int* idx /* M*8 */)
+{
+    for (int m = 0; m < M; ++m) sample_tuple(seed, (uint64_t)(m0 + m), (uint32_t)N, 8, 256, idx + 8 * (size_t)m);
+}
+
+MHO_API void mho_fund8(const double* x1, const double* y1, const double* x2, const double* y2,
+                       const int* idx /* M*8 */, int M, double* F /* M*9 */)
+{
+    for (int m = 0; m < M; ++m) {
+        double sx[8], sy[8], dx[8], dy[8];
+        for (int k = 0; k < 8; ++k) {
+            const int i = idx[8 * (size_t)m + k];
+            sx[k] = x1[i]; sy[k] = y1[i]; dx[k] = x2[i]; dy[k] = y2[i];
+        }
+        double cx1 = sx[0], cy1 = sy[0], cx2 = dx[0], cy2 = dy[0];
+        for (int k = 1; k < 8; ++k) { cx1 = cx1 + sx[k]; cy1 = cy1 + sy[k]; cx2 = cx2 + dx[k]; cy2 = cy2 + dy[k]; }
+        cx1 = cx1 * 0.125; cy1 = cy1 * 0.125; cx2 = cx2 * 0.125; cy2 = cy2 * 0.125;
+        double d1 = 0.0, d2 = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            const double ax = sx[k] - cx1, ay = sy[k] - cy1, bx = dx[k] - cx2, by = dy[k] - cy2;
+            d1 = d1 + sqrt(ax * ax + ay * ay);
+            d2 = d2 + sqrt(bx * bx + by * by);
+        }
+        const double s1 = sqrt(2.0) / (d1 * 0.125), s2 = sqrt(2.0) / (d2 * 0.125);
+        double W[17][9];
+        for (int k = 0; k < 8; ++k) {
+            const double x = (sx[k] - cx1) * s1, y = (sy[k] - cy1) * s1;
+            const double u = (dx[k] - cx2) * s2, v = (dy[k] - cy2) * s2;
+            W[k][0] = u * x; W[k][1] = u * y; W[k][2] = u; W[k][3] = v * x; W[k][4] = v * y; W[k][5] = v;
+            W[k][6] = x; W[k][7] = y; W[k][8] = 1.0;
+        }
+        for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) W[8 + i][j] = (i == j) ? 1.0 : 0.0;
+        double g[9];
+        null9(W, g);
+        fund_finish(g, cx1, cy1, s1, cx2, cy2, s2, F + 9 * (size_t)m);
+    }
+}
+
+MHO_API void mho_sampson_score(const double* x1, const double* y1, const double* x2, const double* y2,
+                               int N, const double* F, int M, double thr2, int* counts)
+{
+    for (int m = 0; m < M; ++m) {
+        int c = 0;
+        for (int n = 0; n < N; ++n) if (sampson_d(F + 9 * (size_t)m, x1[n], y1[n], x2[n], y2[n]) < thr2) ++c;
+        counts[m] = c;
+    }
+}
+
+MHO_API void mho_sampson(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                         const double* F, double* d)
+{
+    for (int n = 0; n < N; ++n) d[n] = sampson_d(F, x1[n], y1[n], x2[n], y2[n]);
+}
+
+// LS 8-point refit on the Sampson inliers of F_in; sums in the strided-tree order.  Returns count.
+MHO_API int mho_fund_refit(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                           const double* F_in, double thr2, double* F_out, unsigned char* mask)
+{
+    TreeAcc c4(4);
+    int count = 0;
+    for (int n = 0; n < N; ++n) {
+        const bool in = sampson_d(F_in, x1[n], y1[n], x2[n], y2[n]) < thr2;
+        if (mask) mask[n] = in ? 1 : 0;
+        if (in) { const double c[4] = { x1[n], y1[n], x2[n], y2[n] }; c4.add(n, c); ++count; }
+    }
+    if (count < 8) { for (int i = 0; i < 9; ++i) F_out[i] = F_in[i]; return count; }
+    double s4[4];
+    c4.finish(s4);
+    const double inv = 1.0 / (double)count;
+    const double cx1 = s4[0] * inv, cy1 = s4[1] * inv, cx2 = s4[2] * inv, cy2 = s4[3] * inv;
+    TreeAcc c2(2);
+    for (int n = 0; n < N; ++n)
+        if (sampson_d(F_in, x1[n], y1[n], x2[n], y2[n]) < thr2) {
+            const double ax = x1[n] - cx1, ay = y1[n] - cy1, bx = x2[n] - cx2, by = y2[n] - cy2;
+            const double c[2] = { sqrt(ax * ax + ay * ay), sqrt(bx * bx + by * by) };
+            c2.add(n, c);
+        }
+    double s2v[2];
+    c2.finish(s2v);
+    const double s1 = sqrt(2.0) / (s2v[0] / (double)count), s2 = sqrt(2.0) / (s2v[1] / (double)count);
+    TreeAcc c45(45);
+    for (int n = 0; n < N; ++n)
+        if (sampson_d(F_in, x1[n], y1[n], x2[n], y2[n]) < thr2) {
+            const double x = (x1[n] - cx1) * s1, y = (y1[n] - cy1) * s1, u = (x2[n] - cx2) * s2, v = (y2[n] - cy2) * s2;
+            const double r[9] = { u * x, u * y, u, v * x, v * y, v, x, y, 1.0 };
+            double c[45];
+            int k = 0;
+            for (int i = 0; i < 9; ++i) for (int j = i; j < 9; ++j) c[k++] = r[i] * r[j];
+            c45.add(n, c);
+        }
+    double u45[45];
+    c45.finish(u45);
+    double A[81], V[81], D[9];
+    int k = 0;
+    for (int i = 0; i < 9; ++i) for (int j = i; j < 9; ++j) { A[i * 9 + j] = u45[k]; A[j * 9 + i] = u45[k]; ++k; }
+    jacobi_sym(9, A, V, D);
+    int jm = 0;
+    for (int j = 1; j < 9; ++j) if (D[j] < D[jm]) jm = j;
+    double g[9];
+    for (int j = 0; j < 9; ++j) g[j] = V[j * 9 + jm];
+    fund_finish(g, cx1, cy1, s1, cx2, cy2, s2, F_out);
+    return count;
 }
 
 // ---------------------------------------------------------------------------

@@ -198,6 +198,46 @@ def dlt4(src, dst, idx):
     return H, wit, sw
 
 
+def sample8(seed, m0, M, N):
+    idx = np.empty((M, 8), dtype=np.int32)
+    lib().mho_sample8(C.c_ulonglong(seed), C.c_longlong(m0), M, N, _i(idx))
+    return idx
+
+
+def fund8(src, dst, idx):
+    x1, y1, x2, y2 = soa(src, dst)
+    idx = i32(idx).reshape(-1, 8)
+    F = np.empty((idx.shape[0], 9))
+    lib().mho_fund8(_d(x1), _d(y1), _d(x2), _d(y2), _i(idx), idx.shape[0], _d(F))
+    return F
+
+
+def sampson_score(src, dst, F, thr2):
+    x1, y1, x2, y2 = soa(src, dst)
+    F = f64(F).reshape(-1, 9)
+    cnt = np.empty(F.shape[0], dtype=np.int32)
+    lib().mho_sampson_score(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(F), F.shape[0], C.c_double(thr2), _i(cnt))
+    return cnt
+
+
+def sampson(src, dst, F):
+    x1, y1, x2, y2 = soa(src, dst)
+    F = f64(F).reshape(9)
+    d = np.empty(x1.size)
+    lib().mho_sampson(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(F), _d(d))
+    return d
+
+
+def fund_refit(src, dst, F, thr2):
+    x1, y1, x2, y2 = soa(src, dst)
+    F = f64(F).reshape(9)
+    out = np.empty(9)
+    mask = np.empty(x1.size, dtype=np.uint8)
+    cnt = lib().mho_fund_refit(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(F), C.c_double(thr2), _d(out),
+                               mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out, mask, int(cnt)
+
+
 def labeling_step(src, dst, aff, H, lam, thr2, rowptr, col, warm, F, e2, labeling):
     x1, y1, x2, y2 = soa(src, dst)
     aff, F, e2 = f64(aff), f64(F), f64(e2)

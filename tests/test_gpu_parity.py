@@ -523,3 +523,76 @@ def test_symmetric_transfer_mode(engine, synth, oracle):
     engine.set_residual_mode(False)
     R2, c2 = engine.residual_matrix(THR2)
     assert np.array_equal(R2.view(np.uint64), R_fwd.view(np.uint64)) and np.array_equal(c2, c_fwd)
+
+
+# ---- epipolar front half on the GPU -------------------------------------
+@pytest.mark.parametrize("n,m,seed", [(8, 16, 1), (500, 256, 2), (5000, 2000, 1234)])
+def test_fundamental_hypotheses_and_sampson_scores(engine, synth, oracle, n, m, seed):
+    sc = synth.make_scene(n, 3, seed=seed, outlier_frac=0.2 if n > 8 else 0.0, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst)
+    engine.propose_fund8(seed, 3, m)
+    F, idx = engine.get_fund_hypotheses()
+    assert np.array_equal(idx, oracle.sample8(seed, 3, m, n))
+    F_ref = oracle.fund8(sc.src, sc.dst, idx)
+    ok = np.isfinite(F_ref).all(axis=1)
+    assert ok.mean() > 0.9
+    assert np.max(np.abs(F[ok] - F_ref[ok])) <= 1e-6                    # unit Frobenius norm: abs == rel
+    assert np.array_equal(F[ok].view(np.uint64), F_ref[ok].view(np.uint64))
+    cnt = engine.score_sampson(4.0)
+    assert np.array_equal(cnt[ok], oracle.sampson_score(sc.src, sc.dst, F_ref[ok], 4.0))
+
+
+def test_fundamental_refit_and_estimate(engine, synth, oracle):
+    sc = synth.make_scene(5000, 3, seed=1234, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.propose_fund8(99, 0, 1000)
+    F, idx = engine.get_fund_hypotheses()
+    cnt = engine.score_sampson(4.0)
+    best = int(np.argmax(cnt))
+    F1, mask, c1 = engine.refit_fundamental(F[best], 4.0, 1)
+    F1r, maskr, c1r = oracle.fund_refit(sc.src, sc.dst, F[best], 4.0)
+    assert c1 == c1r and np.array_equal(mask, maskr)
+    assert np.max(np.abs(F1 - F1r)) <= 1e-6
+    assert np.array_equal(F1.view(np.uint64), F1r.view(np.uint64))
+    # whole estimate: F close to the scene's true epipolar geometry, epipole where the scene put it
+    Fe, e2, m2, inl = engine.estimate_fundamental(99, 1000, 2.0)
+    assert inl == int(m2.sum()) and inl > 0.9 * (sc.gt_label >= 0).sum()
+    d = oracle.sampson(sc.src[sc.gt_label >= 0], sc.dst[sc.gt_label >= 0], Fe)
+    assert np.median(np.sqrt(d)) < 0.5
+    assert np.max(np.abs(e2 - sc.e2) / np.abs(sc.e2)) < 0.05
+    # and the engine runs its hot loop on the estimated geometry
+    engine.set_epipolar(Fe, e2)
+
+
+def test_process_from_raw_correspondences(mh, engine_lib, synth):
+    """Process() without SetEpipolarGeometry: F and the epipole are estimated on the GPU first (the
+    reference's GetFundamentalMatrixAndRefineData role), gross outliers are filtered, then the loop runs.
+    Also the reference's only real data set end to end with no external geometry at all."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    dp = C.POINTER(C.c_double)
+
+    def run(src, dst, aff, thrF):
+        n = len(src)
+        labels = np.full(n, -7, dtype=np.int32)
+        Hout = np.zeros((64, 9))
+        it = C.c_int(0)
+        src, dst, aff = (np.ascontiguousarray(a) for a in (src, dst, aff))
+        k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n,
+                                 None, None, C.c_double(thrF), C.c_double(2.2), C.c_double(0.005), C.c_double(0.5),
+                                 20, C.c_ulonglong(1234), 20000, 16, 0, None, 0,
+                                 labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64,
+                                 C.byref(it), None, None, 0, 4)
+        return k, labels
+
+    sc = synth.make_scene(5000, 3, seed=1234)
+    k, labels = run(sc.src, sc.dst, sc.aff, 2.6)
+    assert k >= 3
+    kept = int((labels != -7).sum())                       # labels cover the F-filtered points only
+    assert 0.7 * sc.n < kept < sc.n
+    g = np.load(os.path.join(GOLDEN, "barrsmith.npz"))
+    pts = g["points"]
+    k, labels = run(pts[:, 0:2], pts[:, 2:4], pts[:, 4:8], 2.6)
+    assert 3 <= k <= 8
+    kept = labels[labels != -7]
+    assert 1000 < kept.size < 2903 and (kept >= 0).sum() > 500

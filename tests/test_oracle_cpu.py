@@ -215,3 +215,39 @@ def test_barrsmith_fixture_plausibility(oracle):
         H = np.linalg.svd(np.array(A))[2][-1].reshape(1, 9)
         d2 = oracle.residual_matrix(s, d, H)[0]
         assert np.median(np.sqrt(d2)) < 2.2, f"plane {k}"
+
+
+# ---- epipolar front half (own definition; cross-checked with numpy) ---------------------------
+def test_fund8_and_refit_vs_numpy(oracle, synth):
+    import epipolar_np as E
+    sc = synth.make_scene(1500, 3, seed=41, noise=0.3, outlier_frac=0.2, with_neighbours=False)
+    idx = oracle.sample8(7, 0, 300, sc.n)
+    assert all(len(set(t)) == 8 for t in idx.tolist())
+    F = oracle.fund8(sc.src, sc.dst, idx)
+    assert np.allclose(np.linalg.norm(F, axis=1), 1.0, atol=1e-12)
+    for t in range(0, 300, 17):
+        Fm = F[t].reshape(3, 3)
+        assert abs(np.linalg.det(Fm)) < 1e-12                       # rank 2
+        # the 8 sample points satisfy the epipolar constraint of their own hypothesis
+        p1 = np.concatenate([sc.src[idx[t]], np.ones((8, 1))], 1)
+        p2 = np.concatenate([sc.dst[idx[t]], np.ones((8, 1))], 1)
+        # rank-2 projection perturbs the exact fit slightly: compare with numpy's 8-point on the same sample
+        Fn = E.eight_point(sc.src[idx[t]], sc.dst[idx[t]])
+        Fn = Fn / np.linalg.norm(Fn)
+        if Fn[2, 2] < 0:
+            Fn = -Fn
+        assert np.max(np.abs(Fn.reshape(9) - F[t])) < 1e-6 or np.abs(np.einsum("ni,ij,nj->n", p2, Fm, p1)).max() < 1e-6
+    cnt = oracle.sampson_score(sc.src, sc.dst, F, 4.0)
+    best = int(np.argmax(cnt))
+    assert cnt[best] > 0.5 * (sc.gt_label >= 0).sum()
+    F1, mask, c1 = oracle.fund_refit(sc.src, sc.dst, F[best], 4.0)
+    assert c1 == cnt[best] == int(mask.sum())
+    F2, mask2, c2 = oracle.fund_refit(sc.src, sc.dst, F1, 4.0)
+    assert c2 >= c1
+    # the refit agrees with the true epipolar geometry on the true inliers
+    d_true = oracle.sampson(sc.src[sc.gt_label >= 0], sc.dst[sc.gt_label >= 0], F2)
+    assert np.median(np.sqrt(d_true)) < 0.5
+    # numpy LS 8-point on the same inliers gives the same matrix up to sign/scale
+    Fn = E.eight_point(sc.src[mask.astype(bool)], sc.dst[mask.astype(bool)]).reshape(9)
+    Fn = Fn / np.linalg.norm(Fn) * np.sign(Fn[8])
+    assert np.max(np.abs(Fn - F1)) < 1e-6
