@@ -100,6 +100,19 @@ MH_API int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hy
                             double F[9], double e2[2], unsigned char* inlier_mask /* n, nullable */,
                             int* inliers);
 
+/* ---- reference-style initialisation ------------- */
+/* ComputeLocalHomographies (M/MultiH.cpp:696-717, GetHomographyHAF :850-911): one homography per
+ * correspondence from its affinity, F and e2; H_out (n x 9, nullable).  feat_out (n x 10, nullable)
+ * receives the feature vectors EstablishStablePointSets clusters (:617-644) with `locality` as the
+ * coordinate weight. */
+MH_API int mh_local_homographies(mh_engine* e, double locality, double* H_out, double* feat_out);
+/* MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157) on n rows of d <= 16 doubles:
+ * every climb (:62-123) runs on the GPU, the sequential seed/merge/vote logic (:52-56,:100-146) on
+ * the host; seeds come from the counter RNG instead of rand().  modes: up to max_modes x d;
+ * assign: per row the index of its mode (-1 if none); n_modes: number of modes found. */
+MH_API int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_width,
+                  unsigned long long seed, double* modes, int max_modes, int* assign, int* n_modes);
+
 /* ---- propose: hypothesis batch ----------------------------------------- */
 /* Sample `m` 4-tuples with the counter RNG (seed, first..first+m-1) and solve the normalised
  * 4-point DLT for each on the GPU (north_star; stands where the reference calls

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
     "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_fund8",
-    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_propose_dlt4",
+    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
@@ -181,6 +181,23 @@ class Engine:
                                                      _p(F, C.c_double), _p(e2, C.c_double), _p(mask, C.c_ubyte),
                                                      C.byref(inl)))
         return F, e2, mask, inl.value
+
+    # -- reference-style initialisation ------------------------------------------
+    def local_homographies(self, locality: float):
+        H = np.empty((self.n, 9), dtype=np.float64)
+        feat = np.empty((self.n, 10), dtype=np.float64)
+        self._check(self.lib.mh_local_homographies(self._h, C.c_double(locality), _p(H, C.c_double), _p(feat, C.c_double)))
+        return H, feat
+
+    def mean_shift(self, data, band_width: float, seed: int):
+        data = _f64(data)
+        n, d = data.shape
+        modes = np.empty((n, d), dtype=np.float64)
+        assign = np.empty(n, dtype=np.int32)
+        k = C.c_int(0)
+        self._check(self.lib.mh_mean_shift(self._h, _p(data, C.c_double), n, d, C.c_double(band_width),
+                                           C.c_ulonglong(seed), _p(modes, C.c_double), n, _p(assign, C.c_int), C.byref(k)))
+        return modes[:k.value].copy(), assign, k.value
 
     # -- propose ------------------------------------------------------------
     def propose_dlt4(self, seed: int, first: int, m: int):

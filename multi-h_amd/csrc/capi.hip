@@ -84,6 +84,10 @@ struct mh_engine {
     DevBuf<int> fund_samples, fund_counts, fund_inl;
     DevBuf<unsigned char> fund_mask;
 
+    // reference-style initialisation
+    DevBuf<double> loc_H, loc_feat, ms_data, ms_mean;
+    DevBuf<int> ms_votes, ms_out, ms_list;
+
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
@@ -406,6 +410,8 @@ void mh_destroy(mh_engine* e)
     e->moments.release(); e->min_eig.release();
     e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
     e->fund_inl.release(); e->fund_mask.release();
+    e->loc_H.release(); e->loc_feat.release(); e->ms_data.release(); e->ms_mean.release();
+    e->ms_votes.release(); e->ms_out.release(); e->ms_list.release();
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_flags.release(); e->ew_acc.release();
@@ -623,6 +629,112 @@ int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypothese
     for (int j = 1; j < 3; ++j) if (D[j] < D[jm]) jm = j;
     e2[0] = V[0 * 3 + jm] / V[2 * 3 + jm];
     e2[1] = V[1 * 3 + jm] / V[2 * 3 + jm];
+    return MH_OK;
+}
+
+int mh_local_homographies(mh_engine* e, double locality, double* H_out, double* feat_out)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!e->have_aff) return fail(MH_ERR_NOT_SET, "affinities are not set");
+    if (!e->have_epi) return fail(MH_ERR_NOT_SET, "fundamental matrix / epipole are not set");
+    HIPCHK(e->loc_H.reserve((size_t)e->n * 9));
+    HIPCHK(e->loc_feat.reserve((size_t)e->n * 10));
+    Affines a{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
+    HIPCHK(launch_haf_point(e->pts(), a, e->epi, locality, e->loc_H.p, e->loc_feat.p, e->stream));
+    if (H_out) HIPCHK(hipMemcpyAsync(H_out, e->loc_H.p, sizeof(double) * 9 * e->n, hipMemcpyDeviceToHost, e->stream));
+    if (feat_out) HIPCHK(hipMemcpyAsync(feat_out, e->loc_feat.p, sizeof(double) * 10 * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_width,
+                  unsigned long long seed, double* modes, int max_modes, int* assign, int* n_modes)
+{
+    int rc = enter(e);
+    if (rc) return rc;
+    if (!data || n <= 0 || d <= 0 || d > 16 || !assign || !n_modes)
+        return fail(MH_ERR_INVALID, "bad argument (1 <= d <= 16)");
+    HIPCHK(e->ms_data.reserve((size_t)n * d));
+    HIPCHK(e->ms_mean.reserve(16));
+    HIPCHK(e->ms_votes.reserve(n));
+    HIPCHK(e->ms_out.reserve(4));
+    HIPCHK(e->ms_list.reserve(2 * (size_t)n));
+    HIPCHK(hipMemcpyAsync(e->ms_data.p, data, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->ms_votes.p, 0, sizeof(int) * n, e->stream));
+    MeanShiftWork w{ e->ms_data.p, n, d, e->ms_mean.p, e->ms_votes.p, e->ms_out.p, e->ms_list.p };
+    const double band_sq = band_width * band_width;                 // MeanShiftClustering.h:31
+    const double stop_thresh = 1e-3 * band_width;                   // :48
+    std::vector<int> init(n), visited(n, 0), list;
+    for (int i = 0; i < n; ++i) init[i] = i;
+    std::vector<std::vector<double>> cent;
+    std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: sorted (row, votes)
+    unsigned long long counter = 0;
+    auto l2 = [](const double* a, const double* b, int dd) {
+        double s = 0.0;
+        for (int j = 0; j < dd; ++j) { const double x = a[j] - b[j]; s = s + x * x; }
+        return std::sqrt(s);
+    };
+    while (!init.empty()) {
+        unsigned long long z = seed + counter++;                    // splitmix64
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const double rnd = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+        const int st = init[(int)std::round(rnd * (double)(init.size() - 1))];          // :55-56
+        HIPCHK(hipMemcpyAsync(e->ms_mean.p, data + (size_t)st * d, sizeof(double) * d, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemsetAsync(e->ms_out.p, 0, sizeof(int) * 4, e->stream));
+        HIPCHK(launch_ms_climb(w, band_sq, stop_thresh, 100000, e->stream));
+        HIPCHK(launch_ms_collect(w, e->stream));
+        int out[4];
+        double mean[16];
+        HIPCHK(hipMemcpyAsync(out, e->ms_out.p, sizeof(out), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(mean, e->ms_mean.p, sizeof(double) * d, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const int len = out[2];
+        list.resize(2 * (size_t)len);
+        if (len) {
+            HIPCHK(hipMemcpyAsync(list.data(), e->ms_list.p, sizeof(int) * 2 * len, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+        std::vector<std::pair<int, int>> mine(len);
+        for (int k = 0; k < len; ++k) { mine[k] = { list[2 * k], list[2 * k + 1] }; visited[list[2 * k]] = 1; }
+        std::sort(mine.begin(), mine.end());
+        if (!out[1]) {
+            visited[st] = 1;                                        // climb that captured no row
+        } else {
+            int merge_with = -1;
+            for (size_t cn = 0; cn < cent.size(); ++cn)
+                if (l2(mean, cent[cn].data(), d) < band_width / 2) { merge_with = (int)cn; break; }    // :101-109
+            if (merge_with > -1) {
+                for (int j = 0; j < d; ++j) cent[merge_with][j] = 0.5 * (cent[merge_with][j] + mean[j]);
+                std::vector<std::pair<int, int>> merged;
+                const auto& a = votes[merge_with];
+                size_t i = 0, k = 0;
+                while (i < a.size() || k < mine.size()) {
+                    if (k >= mine.size() || (i < a.size() && a[i].first < mine[k].first)) merged.push_back(a[i++]);
+                    else if (i >= a.size() || mine[k].first < a[i].first) merged.push_back(mine[k++]);
+                    else { merged.push_back({ a[i].first, a[i].second + mine[k].second }); ++i; ++k; }
+                }
+                votes[merge_with].swap(merged);
+            } else {
+                cent.emplace_back(mean, mean + d);
+                votes.push_back(mine);
+            }
+        }
+        init.clear();                                               // :125-130
+        for (int i = 0; i < n; ++i) if (!visited[i]) init.push_back(i);
+    }
+    std::vector<int> best_votes(n, 0);
+    for (int i = 0; i < n; ++i) assign[i] = -1;
+    for (size_t r = 0; r < votes.size(); ++r)                       // :133-146, first maximum wins
+        for (const auto& pr : votes[r])
+            if (best_votes[pr.first] < pr.second) { best_votes[pr.first] = pr.second; assign[pr.first] = (int)r; }
+    *n_modes = (int)cent.size();
+    if (modes)
+        for (int c = 0; c < (int)cent.size() && c < max_modes; ++c)
+            for (int j = 0; j < d; ++j) modes[(size_t)c * d + j] = cent[c][j];
     return MH_OK;
 }
 

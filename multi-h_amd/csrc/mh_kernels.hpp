@@ -63,6 +63,25 @@ hipError_t launch_data_cost(const Points& p, const double* H, int Nh, double lam
 hipError_t launch_reestimate(const Points& p, const Affines& a, const int* labels, int Nh,
                              const Epipolar& ep, double* H, int* counts, hipStream_t s);
 
+hipError_t launch_haf_point(const Points& p, const Affines& a, const Epipolar& ep, double locality,
+                            double* H_out /* n x 9, nullable */, double* feat_out /* n x 10, nullable */,
+                            hipStream_t s);
+
+// --- meanshift.hip ----------------------------------------------------------
+struct MeanShiftWork {
+    const double* data;      // n x d row-major
+    int n, d;
+    double* mean;            // d   current mean (in/out)
+    int* votes;              // n   votes of the running climb (members get +1 per iteration)
+    int* out;                // [0] iterations, [1] converged, [2] list length
+    int* list;               // 2*n (index, votes) pairs compacted by launch_ms_collect
+};
+// One whole climb from mean[] (single workgroup, iterates on the device until the mean moves less
+// than stop_thresh or max_iters); then launch_ms_collect compacts and clears the votes.
+hipError_t launch_ms_climb(const MeanShiftWork& w, double band_sq, double stop_thresh, int max_iters,
+                           hipStream_t s);
+hipError_t launch_ms_collect(const MeanShiftWork& w, hipStream_t s);
+
 // --- expand.hip -------------------------------------------------------------
 struct Graph {              // symmetric weighted CSR in HBM
     const int* rowptr;      // n+1

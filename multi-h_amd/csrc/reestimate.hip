@@ -106,6 +106,77 @@ k_haf_reestimate(const double* __restrict__ x1, const double* __restrict__ y1,
     for (int q = 0; q < 9; ++q) out[q] = h[q] * inv;
 }
 
+// ---------------------------------------------------------------------------
+// Per-point homographies (ComputeLocalHomographies, M/MultiH.cpp:696-717 -> GetHomographyHAF
+// :850-911): the six HAF rows of ONE correspondence, A^T A (entry = sum over the six rows in
+// order), eigenvector of the smallest eigenvalue, H rows from e2/F/lambda, H / h33 (:910).
+// Also emits the 10-D feature vector EstablishStablePointSets clusters (:617-644): images of
+// (0,0),(1,0),(0,1) under H as x1 x2 x3 y1 y2 y3, then x1,y1,x2,y2 of the point times locality.
+// One thread per point (the 4x4 Jacobi is a few hundred flops).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_haf_point(const double* __restrict__ x1, const double* __restrict__ y1,
+            const double* __restrict__ x2, const double* __restrict__ y2,
+            const double* __restrict__ a11p, const double* __restrict__ a12p,
+            const double* __restrict__ a21p, const double* __restrict__ a22p, int N, Epipolar ep,
+            double locality, double* __restrict__ H_out, double* __restrict__ feat_out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double* F = ep.F;
+    const double ex = ep.ex, ey = ep.ey;
+    const double a11 = a11p[n], a12 = a12p[n], a21 = a21p[n], a22 = a22p[n];
+    const double px = x1[n], py = y1[n], qx = x2[n], qy = y2[n];
+    double r[6][4];
+    r[0][0] = a11 * px + qx - ex; r[0][1] = a11 * py;           r[0][2] = a11; r[0][3] = -F[3];
+    r[1][0] = a12 * px;           r[1][1] = a12 * py + qx - ex; r[1][2] = a12; r[1][3] = -F[4];
+    r[2][0] = a21 * px + qy - ey; r[2][1] = a21 * py;           r[2][2] = a21; r[2][3] = F[0];
+    r[3][0] = a22 * px;           r[3][1] = a22 * py + qy - ey; r[3][2] = a22; r[3][3] = F[1];
+    r[4][0] = ex * px - qx * px;  r[4][1] = ex * py - qx * py;  r[4][2] = ex - qx;
+    r[4][3] = px * F[3] + py * F[4] + F[5];
+    r[5][0] = ey * px - qy * px;  r[5][1] = ey * py - qy * py;  r[5][2] = ey - qy;
+    r[5][3] = -(px * F[0] + py * F[1] + F[2]);
+    double a[16], v[16], d[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j) {
+            double s = r[0][i] * r[0][j];
+            for (int q = 1; q < 6; ++q) s = s + r[q][i] * r[q][j];
+            a[i * 4 + j] = s;
+            a[j * 4 + i] = s;
+        }
+    jacobi_sym_dev(4, a, v, d);
+    int jm = 0;
+    for (int j = 1; j < 4; ++j) if (d[j] < d[jm]) jm = j;
+    const double h6 = v[0 * 4 + jm], h7 = v[1 * 4 + jm], h8 = v[2 * 4 + jm], lam = v[3 * 4 + jm];
+    double h[9];
+    h[6] = h6; h[7] = h7; h[8] = h8;
+    h[3] = ey * h6 - lam * F[0];
+    h[4] = ey * h7 - lam * F[1];
+    h[5] = ey * h8 - lam * F[2];
+    h[0] = ex * h6 + lam * F[3];
+    h[1] = ex * h7 + lam * F[4];
+    h[2] = ex * h8 + lam * F[5];
+    const double inv = 1.0 / h[8];                      // H = H / h33, cv::Mat / scalar scales by 1/s
+    for (int q = 0; q < 9; ++q) h[q] = h[q] * inv;
+    if (H_out) for (int q = 0; q < 9; ++q) H_out[9 * (size_t)n + q] = h[q];
+    if (feat_out) {
+        double* f = feat_out + 10 * (size_t)n;
+        const double s1 = h[8], s2 = h[6] + h[8], s3 = h[7] + h[8];
+        f[0] = h[2] / s1; f[1] = (h[0] + h[2]) / s2; f[2] = (h[1] + h[2]) / s3;
+        f[3] = h[5] / s1; f[4] = (h[3] + h[5]) / s2; f[5] = (h[4] + h[5]) / s3;
+        f[6] = px * locality; f[7] = py * locality; f[8] = qx * locality; f[9] = qy * locality;
+    }
+}
+
+hipError_t launch_haf_point(const Points& p, const Affines& a, const Epipolar& ep, double locality,
+                            double* H_out, double* feat_out, hipStream_t s)
+{
+    if (p.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_haf_point, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2,
+                       a.a11, a.a12, a.a21, a.a22, p.n, ep, locality, H_out, feat_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_reestimate(const Points& p, const Affines& a, const int* labels, int Nh,
                              const Epipolar& ep, double* H, int* counts, hipStream_t s)
 {

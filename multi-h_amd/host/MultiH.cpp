@@ -178,6 +178,11 @@ bool MultiH::Process()
 
     if (!initial_homographies.empty()) {
         for (const cv::Mat& h : initial_homographies) cluster_homographies.push_back(h.clone());
+    } else if (init_mode == INIT_STABLE_SETS) {
+        auto t0 = std::chrono::system_clock::now();
+        if (!EstablishStablePointSets()) return false;
+        std::chrono::duration<double> el = std::chrono::system_clock::now() - t0;
+        printf("[Multi-H] Stable cluster estimation time = %f secs\n", el.count());          // :74
     } else if (!ProposeInitialModels()) {
         return false;
     }
@@ -240,6 +245,44 @@ bool MultiH::DownloadModels(int count)
     if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
     cluster_homographies.clear();
     for (int i = 0; i < count; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
+    return true;
+}
+
+// EstablishStablePointSets (M/MultiH.cpp:604-694) preceded by ComputeLocalHomographies (:696-717):
+// point-wise HAF homographies and their 10-D features on the GPU (mh_local_homographies), mean
+// shift with bandwidth thr_H whose climbs run on the GPU (mh_mean_shift), then per cluster of at
+// least three points one least-squares 3-point homography with LM refinement (host, :664-688).
+bool MultiH::EstablishStablePointSets()
+{
+    const int N = static_cast<int>(src_points.size());
+    std::vector<double> feat(10 * (size_t)N);
+    if (!Check(mh_local_homographies(engine, locality_lambda, nullptr, feat.data()), "mh_local_homographies"))
+        return false;
+    // a degenerate per-point solve (NaN features) would poison the L1 ball test; park such rows far away
+    for (double& f : feat) if (!std::isfinite(f)) f = 1e300;
+    std::vector<int> assign(N);
+    int k = 0;
+    if (!Check(mh_mean_shift(engine, feat.data(), N, 10, threshold_homography, proposal_seed ^ 0x57ab1eull,
+                             nullptr, 0, assign.data(), &k),
+               "mh_mean_shift"))
+        return false;
+    std::vector<std::vector<int>> members(k);
+    for (int i = 0; i < N; ++i) if (assign[i] >= 0) members[assign[i]].push_back(i);
+    for (int c = 0; c < k; ++c) {
+        const int ni = static_cast<int>(members[c].size());
+        if (ni < 3) continue;                                                             // :667
+        std::vector<double> p1(2 * (size_t)ni), p2(2 * (size_t)ni);
+        for (int j = 0; j < ni; ++j) {
+            const int idx = members[c][j];
+            p1[2 * j] = src_points[idx].x; p1[2 * j + 1] = src_points[idx].y;
+            p2[2 * j] = dst_points[idx].x; p2[2 * j + 1] = dst_points[idx].y;
+        }
+        double H[9];
+        if (multih::Homography3PT(p1.data(), p2.data(), ni, fundamental_matrix, H, true))  // :685
+            cluster_homographies.push_back(MatFrom9(H));
+    }
+    if (log_to_console)
+        printf("[Multi-H] Number of stable, local clusters = %d\n", (int)cluster_homographies.size());   // :693
     return true;
 }
 
@@ -462,7 +505,8 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     if (F && e2) mh.SetEpipolarGeometry(F, e2);
     mh.SetProposal(seed, hypotheses, max_models);
     mh.SetFixedIterations(fixed_iterations);
-    mh.SetIterativeProposal(iter_hypotheses, iter_max_new);
+    mh.SetIterativeProposal(iter_hypotheses, iter_max_new < 0 ? 4 : iter_max_new);
+    if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init
     if (init_H && n_init > 0) {
         std::vector<cv::Mat> hs;
         for (int i = 0; i < n_init; ++i) hs.push_back(cv::Mat(3, 3, CV_64F, init_H + 9 * (size_t)i));

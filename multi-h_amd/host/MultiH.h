@@ -73,6 +73,14 @@ public:
     void SetNeighbourK(int k) { knn = k; }
     // Initial cluster_homographies (what EstablishStablePointSets hands to the loop).
     void SetInitialHomographies(const std::vector<cv::Mat>& Hs);
+    // How the initial models are made when SetInitialHomographies was not called:
+    //   INIT_DLT          random minimal samples -> batched 4-point DLT -> greedy selection (north_star)
+    //   INIT_STABLE_SETS  the reference's own route: per-point HAF homographies
+    //                     (ComputeLocalHomographies, M/MultiH.cpp:696-717) -> 10-D mean shift ->
+    //                     one 3-point LSQ homography per cluster of >= 3 points
+    //                     (EstablishStablePointSets, :604-694), all heavy steps on the GPU.
+    enum { INIT_DLT = 0, INIT_STABLE_SETS = 1 };
+    void SetInitialisation(int mode) { init_mode = mode; }
     // Propose step used when no initial models are given: `hypotheses` random 4-tuples ->
     // DLT -> greedy selection of at most `max_models` models with >= max(min inliers, 8).
     void SetProposal(uint64_t seed, int hypotheses, int max_models);
@@ -120,6 +128,7 @@ protected:
     int fixed_iterations = 0;
     int iter_hypotheses = 0, iter_max_new = 4;
     int fundamental_hypotheses = 4000;
+    int init_mode = INIT_DLT;
     uint64_t merge_rng_counter = 0;
     double loop_seconds = 0.0;
     std::vector<cv::Mat> initial_homographies;
@@ -128,6 +137,7 @@ protected:
     bool UploadModels();
     bool DownloadModels(int count);
     bool ProposeInitialModels();          // north_star propose: DLT batch + greedy selection
+    bool EstablishStablePointSets();      // M/MultiH.cpp:604-694 (with ComputeLocalHomographies :696-717)
     bool ProposeModels(uint64_t seed, long long first, int hypotheses, int max_models,
                        std::vector<unsigned char>& mask);
     void ClusterMergingAndLabeling();     // M/MultiH.cpp:224-312

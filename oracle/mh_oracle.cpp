@@ -876,6 +876,114 @@ MHO_API void mho_dlt4(const double* x1, const double* y1, const double* x2, cons
 }
 
 // ---------------------------------------------------------------------------
+// 8b. Per-point homographies and the mean shift over them (reference-style initialisation)
+// ---------------------------------------------------------------------------
+// ComputeLocalHomographies / GetHomographyHAF (M/MultiH.cpp:696-717, :850-911) + the 10-D feature of
+// EstablishStablePointSets (:617-644).
+MHO_API void mho_haf_point(const double* x1, const double* y1, const double* x2, const double* y2,
+                           const double* aff, int N, const double* F, const double* e2, double locality,
+                           double* H /* N*9 */, double* feat /* N*10 */)
+{
+    const double ex = e2[0], ey = e2[1];
+    for (int n = 0; n < N; ++n) {
+        double r[6][4];
+        haf_rows(aff[4 * n], aff[4 * n + 1], aff[4 * n + 2], aff[4 * n + 3], x1[n], y1[n], x2[n], y2[n], F, ex, ey, r);
+        double a[16], v[16], d[4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = i; j < 4; ++j) {
+                double s = r[0][i] * r[0][j];
+                for (int q = 1; q < 6; ++q) s = s + r[q][i] * r[q][j];
+                a[i * 4 + j] = s; a[j * 4 + i] = s;
+            }
+        jacobi_sym(4, a, v, d);
+        int jm = 0;
+        for (int j = 1; j < 4; ++j) if (d[j] < d[jm]) jm = j;
+        const double h6 = v[0 * 4 + jm], h7 = v[1 * 4 + jm], h8 = v[2 * 4 + jm], lam = v[3 * 4 + jm];
+        double h[9];
+        h[6] = h6; h[7] = h7; h[8] = h8;
+        h[3] = ey * h6 - lam * F[0]; h[4] = ey * h7 - lam * F[1]; h[5] = ey * h8 - lam * F[2];
+        h[0] = ex * h6 + lam * F[3]; h[1] = ex * h7 + lam * F[4]; h[2] = ex * h8 + lam * F[5];
+        const double inv = 1.0 / h[8];
+        for (int q = 0; q < 9; ++q) h[q] = h[q] * inv;
+        if (H) for (int q = 0; q < 9; ++q) H[9 * (size_t)n + q] = h[q];
+        if (feat) {
+            double* f = feat + 10 * (size_t)n;
+            const double s1 = h[8], s2 = h[6] + h[8], s3 = h[7] + h[8];
+            f[0] = h[2] / s1; f[1] = (h[0] + h[2]) / s2; f[2] = (h[1] + h[2]) / s3;
+            f[3] = h[5] / s1; f[4] = (h[3] + h[5]) / s2; f[5] = (h[4] + h[5]) / s3;
+            f[6] = x1[n] * locality; f[7] = y1[n] * locality; f[8] = x2[n] * locality; f[9] = y2[n] * locality;
+        }
+    }
+}
+
+// MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157) with the engine's counter RNG
+// and the engine's summation order for the member sums (strided tree), so that the GPU climbs can be
+// compared bit for bit.  Returns the number of modes; modes (k x d), assign (n).
+MHO_API int mho_mean_shift(const double* data, int n, int d, double bw, unsigned long long seed,
+                           double* modes, int max_modes, int* assign)
+{
+    const double band_sq = bw * bw, stop = 1e-3 * bw;
+    std::vector<int> init(n), visited(n, 0);
+    for (int i = 0; i < n; ++i) init[i] = i;
+    std::vector<std::vector<double>> cent;
+    std::vector<std::vector<int>> votes;
+    uint64_t counter = 0;
+    auto l2 = [](const double* a, const double* b, int dd) {
+        double s = 0.0;
+        for (int j = 0; j < dd; ++j) { const double x = a[j] - b[j]; s = s + x * x; }
+        return sqrt(s);
+    };
+    while (!init.empty()) {
+        const double rnd = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
+        const int st = init[(int)round(rnd * (double)(init.size() - 1))];
+        std::vector<double> mean(data + (size_t)st * d, data + (size_t)(st + 1) * d);
+        std::vector<int> my(n, 0);
+        bool converged = false;
+        for (int it = 0; it < 100000; ++it) {
+            const std::vector<double> old = mean;
+            TreeAcc acc(d);
+            int in = 0;
+            for (int i = 0; i < n; ++i) {
+                double dist = 0.0;
+                for (int j = 0; j < d; ++j) { const double r = old[j] - data[(size_t)i * d + j]; dist += sqrt(r * r); }
+                if (dist < band_sq) { acc.add(i, data + (size_t)i * d); ++in; ++my[i]; visited[i] = 1; }
+            }
+            if (in == 0) break;
+            std::vector<double> sum(d);
+            acc.finish(sum.data());
+            const double inv = 1.0 / (double)in;
+            double move = 0.0;
+            for (int j = 0; j < d; ++j) { mean[j] = sum[j] * inv; const double dd = mean[j] - old[j]; move = move + dd * dd; }
+            if (sqrt(move) < stop) { converged = true; break; }
+        }
+        if (!converged) {
+            visited[st] = 1;
+        } else {
+            int mw = -1;
+            for (size_t cn = 0; cn < cent.size(); ++cn)
+                if (l2(mean.data(), cent[cn].data(), d) < bw / 2) { mw = (int)cn; break; }
+            if (mw > -1) {
+                for (int j = 0; j < d; ++j) cent[mw][j] = 0.5 * (cent[mw][j] + mean[j]);
+                for (int i = 0; i < n; ++i) votes[mw][i] += my[i];
+            } else {
+                cent.push_back(mean);
+                votes.push_back(my);
+            }
+        }
+        init.clear();
+        for (int i = 0; i < n; ++i) if (!visited[i]) init.push_back(i);
+    }
+    std::vector<int> bv(n, 0);
+    for (int i = 0; i < n; ++i) assign[i] = -1;
+    for (size_t r = 0; r < votes.size(); ++r)
+        for (int i = 0; i < n; ++i)
+            if (bv[i] < votes[r][i]) { bv[i] = votes[r][i]; assign[i] = (int)r; }
+    for (int c = 0; c < (int)cent.size() && c < max_modes; ++c)
+        for (int j = 0; j < d; ++j) modes[(size_t)c * d + j] = cent[c][j];
+    return (int)cent.size();
+}
+
+// ---------------------------------------------------------------------------
 // 9b. Epipolar front half — own definition, "parity unpinned": the
 //     reference calls cv::findFundamentalMat(RANSAC) (M/MultiH.cpp:775), OpenCV 3.1.0 calib3d.
 // ---------------------------------------------------------------------------

@@ -198,6 +198,25 @@ def dlt4(src, dst, idx):
     return H, wit, sw
 
 
+def haf_point(src, dst, aff, F, e2, locality):
+    x1, y1, x2, y2 = soa(src, dst)
+    aff, F, e2 = f64(aff), f64(F), f64(e2)
+    H = np.empty((x1.size, 9))
+    feat = np.empty((x1.size, 10))
+    lib().mho_haf_point(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(F), _d(e2), C.c_double(locality),
+                        _d(H), _d(feat))
+    return H, feat
+
+
+def mean_shift(data, bw, seed):
+    data = f64(data)
+    n, d = data.shape
+    modes = np.empty((n, d))
+    assign = np.empty(n, dtype=np.int32)
+    k = lib().mho_mean_shift(_d(data), n, d, C.c_double(bw), C.c_ulonglong(seed), _d(modes), n, _i(assign))
+    return modes[:k].copy(), assign, int(k)
+
+
 def sample8(seed, m0, M, N):
     idx = np.empty((M, 8), dtype=np.int32)
     lib().mho_sample8(C.c_ulonglong(seed), C.c_longlong(m0), M, N, _i(idx))

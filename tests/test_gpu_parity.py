@@ -596,3 +596,60 @@ def test_process_from_raw_correspondences(mh, engine_lib, synth):
     assert 3 <= k <= 8
     kept = labels[labels != -7]
     assert 1000 < kept.size < 2903 and (kept >= 0).sum() > 500
+
+
+# ---- reference-style initialisation: per-point HAF + mean shift ------------------------------
+def test_local_homographies_and_features(engine, synth, oracle):
+    sc = synth.make_scene(3000, 3, seed=5, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    H, feat = engine.local_homographies(0.005)
+    H_ref, feat_ref = oracle.haf_point(sc.src, sc.dst, sc.aff, sc.F, sc.e2, 0.005)
+    ok = np.isfinite(H_ref).all(axis=1)
+    assert ok.mean() > 0.99
+    assert np.array_equal(H[ok].view(np.uint64), H_ref[ok].view(np.uint64))
+    assert np.array_equal(feat[ok].view(np.uint64), feat_ref[ok].view(np.uint64))
+    # a point-wise homography maps its own point onto its correspondence (inliers, up to the affinity noise)
+    inl = (sc.gt_label >= 0) & ok
+    p = np.stack([synth.apply_h(H[i], sc.src[i:i + 1])[0] for i in np.flatnonzero(inl)[:200]])
+    assert np.median(np.abs(p - sc.dst[np.flatnonzero(inl)[:200]])) < 1.0
+
+
+@pytest.mark.parametrize("n,d,seed", [(60, 6, 1), (500, 10, 2), (3000, 10, 3)])
+def test_gpu_mean_shift_matches_oracle(engine, oracle, n, d, seed):
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-40, 40, size=(max(3, n // 40), d))
+    data = np.concatenate([c + rng.normal(0, 0.2, size=(30, d)) for c in centres])[:n]
+    data = np.concatenate([data, rng.uniform(-40, 40, size=(n - len(data), d))]) if len(data) < n else data
+    modes, assign, k = engine.mean_shift(data, 2.2, seed)
+    modes_o, assign_o, k_o = oracle.mean_shift(data, 2.2, seed)
+    assert k == k_o
+    assert np.array_equal(assign, assign_o)
+    assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64))
+    assert (assign >= 0).all()
+
+
+def test_process_with_reference_style_initialisation(mh, engine_lib, synth):
+    """INIT_STABLE_SETS: per-point HAF -> mean shift -> 3-point LSQ per cluster (the reference's own
+    ComputeLocalHomographies + EstablishStablePointSets), then the usual merge/label loop."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    sc = synth.make_scene(3000, 3, seed=77)
+    n = sc.n
+    dp = C.POINTER(C.c_double)
+    labels = np.full(n, -7, dtype=np.int32)
+    Hout = np.zeros((256, 9))
+    it = C.c_int(0)
+    src, dst, aff, F, e2 = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.aff, sc.F, sc.e2))
+    k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n,
+                             F.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2),
+                             C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1234), 0, 0, 0, None, 0,
+                             labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256,
+                             C.byref(it), None, None, 0, -1)
+    assert k >= 3 and labels.min() >= -1 and labels.max() < k
+    dom = []
+    for p in range(3):
+        lab_p = labels[sc.gt_label == p]
+        vals, counts = np.unique(lab_p[lab_p >= 0], return_counts=True)
+        assert counts.max() > 0.5 * (sc.gt_label == p).sum()
+        dom.append(int(vals[np.argmax(counts)]))
+    assert len(set(dom)) == 3
