@@ -100,6 +100,17 @@ MH_API int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hy
                             double F[9], double e2[2], unsigned char* inlier_mask /* n, nullable */,
                             int* inliers);
 
+/* Epipoles of F with third coordinate 1: e1 = eigenvector of F^T F, e2 = eigenvector of F F^T with the
+ * smallest eigenvalue (M/MultiH.cpp:786-799).  Host arithmetic only; e may be NULL. */
+MH_API int mh_epipoles(mh_engine* e, const double F[9], double e1[2], double e2[2]);
+/* Per-correspondence refinement of GetFundamentalMatrixAndRefineData (M/MultiH.cpp:807-838) on the
+ * GPU: Hartley-Sturm correction (OptimalTriangulation :1116-1188), affine consistency filter
+ * (distanceError > 1 drops the point, :824-827) and the optimal affinity (:1190-1223).
+ * in_mask (n, nullable): only points with mask != 0 are processed (the F-RANSAC mask of :809).
+ * keep (n): 1 where the point survives; refined (n x 8): x1 y1 x2 y2 a11 a12 a21 a22 of survivors. */
+MH_API int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2], const double e2[2],
+                              const unsigned char* in_mask, unsigned char* keep, double* refined);
+
 /* ---- reference-style initialisation ------------- */
 /* ComputeLocalHomographies (M/MultiH.cpp:696-717, GetHomographyHAF :850-911): one homography per
  * correspondence from its affinity, F and e2; H_out (n x 9, nullable).  feat_out (n x 10, nullable)

@@ -23,7 +23,8 @@ SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
     "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_get_sym_graph", "mh_propose_fund8",
-    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
+    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
+    "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
@@ -181,6 +182,24 @@ class Engine:
                                                      _p(F, C.c_double), _p(e2, C.c_double), _p(mask, C.c_ubyte),
                                                      C.byref(inl)))
         return F, e2, mask, inl.value
+
+    def epipoles(self, F):
+        F = _f64(F).reshape(9)
+        e1, e2 = np.empty(2), np.empty(2)
+        self._check(self.lib.mh_epipoles(self._h, _p(F, C.c_double), _p(e1, C.c_double), _p(e2, C.c_double)))
+        return e1, e2
+
+    def refine_correspondences(self, F, e1, e2, in_mask=None):
+        F, e1, e2 = _f64(F).reshape(9), _f64(e1).reshape(2), _f64(e2).reshape(2)
+        keep = np.empty(self.n, dtype=np.uint8)
+        out = np.empty((self.n, 8), dtype=np.float64)
+        mp = None
+        if in_mask is not None:
+            in_mask = np.ascontiguousarray(in_mask, dtype=np.uint8)
+            mp = _p(in_mask, C.c_ubyte)
+        self._check(self.lib.mh_refine_correspondences(self._h, _p(F, C.c_double), _p(e1, C.c_double), _p(e2, C.c_double),
+                                                       mp, _p(keep, C.c_ubyte), _p(out, C.c_double)))
+        return keep, out
 
     # -- reference-style initialisation ------------------------------------------
     def local_homographies(self, locality: float):

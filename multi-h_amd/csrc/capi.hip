@@ -82,7 +82,8 @@ struct mh_engine {
     int fm = 0;
     DevBuf<double> fund, fund_one;
     DevBuf<int> fund_samples, fund_counts, fund_inl;
-    DevBuf<unsigned char> fund_mask;
+    DevBuf<unsigned char> fund_mask, ref_keep, ref_in;
+    DevBuf<double> ref_out;
 
     // reference-style initialisation
     DevBuf<double> loc_H, loc_feat, ms_data, ms_mean;
@@ -409,7 +410,7 @@ void mh_destroy(mh_engine* e)
     e->H.release(); e->samples.release(); e->counts.release(); e->R.release(); e->mask.release();
     e->moments.release(); e->min_eig.release();
     e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
-    e->fund_inl.release(); e->fund_mask.release();
+    e->fund_inl.release(); e->fund_mask.release(); e->ref_keep.release(); e->ref_in.release(); e->ref_out.release();
     e->loc_H.release(); e->loc_feat.release(); e->ms_data.release(); e->ms_mean.release();
     e->ms_votes.release(); e->ms_out.release(); e->ms_list.release();
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
@@ -595,6 +596,29 @@ int mh_refit_fundamental(mh_engine* e, const double F_in[9], double thr2, int it
     return MH_OK;
 }
 
+int mh_epipoles(mh_engine*, const double F[9], double e1[2], double e2[2])
+{
+    if (!F || !e1 || !e2) return fail(MH_ERR_INVALID, "null argument");
+    for (int which = 0; which < 2; ++which) {
+        double A[9], V[9], D[3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < 3; ++k)
+                    a = a + (which == 0 ? F[3 * k + i] * F[3 * k + j]      // F^T F  (:795)
+                                        : F[3 * i + k] * F[3 * j + k]);    // F F^T  (:789)
+                A[3 * i + j] = a;
+            }
+        host_jacobi3(A, V, D);
+        int jm = 0;
+        for (int j = 1; j < 3; ++j) if (D[j] < D[jm]) jm = j;
+        double* out = which == 0 ? e1 : e2;
+        out[0] = V[0 * 3 + jm] / V[2 * 3 + jm];
+        out[1] = V[1 * 3 + jm] / V[2 * 3 + jm];
+    }
+    return MH_OK;
+}
+
 int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypotheses, double thr, double F[9],
                             double e2[2], unsigned char* inlier_mask, int* inliers)
 {
@@ -615,20 +639,31 @@ int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypothese
     double Fdummy[9];
     rc = mh_refit_fundamental(e, F, thr * thr, 1, Fdummy, inlier_mask, inliers);
     if (rc) return rc;
-    // epipole in image 2: eigenvector of F F^T with the smallest eigenvalue, / third coordinate
-    // (M/MultiH.cpp:789-793)
-    double A[9], V[9], D[3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double a = 0.0;
-            for (int k = 0; k < 3; ++k) a = a + F[3 * i + k] * F[3 * j + k];
-            A[3 * i + j] = a;
-        }
-    host_jacobi3(A, V, D);
-    int jm = 0;
-    for (int j = 1; j < 3; ++j) if (D[j] < D[jm]) jm = j;
-    e2[0] = V[0 * 3 + jm] / V[2 * 3 + jm];
-    e2[1] = V[1 * 3 + jm] / V[2 * 3 + jm];
+    double e1[2];
+    return mh_epipoles(e, F, e1, e2);                  // M/MultiH.cpp:786-799
+}
+
+int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2], const double e2[2],
+                              const unsigned char* in_mask, unsigned char* keep, double* refined)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!F || !e1 || !e2 || !keep || !refined) return fail(MH_ERR_INVALID, "null argument");
+    if (!e->have_aff) return fail(MH_ERR_NOT_SET, "affinities are not set");
+    HIPCHK(e->ref_keep.reserve((size_t)e->n + 2));
+    HIPCHK(e->ref_out.reserve((size_t)e->n * 8));
+    const unsigned char* dmask = nullptr;
+    if (in_mask) {
+        HIPCHK(e->ref_in.reserve((size_t)e->n + 2));
+        HIPCHK(hipMemcpyAsync(e->ref_in.p, in_mask, e->n, hipMemcpyHostToDevice, e->stream));
+        dmask = e->ref_in.p;
+    }
+    HIPCHK(hipMemsetAsync(e->ref_out.p, 0, sizeof(double) * 8 * (size_t)e->n, e->stream));
+    Affines a{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
+    HIPCHK(launch_refine_points(e->pts(), a, F, e1, e2, dmask, e->ref_keep.p, e->ref_out.p, e->stream));
+    HIPCHK(hipMemcpyAsync(keep, e->ref_keep.p, e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(refined, e->ref_out.p, sizeof(double) * 8 * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
 }
 

@@ -67,6 +67,11 @@ hipError_t launch_haf_point(const Points& p, const Affines& a, const Epipolar& e
                             double* H_out /* n x 9, nullable */, double* feat_out /* n x 10, nullable */,
                             hipStream_t s);
 
+// --- refine.hip -------------------------------------------------------------
+hipError_t launch_refine_points(const Points& p, const Affines& a, const double F[9], const double e1[2],
+                                const double e2[2], const unsigned char* in_mask, unsigned char* keep,
+                                double* out /* n x 8 */, hipStream_t s);
+
 // --- meanshift.hip ----------------------------------------------------------
 struct MeanShiftWork {
     const double* data;      // n x d row-major

@@ -128,10 +128,9 @@ bool MultiH::Process()
         return false;
 
     if (!have_epipolar) {
-        // GetFundamentalMatrixAndRefineData, first part (M/MultiH.cpp:775-799) on the GPU: RANSAC over
-        // normalised 8-point hypotheses with Sampson scoring, LS refit, epipole from F F^T.  The
-        // reference then also applies the Hartley-Sturm correction and the affine consistency filter
-        // (:807-838); those are not reproduced — F-inliers are kept as they are.
+        // GetFundamentalMatrixAndRefineData (M/MultiH.cpp:770-848) on the GPU: RANSAC over normalised
+        // 8-point hypotheses with Sampson scoring, LS refit, epipoles from F^T F / F F^T, then the
+        // per-correspondence refinement of :807-838.
         std::vector<unsigned char> mask(N, 0);
         int inl = 0;
         const bool ok = Check(mh_estimate_fundamental(engine, proposal_seed ^ 0xf00dull, fundamental_hypotheses,
@@ -145,10 +144,24 @@ bool MultiH::Process()
         if (degenerate_case) {
             printf("[Multi-H] Degenerate case, the fundamental matrix cannot be estimated.\n");
         } else {
+            // :807-838 on the GPU: Hartley-Sturm correction, affine consistency filter, optimal affinity
+            double e1[2];
+            std::vector<unsigned char> keep(N, 0);
+            std::vector<double> refined(8 * (size_t)N);
+            if (!Check(mh_epipoles(engine, fundamental_matrix, e1, epipole_2), "mh_epipoles") ||
+                !Check(mh_refine_correspondences(engine, fundamental_matrix, e1, epipole_2, mask.data(), keep.data(),
+                                                 refined.data()),
+                       "mh_refine_correspondences"))
+                return false;
             std::vector<cv::Point2d> s2, d2;
             std::vector<cv::Mat> a2;
             for (int i = 0; i < N; ++i)
-                if (mask[i]) { s2.push_back(src_points[i]); d2.push_back(dst_points[i]); a2.push_back(affinities[i]); }
+                if (keep[i]) {
+                    const double* r = &refined[8 * (size_t)i];
+                    s2.push_back(cv::Point2d(r[0], r[1]));
+                    d2.push_back(cv::Point2d(r[2], r[3]));
+                    a2.push_back(cv::Mat(2, 2, CV_64F, r + 4));
+                }
             printf("[Multi-H] %d points kept from the initial %d after filtering.\n", (int)s2.size(), N);   // :840
             if (s2.size() < 8) {
                 degenerate_case = true;

@@ -11,9 +11,10 @@
 // front half of the reference's Process() — findFundamentalMat, Hartley-Sturm
 // correction, affine consistency, per-point HAF, stable-set initialisation
 // (M/MultiH.cpp:770-848, 696-717, 604-694) — is §8(f) row 4 ("next") and is NOT
-// fully re-implemented: F and the epipole are either supplied (SetEpipolarGeometry) or estimated on
-// the GPU (8-point RANSAC, Sampson scoring, LS refit); the Hartley-Sturm point correction and the
-// affine consistency filter are not reproduced.  Optional neighbour hits and initial models can be
+// re-implemented on the GPU: F and the epipoles are either supplied (SetEpipolarGeometry; the points are
+// then taken as already refined) or estimated (8-point RANSAC, Sampson scoring, LS refit) and followed
+// by the per-correspondence refinement (Hartley-Sturm correction, affine consistency filter, optimal
+// affinity).  Optional neighbour hits and initial models can be
 // supplied; when no initial models are given the engine proposes them itself from random minimal
 // samples with the batched 4-point DLT (north_star).
 #pragma once

@@ -1189,6 +1189,146 @@ MHO_API int mho_fund_refit(const double* x1, const double* y1, const double* x2,
 }
 
 // ---------------------------------------------------------------------------
+// 9c. Per-correspondence refinement of GetFundamentalMatrixAndRefineData (M/MultiH.cpp:807-838):
+//     OptimalTriangulation (:1116-1188), GetAffineConsistency/GetBetaScale (:1057-1114),
+//     GetOptimalAffineTransformation (:1190-1223).  cv::solvePoly (OpenCV, unpinned) is replaced by
+//     Durand-Kerner with fixed start values; the 6x6 inverse of :1219 by its closed form.
+// ---------------------------------------------------------------------------
+namespace {
+struct Cplx { double re, im; };
+inline Cplx cmul(Cplx a, Cplx b) { return { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; }
+inline Cplx csub(Cplx a, Cplx b) { return { a.re - b.re, a.im - b.im }; }
+inline Cplx cdiv(Cplx a, Cplx b)
+{
+    const double den = b.re * b.re + b.im * b.im;
+    return { (a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den };
+}
+void poly_roots(const double* c, int n, Cplx* z)
+{
+    double m[7];
+    for (int k = 0; k <= n; ++k) m[k] = c[k] / c[n];
+    Cplx seed = { 1.0, 0.0 };
+    const Cplx base = { 0.4, 0.9 };
+    for (int k = 0; k < n; ++k) { z[k] = seed; seed = cmul(seed, base); }
+    for (int it = 0; it < 200; ++it) {
+        double moved = 0.0;
+        for (int k = 0; k < n; ++k) {
+            Cplx p = { 1.0, 0.0 };
+            for (int j = n - 1; j >= 0; --j) { p = cmul(p, z[k]); p.re = p.re + m[j]; }
+            Cplx q = { 1.0, 0.0 };
+            for (int j = 0; j < n; ++j) if (j != k) q = cmul(q, csub(z[k], z[j]));
+            const Cplx d = cdiv(p, q);
+            z[k] = csub(z[k], d);
+            const double step = fabs(d.re) + fabs(d.im);
+            const double mag = fabs(z[k].re) + fabs(z[k].im);
+            if (step > 1e-14 * mag + 1e-300 && step > moved) moved = step;
+        }
+        if (moved == 0.0) break;
+    }
+}
+} // namespace
+
+MHO_API void mho_poly_roots(const double* c, int n, double* re, double* im)
+{
+    Cplx z[6];
+    poly_roots(c, n, z);
+    for (int i = 0; i < n; ++i) { re[i] = z[i].re; im[i] = z[i].im; }
+}
+
+MHO_API void mho_refine_points(const double* x1, const double* y1, const double* x2, const double* y2,
+                               const double* aff, int N, const double* F, const double* e1, const double* e2,
+                               const unsigned char* in_mask, unsigned char* keep, double* out /* N*8 */)
+{
+    const double e1x = e1[0], e1y = e1[1], e2x = e2[0], e2y = e2[1];
+    for (int n = 0; n < N; ++n) {
+        keep[n] = 0;
+        for (int q = 0; q < 8; ++q) out[8 * (size_t)n + q] = 0.0;
+        if (in_mask && !in_mask[n]) continue;
+        const double px = x1[n], py = y1[n], qx = x2[n], qy = y2[n];
+        double G[9], F2[9], M2[9], F3[9];
+        for (int r = 0; r < 3; ++r) {
+            G[3 * r] = F[3 * r]; G[3 * r + 1] = F[3 * r + 1];
+            G[3 * r + 2] = (F[3 * r] * px + F[3 * r + 1] * py) + F[3 * r + 2];
+        }
+        for (int c = 0; c < 3; ++c) { F2[c] = G[c]; F2[3 + c] = G[3 + c]; F2[6 + c] = (qx * G[c] + qy * G[3 + c]) + G[6 + c]; }
+        for (int c = 0; c < 3; ++c) {
+            M2[c] = (-e2x) * F2[c] + (-e2y) * F2[3 + c];
+            M2[3 + c] = e2y * F2[c] + (-e2x) * F2[3 + c];
+            M2[6 + c] = F2[6 + c];
+        }
+        for (int r = 0; r < 3; ++r) {
+            F3[3 * r] = M2[3 * r] * e1x + M2[3 * r + 1] * e1y;
+            F3[3 * r + 1] = M2[3 * r] * (-e1y) + M2[3 * r + 1] * e1x;
+            F3[3 * r + 2] = M2[3 * r + 2];
+        }
+        const double f1 = 1.0, f2 = 1.0;
+        const double a = F3[4], b = F3[5], c = F3[7], d = F3[8];
+        const double f14 = f1 * f1 * f1 * f1, f22 = f2 * f2, f12 = f1 * f1;
+        const double adbc = a * d - b * c;
+        double t[7];
+        t[6] = -a * c * f14 * adbc;
+        t[5] = (a * a + f22 * c * c) * (a * a + f22 * c * c) - (a * d + b * c) * f14 * adbc;
+        t[4] = 2 * (a * a + f22 * c * c) * (2 * a * b + 2 * c * d * f22) - d * b * f14 * adbc - 2 * a * c * f12 * adbc;
+        t[3] = (2 * a * b + 2 * c * d * f22) * (2 * a * b + 2 * c * d * f22) + 2 * (a * a + f22 * c * c) * (b * b + f22 * d * d) -
+               2 * f12 * adbc * (a * d + b * c);
+        t[2] = 2 * (2 * a * b + 2 * c * d * f22) * (b * b + f22 * d * d) - 2 * (f12 * a * d - f12 * b * c) * b * d - a * c * adbc;
+        t[1] = (b * b + f22 * d * d) * (b * b + f22 * d * d) - (a * d + b * c) * adbc;
+        t[0] = -adbc * b * d;
+        int deg = 6;
+        while (deg > 0 && t[deg] == 0.0) --deg;
+        double bestS = 2147483647.0, bestT = 0.0;
+        if (deg > 0) {
+            Cplx z[6];
+            poly_roots(t, deg, z);
+            for (int i = 0; i < deg; ++i)
+                if (fabs(z[i].im) <= 1e-10) {
+                    const double tt = z[i].re;
+                    const double ct = c * tt + d, at = a * tt + b;
+                    const double val = tt * tt / (1 + f12 * tt * tt) + (ct * ct) / (at * at + f22 * (ct * ct));
+                    if (val < bestS) { bestS = val; bestT = tt; }
+                }
+        }
+        const double valInf = 1 / f12 + (c * c) / (a * a + f22 * c * c);
+        if (valInf < bestS) continue;
+        const double l0 = F3[1] * bestT + F3[2], l1 = F3[4] * bestT + F3[5], l2 = F3[7] * bestT + F3[8];
+        const double w2 = l0 * l0 + l1 * l1;
+        const double iw = 1.0 / w2;
+        const double p2x = (-l0 * l2) * iw, p2y = (-l1 * l2) * iw;
+        const double s1 = e1x * e1x + e1y * e1y, s2 = e2x * e2x + e2y * e2y;
+        const double ux = (e1x * 0.0 - e1y * bestT) / s1 + px;
+        const double uy = (e1y * 0.0 + e1x * bestT) / s1 + py;
+        const double vx = (-e2x * p2x + e2y * p2y) / s2 + qx;
+        const double vy = (-e2y * p2x - e2x * p2y) / s2 + qy;
+        const double A11 = aff[4 * n], A12 = aff[4 * n + 1], A21 = aff[4 * n + 2], A22 = aff[4 * n + 3];
+        const double L1[3] = { (F[0] * vx + F[3] * vy) + F[6], (F[1] * vx + F[4] * vy) + F[7], (F[2] * vx + F[5] * vy) + F[8] };
+        const double L2[3] = { (F[0] * ux + F[1] * uy) + F[2], (F[3] * ux + F[4] * uy) + F[5], (F[6] * ux + F[7] * uy) + F[8] };
+        const double xn1 = ux + 1.0;
+        const double yn1 = -(L1[0] * xn1 + L1[2]) / L1[1];
+        double d1x = xn1 - ux, d1y = yn1 - uy;
+        const double nd1 = sqrt(d1x * d1x + d1y * d1y);
+        d1x = d1x / nd1; d1y = d1y / nd1;
+        const double beta = fabs(sqrt(L2[0] * L2[0] + L2[1] * L2[1]) /
+                                 ((-F[0] * d1y + F[1] * d1x) * vx + (-F[3] * d1y + F[4] * d1x) * vy - F[6] * d1y + F[7] * d1x));
+        double n1x = L1[0] / L1[2], n1y = L1[1] / L1[2], n2x = L2[0] / L2[2], n2y = L2[1] / L2[2];
+        const double nn1 = sqrt(n1x * n1x + n1y * n1y), nn2 = sqrt(n2x * n2x + n2y * n2y);
+        n1x = n1x / nn1; n1y = n1y / nn1; n2x = n2x / nn2; n2y = n2y / nn2;
+        const double det = A11 * A22 - A12 * A21;
+        const double r1x = (A22 * n1x - A21 * n1y) / det, r1y = (-A12 * n1x + A11 * n1y) / det;
+        const double ex_ = r1x - beta * n2x, ey_ = r1y - beta * n2y;
+        const double distanceError = sqrt(ex_ * ex_ + ey_ * ey_);
+        if (!(distanceError <= 1.0)) continue;
+        if (n1x * n2x + n1y * n2y < 0) { n2x = -n2x; n2y = -n2y; }
+        const double ppx = beta * n2x, ppy = beta * n2y, pp = ppx * ppx + ppy * ppy;
+        const double lam1 = (n1x - (ppx * A11 + ppy * A21)) / pp;
+        const double lam2 = (n1y - (ppx * A12 + ppy * A22)) / pp;
+        double* o = out + 8 * (size_t)n;
+        o[0] = ux; o[1] = uy; o[2] = vx; o[3] = vy;
+        o[4] = A11 + ppx * lam1; o[5] = A12 + ppx * lam2; o[6] = A21 + ppy * lam1; o[7] = A22 + ppy * lam2;
+        keep[n] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 10. LabelingStep and the alternating loop              
 // ---------------------------------------------------------------------------
 // LabelingStep, M/MultiH.cpp:513-602: data cost -> expansion (warm start iff

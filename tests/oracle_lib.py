@@ -198,6 +198,28 @@ def dlt4(src, dst, idx):
     return H, wit, sw
 
 
+def poly_roots(coeffs):
+    c = f64(coeffs)
+    n = c.size - 1
+    re, im = np.empty(n), np.empty(n)
+    lib().mho_poly_roots(_d(c), n, _d(re), _d(im))
+    return re + 1j * im
+
+
+def refine_points(src, dst, aff, F, e1, e2, in_mask=None):
+    x1, y1, x2, y2 = soa(src, dst)
+    aff, F, e1, e2 = f64(aff), f64(F), f64(e1), f64(e2)
+    keep = np.empty(x1.size, dtype=np.uint8)
+    out = np.empty((x1.size, 8))
+    mp = None
+    if in_mask is not None:
+        in_mask = np.ascontiguousarray(in_mask, dtype=np.uint8)
+        mp = in_mask.ctypes.data_as(C.POINTER(C.c_ubyte))
+    lib().mho_refine_points(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(F), _d(e1), _d(e2), mp,
+                            keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(out))
+    return keep, out
+
+
 def haf_point(src, dst, aff, F, e2, locality):
     x1, y1, x2, y2 = soa(src, dst)
     aff, F, e2 = f64(aff), f64(F), f64(e2)

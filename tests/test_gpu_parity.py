@@ -653,3 +653,20 @@ def test_process_with_reference_style_initialisation(mh, engine_lib, synth):
         assert counts.max() > 0.5 * (sc.gt_label == p).sum()
         dom.append(int(vals[np.argmax(counts)]))
     assert len(set(dom)) == 3
+
+
+def test_refine_correspondences(engine, synth, oracle):
+    """GetFundamentalMatrixAndRefineData's per-point part (M/MultiH.cpp:807-838) on the GPU vs the oracle:
+    keep mask identical, corrected coordinates and optimal affinities bit-identical."""
+    sc = synth.make_scene(4000, 3, seed=23, noise=0.5, outlier_frac=0.15, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    e1, e2 = engine.epipoles(sc.F)
+    assert np.max(np.abs(e2 - sc.e2) / np.abs(sc.e2)) < 1e-6
+    mask = (np.random.default_rng(0).random(sc.n) < 0.9).astype(np.uint8)
+    keep, out = engine.refine_correspondences(sc.F, e1, e2, mask)
+    keep_o, out_o = oracle.refine_points(sc.src, sc.dst, sc.aff, sc.F, e1, e2, mask)
+    assert np.array_equal(keep, keep_o)
+    k = keep.astype(bool)
+    assert (keep[mask == 0] == 0).all() and k.sum() > 0.6 * sc.n
+    assert np.max(np.abs(out[k] - out_o[k]) / np.maximum(1e-12, np.abs(out_o[k]))) <= 1e-6
+    assert np.array_equal(out[k].view(np.uint64), out_o[k].view(np.uint64))
