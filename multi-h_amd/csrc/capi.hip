@@ -87,7 +87,8 @@ struct mh_engine {
 
     // reference-style initialisation
     DevBuf<double> loc_H, loc_feat, ms_data, ms_mean;
-    DevBuf<int> ms_votes, ms_out, ms_list;
+    DevBuf<int> ms_votes, ms_out, ms_list, ms_pcnt;
+    DevBuf<double> ms_partial;
 
     // labeling
     int cost_L = 0;
@@ -412,7 +413,7 @@ void mh_destroy(mh_engine* e)
     e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
     e->fund_inl.release(); e->fund_mask.release(); e->ref_keep.release(); e->ref_in.release(); e->ref_out.release();
     e->loc_H.release(); e->loc_feat.release(); e->ms_data.release(); e->ms_mean.release();
-    e->ms_votes.release(); e->ms_out.release(); e->ms_list.release();
+    e->ms_votes.release(); e->ms_out.release(); e->ms_list.release(); e->ms_pcnt.release(); e->ms_partial.release();
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_flags.release(); e->ew_acc.release();
@@ -695,9 +696,12 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     HIPCHK(e->ms_votes.reserve(n));
     HIPCHK(e->ms_out.reserve(4));
     HIPCHK(e->ms_list.reserve(2 * (size_t)n));
+    HIPCHK(e->ms_partial.reserve(64 * 16));
+    HIPCHK(e->ms_pcnt.reserve(64));
     HIPCHK(hipMemcpyAsync(e->ms_data.p, data, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(e->ms_votes.p, 0, sizeof(int) * n, e->stream));
-    MeanShiftWork w{ e->ms_data.p, n, d, e->ms_mean.p, e->ms_votes.p, e->ms_out.p, e->ms_list.p };
+    MeanShiftWork w{ e->ms_data.p, n, d, e->ms_mean.p, e->ms_votes.p, e->ms_out.p, e->ms_list.p,
+                     e->ms_partial.p, e->ms_pcnt.p };
     const double band_sq = band_width * band_width;                 // MeanShiftClustering.h:31
     const double stop_thresh = 1e-3 * band_width;                   // :48
     std::vector<int> init(n), visited(n, 0), list;
@@ -720,10 +724,15 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         const int st = init[(int)std::round(rnd * (double)(init.size() - 1))];          // :55-56
         HIPCHK(hipMemcpyAsync(e->ms_mean.p, data + (size_t)st * d, sizeof(double) * d, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemsetAsync(e->ms_out.p, 0, sizeof(int) * 4, e->stream));
-        HIPCHK(launch_ms_climb(w, band_sq, stop_thresh, 100000, e->stream));
-        HIPCHK(launch_ms_collect(w, e->stream));
         int out[4];
         double mean[16];
+        for (int batch = 0; batch < 20000; ++batch) {               // batches of 6 device-side iterations
+            HIPCHK(launch_ms_iterations(w, band_sq, stop_thresh, 6, e->stream));
+            HIPCHK(hipMemcpyAsync(out, e->ms_out.p, sizeof(out), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (out[1] || out[3]) break;
+        }
+        HIPCHK(launch_ms_collect(w, e->stream));
         HIPCHK(hipMemcpyAsync(out, e->ms_out.p, sizeof(out), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(mean, e->ms_mean.p, sizeof(double) * d, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));

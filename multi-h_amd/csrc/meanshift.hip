@@ -5,70 +5,88 @@
 // quirk A-8), new mean = (sum of members) * (1/count), every member gets a vote and is marked
 // visited, stop when ||mean - old|| < 1e-3*bandwidth.  The reference allocates an N x D repmat per
 // iteration; at N = 50k (EstablishStablePointSets, M/MultiH.cpp:604-694) that inner loop is the
-// cost.  Here ONE workgroup runs a whole climb on the device: 256 threads sweep the rows strided,
-// member sums are reduced in the engine's deterministic order (thread t adds rows t, t+256, ... then
-// a binary tree), the convergence test is evaluated by every thread on the same LDS values, so no
-// host round trip happens inside a climb.  The seed order, vote merging and final assignment stay on
-// the host (they are sequential by definition, :52-56,:100-146).
+// cost.  Here an iteration is two launches that never return to the host:
+//   k_ms_partial  MS_GROUPS workgroups sweep the rows (global thread g takes rows g, g+T, g+2T, ...),
+//                 members vote, each workgroup reduces its member sums with a binary tree;
+//   k_ms_update   one wave adds the MS_GROUPS partials in order, forms the new mean, tests
+//                 convergence and raises the `done` word that turns the rest of the batch into no-ops.
+// The summation order (strided, tree inside a group, groups in sequence) is fixed — it does not
+// depend on the device — and is mirrored by the oracle (mho_mean_shift), so modes and assignments
+// are bit-identical.  The seed order, vote merging and final assignment stay on the host (they are
+// sequential by definition, :52-56,:100-146).
 #include "mh_kernels.hpp"
 
 namespace mh {
 
 constexpr int MS_MAXD = 16;
+constexpr int MS_GROUPS = 64;            // workgroups per sweep; part of the numerical definition
 
 __global__ void __launch_bounds__(256)
-k_ms_climb(MeanShiftWork w, double band_sq, double stop_thresh, int max_iters)
+k_ms_partial(MeanShiftWork w, double band_sq)
 {
+    if (w.out[1] || w.out[3]) return;                       // converged or dead end: rest of the batch idles
     const int t = threadIdx.x;
     const int D = w.d;
-    __shared__ double s_mean[MS_MAXD];
+    const int T = MS_GROUPS * 256;
     __shared__ double sv[256][MS_MAXD];
     __shared__ int sc[256];
-    if (t < D) s_mean[t] = w.mean[t];
-    __syncthreads();
-    int it = 0, converged = 0;
-    for (; it < max_iters; ++it) {
-        double acc[MS_MAXD];
-        double old[MS_MAXD];
+    double old[MS_MAXD], acc[MS_MAXD];
 #pragma unroll
-        for (int j = 0; j < MS_MAXD; ++j) { acc[j] = 0.0; old[j] = j < D ? s_mean[j] : 0.0; }
-        int cnt = 0;
-        for (int i = t; i < w.n; i += 256) {
-            const double* row = w.data + (size_t)i * D;
-            double dist = 0.0;
-            for (int j = 0; j < D; ++j) { const double r = old[j] - row[j]; dist += sqrt(r * r); }   // :78-83
-            if (dist < band_sq) {                                                                    // :85
-                for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
-                ++cnt;
-                w.votes[i] += 1;          // row i belongs to this thread only
-            }
+    for (int j = 0; j < MS_MAXD; ++j) { old[j] = j < D ? w.mean[j] : 0.0; acc[j] = 0.0; }
+    int cnt = 0;
+    for (int i = blockIdx.x * 256 + t; i < w.n; i += T) {
+        const double* row = w.data + (size_t)i * D;
+        double dist = 0.0;
+        for (int j = 0; j < D; ++j) { const double r = old[j] - row[j]; dist += sqrt(r * r); }   // :78-83
+        if (dist < band_sq) {                                                                    // :85
+            for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
+            ++cnt;
+            w.votes[i] += 1;                               // row i belongs to this thread only
         }
-        for (int j = 0; j < MS_MAXD; ++j) sv[t][j] = acc[j];
-        sc[t] = cnt;
-        __syncthreads();
-        for (int s = 128; s >= 1; s >>= 1) {
-            if (t < s) {
-                for (int j = 0; j < D; ++j) sv[t][j] = sv[t][j] + sv[t + s][j];
-                sc[t] += sc[t + s];
-            }
-            __syncthreads();
-        }
-        const int in = sc[0];
-        if (in == 0) break;               // the reference would spin on a NaN mean; end the climb
-        const double inv = 1.0 / (double)in;                          // cv::Mat / scalar (:96)
-        double move = 0.0;
-        for (int j = 0; j < D; ++j) { const double m = sv[0][j] * inv; const double dd = m - old[j]; move = move + dd * dd; }
-        __syncthreads();
-        if (t < D) s_mean[t] = sv[0][t] * inv;
-        __syncthreads();
-        if (sqrt(move) < stop_thresh) { converged = 1; ++it; break; }  // :98
     }
-    if (t < D) w.mean[t] = s_mean[t];
-    if (t == 0) { w.out[0] = it; w.out[1] = converged; }
+    for (int j = 0; j < MS_MAXD; ++j) sv[t][j] = acc[j];
+    sc[t] = cnt;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) {
+            for (int j = 0; j < D; ++j) sv[t][j] = sv[t][j] + sv[t + s][j];
+            sc[t] += sc[t + s];
+        }
+        __syncthreads();
+    }
+    if (t < D) w.partial[(size_t)blockIdx.x * MS_MAXD + t] = sv[0][t];
+    if (t == 0) w.partial_cnt[blockIdx.x] = sc[0];
 }
 
-// (index, votes) of every row touched by the climb, in index order per thread block scan is not
-// needed: the host sorts the short list.  Clears the votes for the next climb.
+__global__ void __launch_bounds__(64)
+k_ms_update(MeanShiftWork w, double stop_thresh)
+{
+    if (w.out[1] || w.out[3]) return;
+    const int j = threadIdx.x;
+    const int D = w.d;
+    __shared__ double s_move[MS_MAXD];
+    int in = 0;
+    for (int b = 0; b < MS_GROUPS; ++b) in += w.partial_cnt[b];
+    if (in == 0) { if (j == 0) w.out[3] = 1; return; }      // the reference would spin on a NaN mean
+    double m = 0.0, dd = 0.0;
+    if (j < D) {
+        double s = 0.0;
+        for (int b = 0; b < MS_GROUPS; ++b) s = s + w.partial[(size_t)b * MS_MAXD + j];
+        m = s * (1.0 / (double)in);                         // cv::Mat / scalar scales by 1/s (:96)
+        dd = m - w.mean[j];
+        s_move[j] = dd * dd;
+    }
+    __syncthreads();
+    if (j < D) w.mean[j] = m;
+    if (j == 0) {
+        double move = 0.0;
+        for (int q = 0; q < D; ++q) move = move + s_move[q];
+        w.out[0] += 1;
+        if (sqrt(move) < stop_thresh) w.out[1] = 1;         // :98
+    }
+}
+
+// (index, votes) of every row touched by the climb (the host sorts the short list); clears the votes.
 __global__ void __launch_bounds__(256)
 k_ms_collect(MeanShiftWork w)
 {
@@ -83,11 +101,14 @@ k_ms_collect(MeanShiftWork w)
     }
 }
 
-hipError_t launch_ms_climb(const MeanShiftWork& w, double band_sq, double stop_thresh, int max_iters,
-                           hipStream_t s)
+hipError_t launch_ms_iterations(const MeanShiftWork& w, double band_sq, double stop_thresh, int iterations,
+                                hipStream_t s)
 {
     if (w.d > MS_MAXD) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_ms_climb, dim3(1), dim3(256), 0, s, w, band_sq, stop_thresh, max_iters);
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(k_ms_partial, dim3(MS_GROUPS), dim3(256), 0, s, w, band_sq);
+        hipLaunchKernelGGL(k_ms_update, dim3(1), dim3(64), 0, s, w, stop_thresh);
+    }
     return hipGetLastError();
 }
 

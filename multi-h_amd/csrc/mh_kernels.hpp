@@ -78,13 +78,15 @@ struct MeanShiftWork {
     int n, d;
     double* mean;            // d   current mean (in/out)
     int* votes;              // n   votes of the running climb (members get +1 per iteration)
-    int* out;                // [0] iterations, [1] converged, [2] list length
+    int* out;                // [0] iterations, [1] converged, [2] list length, [3] dead end (no member)
     int* list;               // 2*n (index, votes) pairs compacted by launch_ms_collect
+    double* partial;         // MS_GROUPS x 16 member sums of the running iteration
+    int* partial_cnt;        // MS_GROUPS
 };
-// One whole climb from mean[] (single workgroup, iterates on the device until the mean moves less
-// than stop_thresh or max_iters); then launch_ms_collect compacts and clears the votes.
-hipError_t launch_ms_climb(const MeanShiftWork& w, double band_sq, double stop_thresh, int max_iters,
-                           hipStream_t s);
+// `iterations` climb iterations (two launches each, no host round trip); iterations after
+// convergence are no-ops.  launch_ms_collect compacts and clears the votes.
+hipError_t launch_ms_iterations(const MeanShiftWork& w, double band_sq, double stop_thresh, int iterations,
+                                hipStream_t s);
 hipError_t launch_ms_collect(const MeanShiftWork& w, hipStream_t s);
 
 // --- expand.hip -------------------------------------------------------------

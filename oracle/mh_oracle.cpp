@@ -941,16 +941,26 @@ MHO_API int mho_mean_shift(const double* data, int n, int d, double bw, unsigned
         bool converged = false;
         for (int it = 0; it < 100000; ++it) {
             const std::vector<double> old = mean;
-            TreeAcc acc(d);
+            // engine order: 64 groups x 256 strided lanes (row i -> lane i % 16384), binary tree
+            // inside each group, groups added in sequence
+            const int G = 64;
+            std::vector<TreeAcc> acc(G, TreeAcc(d));
             int in = 0;
             for (int i = 0; i < n; ++i) {
                 double dist = 0.0;
                 for (int j = 0; j < d; ++j) { const double r = old[j] - data[(size_t)i * d + j]; dist += sqrt(r * r); }
-                if (dist < band_sq) { acc.add(i, data + (size_t)i * d); ++in; ++my[i]; visited[i] = 1; }
+                if (dist < band_sq) {
+                    const int lane = i % (G * MHO_W);
+                    acc[lane / MHO_W].add(lane % MHO_W, data + (size_t)i * d);
+                    ++in; ++my[i]; visited[i] = 1;
+                }
             }
             if (in == 0) break;
-            std::vector<double> sum(d);
-            acc.finish(sum.data());
+            std::vector<double> sum(d, 0.0), part(d);
+            for (int b = 0; b < G; ++b) {
+                acc[b].finish(part.data());
+                for (int j = 0; j < d; ++j) sum[j] = sum[j] + part[j];
+            }
             const double inv = 1.0 / (double)in;
             double move = 0.0;
             for (int j = 0; j < d; ++j) { mean[j] = sum[j] * inv; const double dd = mean[j] - old[j]; move = move + dd * dd; }
