@@ -80,6 +80,37 @@ def cpu_baseline(sc, thr2: float, sample: int, seed: int):
     }, H, c1
 
 
+def labeling_extra(mh, eng, a, thr2, lam):
+    """Context for the label half of the path (not part of `value`): one LabelingStep on the GPU next
+    to the REFERENCE's own alpha-expansion (oracle/_ref: GCoptimization + BK compiled unmodified, its
+    lazy callback data cost restated) on one host core, same inputs, labels compared."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    sc = mh.synth.make_scene(a.points, a.planes, seed=a.seed)
+    eng.set_correspondences(sc.src, sc.dst, sc.aff)
+    eng.set_epipolar(sc.F, sc.e2)
+    eng.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
+    H = sc.H_true * (1.0 + np.random.default_rng(0).normal(0, 1e-4, size=sc.H_true.shape))
+    eng.set_models(H)
+    eng.labeling_step(False, np.full(sc.n, -1, np.int32))           # warm-up
+    eng.set_models(H)
+    t0 = time.perf_counter()
+    lab, energy, cycles = eng.labeling_step(False, np.full(sc.n, -1, np.int32))
+    gpu_ms = (time.perf_counter() - t0) * 1e3
+    out = {"sites": sc.n, "labels": H.shape[0] + 1, "neighbour_hits": int(sc.hit_col.size),
+           "gpu_labeling_step_ms": gpu_ms, "energy": int(energy), "cycles": int(cycles)}
+    if O.ref() is not None:
+        t0 = time.perf_counter()
+        lab_r, e_r = O.ref_expand_formula(sc.src, sc.dst, H, lam, thr2, sc.hit_rowptr, sc.hit_col)
+        out["cpu_reference_expansion_ms"] = (time.perf_counter() - t0) * 1e3
+        out["cpu_reference"] = {"kind": "reference", "cores": 1,
+                                "what": "GCoptimization::expansion of /root/reference compiled unmodified (oracle/_ref)"}
+        out["labels_identical"] = bool(np.array_equal(lab_r - 1, lab) and e_r == int(energy))
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -225,6 +256,10 @@ def main():
             eng.set_models(Hs)
             import numpy as np
             assert np.array_equal(eng.score(thr2), cs), "GPU/oracle score mismatch"
+            try:
+                out["labeling"] = labeling_extra(mh, eng, a, thr2, lam)
+            except Exception as ex:                      # context only: never lose the headline line
+                out["labeling"] = {"error": repr(ex)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
