@@ -159,6 +159,10 @@ MH_API int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows
 /* Label points with the single model idx where inlier (ComputeInliersOfHomography,
  * M/MultiH.cpp:743-768): labels[i] = label_value if d2 < thr2, else unchanged. */
 MH_API int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int* labels /* in/out n */);
+/* Same labelling for a homography that is NOT in the resident model set (row-major H[9]); the
+ * model set is left untouched.  Used by the sharded propose stage, where the winning hypothesis
+ * of a round may live on another rank. */
+MH_API int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int label_value, int* labels /* in/out n */);
 /* Per-model inlier moments {n, Sx, Sy, Sxx, Sxy, Syy} and smallest eigenvalue of the 3x3
  * scatter — the collinearity test of MergingStep (M/MultiH.cpp:446-463). */
 MH_API int mh_inlier_moments(mh_engine* e, double thr2, double* moments /* m x 6 */, double* min_eig /* m */);

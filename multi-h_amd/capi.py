@@ -26,7 +26,7 @@ SYMBOLS = [
     "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
-    "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
@@ -273,6 +273,13 @@ class Engine:
         labels = _i32(labels).copy()
         self._check(self.lib.mh_inliers_of_model(self._h, int(idx), C.c_double(thr2), int(label_value),
                                                  _p(labels, C.c_int)))
+        return labels
+
+    def inliers_of_homography(self, H, thr2: float, label_value: int, labels):
+        labels = _i32(labels).copy()
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+        self._check(self.lib.mh_inliers_of_homography(self._h, _p(H, C.c_double), C.c_double(thr2), int(label_value),
+                                                      _p(labels, C.c_int)))
         return labels
 
     def inlier_moments(self, thr2: float):

@@ -71,7 +71,7 @@ struct mh_engine {
     // model set
     int m = 0;
     bool have_samples = false;
-    DevBuf<double> H;
+    DevBuf<double> H, H_one;
     DevBuf<int> samples, counts;
     DevBuf<double> R;
     long long ldr = 0;
@@ -917,6 +917,21 @@ int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int
     HIPCHK(e->labels_pts.reserve(e->n));
     HIPCHK(hipMemcpyAsync(e->labels_pts.p, labels, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
     HIPCHK(launch_inliers_of_model(e->pts(), e->H.p, idx, thr2, label_value, e->labels_pts.p, e->stream));
+    HIPCHK(hipMemcpyAsync(labels, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+}
+
+int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int label_value, int* labels)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!H || !labels) return fail(MH_ERR_INVALID, "null homography or labels");
+    HIPCHK(e->H_one.reserve(9));
+    HIPCHK(e->labels_pts.reserve(e->n));
+    HIPCHK(hipMemcpyAsync(e->H_one.p, H, sizeof(double) * 9, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->labels_pts.p, labels, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(launch_inliers_of_model(e->pts(), e->H_one.p, 0, thr2, label_value, e->labels_pts.p, e->stream));
     HIPCHK(hipMemcpyAsync(labels, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;

@@ -35,35 +35,45 @@ __device__ __forceinline__ double fwd_d2(double h0, double h1, double h2, double
 //     passes the quotient through.  The sequence below issues exactly the remaining rounded
 //     operations, so its result is bit-identical to `n / s`.
 //   * n == +-0 gives +-0 on both paths (the sign of a zero quotient cannot reach d2).
-// What is NOT covered by the window is detected without looking at the numerators:
-//   * s outside the window                         -> `s_ok` false (2 integer ops);
-//   * |n| >= 2^768, n = inf/NaN                    -> |u| >= 2^511 or NaN, hence d2 is NaN, inf or
-//                                                     >= 2^1000: caught by !(d2 < 2^1000);
+// The preconditions are split so that the per-pair cost is ONE compare on s:
+//   * |s| < 2^257 and |n| < 2^768, both finite     -> guaranteed by |h_i| < 2^120 for the MODEL
+//                                                     (`model_pre`, once per workgroup) and
+//                                                     |x|,|y| < 2^120 for the POINT (`point_pre`,
+//                                                     once per tile): |s|, |n| < 3 * 2^240;
+//   * |s| >= 2^-255 (and s not NaN)                -> the per-pair v_cmp_f64 with the |.| modifier;
 //   * 0 < |n| < 2^-766 (incl. denormals)           -> |u| < 2^-510 on BOTH paths; x2 - u rounds to
-//                                                     x2 on both unless |x2| < 2^-450, which is a
-//                                                     per-POINT property checked once per tile
-//                                                     (`pt_ok`, hoisted out of the model loop).
+//                                                     x2 on both unless |x2| < 2^-450, a per-POINT
+//                                                     property folded into `point_pre` (which also
+//                                                     rejects inf/NaN targets).
 // Any lane failing a check recomputes the pair with the compiler's full IEEE division.
 // ---------------------------------------------------------------------------
 
-// true iff the biased exponent of v lies in [768, 1279]  (unbiased [-255, 256])
-__device__ __forceinline__ bool exp_in_window(double v)
+__device__ __forceinline__ unsigned int abs_hi(double v) { return (unsigned int)__double2hiint(v) & 0x7fffffffu; }
+
+// |v| < 2^120 and not NaN/inf
+__device__ __forceinline__ bool mag_bounded(double v) { return abs_hi(v) < ((1023u + 120u) << 20); }
+
+// 2^-450 <= |v| < 2^120
+__device__ __forceinline__ bool mag_mid(double v) { return (abs_hi(v) - ((1023u - 450u) << 20)) < (570u << 20); }
+
+// per-point precondition: source (x, y) bounded, target (x2, y2) neither tiny nor huge
+__device__ __forceinline__ bool point_pre(double x, double y, double x2, double y2)
 {
-    const unsigned int h = (unsigned int)__double2hiint(v);
-    return ((h << 1) - (768u << 21)) < 0x40000000u;
+    return mag_bounded(x) && mag_bounded(y) && mag_mid(x2) && mag_mid(y2);
 }
 
-// true iff |v| >= 2^-450 and finite-or-anything-large (only smallness matters for pt_ok)
-__device__ __forceinline__ bool not_tiny(double v)
+// per-model precondition: all nine coefficients bounded
+__device__ __forceinline__ bool model_pre(const double* h)
 {
-    const unsigned int h = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-    return h >= ((1023u - 450u) << 20);
+    bool ok = true;
+    for (int i = 0; i < 9; ++i) ok = ok && mag_bounded(h[i]);
+    return ok;
 }
 
 __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, double h3,
                                               double h4, double h5, double h6, double h7,
                                               double h8, double x, double y, double x2, double y2,
-                                              bool pt_ok)
+                                              bool pre_ok)
 {
     const double s = h6 * x + h7 * y + h8;
     const double nx = h0 * x + h1 * y + h2;
@@ -82,8 +92,8 @@ __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, d
     const double dx = x2 - u;
     const double dy = y2 - v;
     double d2 = dx * dx + dy * dy;
-    // bitwise, not short-circuit: three lane masks and-ed on the scalar unit, one branch
-    const int ok = (int)pt_ok & (int)exp_in_window(s) & (int)(d2 < 0x1p1000);
+    // bitwise, not short-circuit: two lane masks and-ed on the scalar unit, one branch
+    const int ok = (int)pre_ok & (int)(__builtin_fabs(s) >= 0x1p-255);
     if (__builtin_expect(!ok, 0)) {
         // The empty volatile asm keeps hipcc from if-converting this branch into
         // "compute both and select", which would put the IEEE sequence back on the hot path.

@@ -56,18 +56,22 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
         const size_t g = (size_t)m0 * 9 + i;
         s_h[i] = (g < (size_t)M * 9) ? H[g] : 0.0;
     }
+    __shared__ int s_hok[MC];                   // per-model precondition of the shared-reciprocal division
+    __shared__ int s_aok[SYM ? MC : 1];
     __syncthreads();
-    if (SYM) {
-        // H^-1 up to scale = adjugate; each entry is (mul, mul, sub), rounded once per operation
-        if (threadIdx.x < MC) {
-            const double* h = s_h + 9 * threadIdx.x;
+    if (threadIdx.x < MC) {
+        const double* h = s_h + 9 * threadIdx.x;
+        s_hok[threadIdx.x] = model_pre(h);
+        if (SYM) {
+            // H^-1 up to scale = adjugate; each entry is (mul, mul, sub), rounded once per operation
             double* a = s_a + 9 * threadIdx.x;
             a[0] = h[4] * h[8] - h[5] * h[7]; a[1] = h[2] * h[7] - h[1] * h[8]; a[2] = h[1] * h[5] - h[2] * h[4];
             a[3] = h[5] * h[6] - h[3] * h[8]; a[4] = h[0] * h[8] - h[2] * h[6]; a[5] = h[2] * h[3] - h[0] * h[5];
             a[6] = h[3] * h[7] - h[4] * h[6]; a[7] = h[1] * h[6] - h[0] * h[7]; a[8] = h[0] * h[4] - h[1] * h[3];
+            s_aok[threadIdx.x] = model_pre(a);
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     int cnt = 0;                                // lane mi of each wave counts model m0+mi
     static_assert(MC <= 64, "one counting lane per model");
@@ -75,6 +79,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
         double px[PPL], py[PPL], qx[PPL], qy[PPL];
         bool ok[PPL], pok[PPL], pokb[SYM ? PPL : 1];
+        unsigned long long okm[PPL];            // ok[] as wave masks: the inlier ballot is (d2 < thr2) & okm
         const int wbase = base + wave * WAVE_PTS;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -91,23 +96,25 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                 ok[2 * c] = true; ok[2 * c + 1] = true;
             } else if (n < N) {
                 px[2 * c] = x1[n]; py[2 * c] = y1[n]; qx[2 * c] = x2[n]; qy[2 * c] = y2[n];
-                px[2 * c + 1] = 0.0; py[2 * c + 1] = 0.0; qx[2 * c + 1] = 0.0; qy[2 * c + 1] = 0.0;
+                px[2 * c + 1] = 1.0; py[2 * c + 1] = 1.0; qx[2 * c + 1] = 1.0; qy[2 * c + 1] = 1.0;   // padding stays on the fast path
                 ok[2 * c] = true; ok[2 * c + 1] = false;
             } else {
-                px[2 * c] = 0.0; py[2 * c] = 0.0; qx[2 * c] = 0.0; qy[2 * c] = 0.0;
-                px[2 * c + 1] = 0.0; py[2 * c + 1] = 0.0; qx[2 * c + 1] = 0.0; qy[2 * c + 1] = 0.0;
+                px[2 * c] = 1.0; py[2 * c] = 1.0; qx[2 * c] = 1.0; qy[2 * c] = 1.0;
+                px[2 * c + 1] = 1.0; py[2 * c + 1] = 1.0; qx[2 * c + 1] = 1.0; qy[2 * c + 1] = 1.0;
                 ok[2 * c] = false; ok[2 * c + 1] = false;
             }
             if (MASK) {
                 if (ok[2 * c]) ok[2 * c] = mask[n] != 0;
                 if (ok[2 * c + 1]) ok[2 * c + 1] = mask[n + 1] != 0;
             }
+            okm[2 * c] = __builtin_amdgcn_ballot_w64(ok[2 * c]);
+            okm[2 * c + 1] = __builtin_amdgcn_ballot_w64(ok[2 * c + 1]);
             // per-point precondition of the shared-reciprocal division (see mh_device.hpp)
-            pok[2 * c] = not_tiny(qx[2 * c]) && not_tiny(qy[2 * c]);
-            pok[2 * c + 1] = not_tiny(qx[2 * c + 1]) && not_tiny(qy[2 * c + 1]);
+            pok[2 * c] = point_pre(px[2 * c], py[2 * c], qx[2 * c], qy[2 * c]);
+            pok[2 * c + 1] = point_pre(px[2 * c + 1], py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
             if (SYM) {
-                pokb[2 * c] = not_tiny(px[2 * c]) && not_tiny(py[2 * c]);
-                pokb[2 * c + 1] = not_tiny(px[2 * c + 1]) && not_tiny(py[2 * c + 1]);
+                pokb[2 * c] = point_pre(qx[2 * c], qy[2 * c], px[2 * c], py[2 * c]);
+                pokb[2 * c + 1] = point_pre(qx[2 * c + 1], qy[2 * c + 1], px[2 * c + 1], py[2 * c + 1]);
             }
         }
 
@@ -122,6 +129,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                 const double* h = HSGPR ? (H + 9 * (size_t)m) : (s_h + 9 * mi);
                 const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5],
                              h6 = h[6], h7 = h[7], h8 = h[8];
+                const bool hok = s_hok[mi] != 0;           // wave-uniform
+                const bool aok = SYM ? (s_aok[mi] != 0) : false;
                 int c_m = 0;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
@@ -134,21 +143,21 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                     }
                     double d0s, d1s;
                     const double d0 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
-                                                         py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c])
+                                                         py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c] && hok)
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
                                                     py[2 * c], qx[2 * c], qy[2 * c]);
                     const double d1 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
-                                                         py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1])
+                                                         py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1] && hok)
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
                                                     py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
                     d0s = d0; d1s = d1;
                     if (SYM) {       // + ||H^-1 p2 - p1||^2 (north_star's symmetric transfer; no reference oracle)
                         const double* a = s_a + 9 * mi;
                         const double b0 = fwd_d2_fast(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
-                                                      qx[2 * c], qy[2 * c], px[2 * c], py[2 * c], pokb[2 * c]);
+                                                      qx[2 * c], qy[2 * c], px[2 * c], py[2 * c], pokb[2 * c] && aok);
                         const double b1 = fwd_d2_fast(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
                                                       qx[2 * c + 1], qy[2 * c + 1], px[2 * c + 1], py[2 * c + 1],
-                                                      pokb[2 * c + 1]);
+                                                      pokb[2 * c + 1] && aok);
                         d0s = d0 + b0;
                         d1s = d1 + b1;
                     }
@@ -166,8 +175,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                             dstp[0] = d0s;
                         }
                     }
-                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c] && d0s < thr2));
-                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[2 * c + 1] && d1s < thr2));
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0s < thr2) & okm[2 * c]);
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1s < thr2) & okm[2 * c + 1]);
                 }
                 cnt += (lane == mi) ? c_m : 0;
             }

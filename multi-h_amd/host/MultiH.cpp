@@ -319,6 +319,7 @@ bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models
     const int N = static_cast<int>(src_points.size());
     const int need = std::max(minimum_inlier_number, 8);
     if (M <= 0 || max_models <= 0) return true;
+    if (shard_world > 1) return ProposeModelsSharded(seed, first, M, max_models, mask);
     if (!Check(mh_propose_dlt4(engine, seed, first, M), "mh_propose_dlt4")) return false;
     std::vector<double> H(9 * (size_t)M);
     if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
@@ -336,6 +337,70 @@ bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models
         std::fill(lab.begin(), lab.end(), -1);
         if (!Check(mh_inliers_of_model(engine, best, sqr_threshold_homography, 0, lab.data()),
                    "mh_inliers_of_model"))
+            return false;
+        for (int i = 0; i < N; ++i) if (lab[i] == 0) mask[i] = 0;
+        any_masked = true;
+    }
+    return true;
+}
+
+void MultiH::SetSharding(int rank, int world, AllGatherFn fn, void* ctx)
+{
+    if (world <= 1 || !fn || rank < 0 || rank >= world) {
+        shard_rank = 0; shard_world = 1; shard_allgather = nullptr; shard_ctx = nullptr;
+        return;
+    }
+    shard_rank = rank; shard_world = world; shard_allgather = fn; shard_ctx = ctx;
+}
+
+// The same greedy selection over a batch whose hypotheses are spread over the ranks: rank r owns
+// counters [first + off_r, first + off_r + m_r).  Selection order is the single-GPU one (highest
+// score, lowest global counter on ties), so world sizes 1..G give identical model lists.
+bool MultiH::ProposeModelsSharded(uint64_t seed, long long first, int M, int max_models,
+                                  std::vector<unsigned char>& mask)
+{
+    const int N = static_cast<int>(src_points.size());
+    const int need = std::max(minimum_inlier_number, 8);
+    const int W = shard_world, base = M / W, rem = M % W;
+    const int longest = base + (rem ? 1 : 0);
+    auto size_of = [&](int r) { return base + (r < rem ? 1 : 0); };
+    const int mine = size_of(shard_rank);
+    const long long off = (long long)shard_rank * base + std::min(shard_rank, rem);
+
+    std::vector<double> H(9 * (size_t)std::max(mine, 1), 0.0);
+    if (mine > 0) {
+        if (!Check(mh_propose_dlt4(engine, seed, first + off, mine), "mh_propose_dlt4")) return false;
+        if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
+    }
+    std::vector<int> local(longest, -1), all((size_t)W * longest), lab(N);
+    std::vector<double> all_H(9 * (size_t)W);
+    bool any_masked = false;
+    for (unsigned char m : mask) any_masked = any_masked || (m == 0);
+    for (int round = 0; round < max_models; ++round) {
+        if (mine > 0 &&
+            !Check(mh_score(engine, sqr_threshold_homography, any_masked ? mask.data() : nullptr, local.data()),
+                   "mh_score"))
+            return false;
+        if (shard_allgather(shard_ctx, local.data(), all.data(), sizeof(int) * (size_t)longest) != 0) {
+            std::cerr << "Error: score all-gather failed" << std::endl;
+            return false;
+        }
+        int best_rank = -1, best_count = -1;
+        for (int r = 0; r < W; ++r)
+            for (int j = 0; j < size_of(r); ++j)
+                if (all[(size_t)r * longest + j] > best_count) { best_count = all[(size_t)r * longest + j]; best_rank = r; }
+        if (best_rank < 0 || best_count < need) break;
+        // every rank offers the first maximum of its own shard; the owner's is the global one
+        const int my_best = mine > 0 ? static_cast<int>(std::max_element(local.begin(), local.begin() + mine) - local.begin()) : 0;
+        if (shard_allgather(shard_ctx, &H[9 * (size_t)my_best], all_H.data(), sizeof(double) * 9) != 0) {
+            std::cerr << "Error: model all-gather failed" << std::endl;
+            return false;
+        }
+        const double* Hb = &all_H[9 * (size_t)best_rank];
+        cluster_homographies.push_back(MatFrom9(Hb));
+        std::fill(lab.begin(), lab.end(), -1);
+        if (!Check(mh_inliers_of_homography(engine, Hb, sqr_threshold_homography, 0, lab.data()),
+                   "mh_inliers_of_homography"))
             return false;
         for (int i = 0; i < N; ++i) if (lab[i] == 0) mask[i] = 0;
         any_masked = true;
@@ -498,6 +563,20 @@ void MultiH::HandleDegenerateCase()
     cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)best]));
 }
 
+// Sharding for the next mhh_run_process call of this process (one process per GPU).
+static int g_shard_rank = 0, g_shard_world = 1;
+static MultiH::AllGatherFn g_shard_fn = nullptr;
+static void* g_shard_ctx = nullptr;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_sharding(int rank, int world, int (*fn)(void*, const void*, void*, size_t), void* ctx)
+{
+    g_shard_rank = rank; g_shard_world = world; g_shard_fn = fn; g_shard_ctx = ctx;
+}
+
+static int g_device = 0;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_device(int device) { g_device = device; }
+
 // ---- C hook for the GPU-side integration test (ctypes; plain arrays in/out) ----------------
 extern "C" __attribute__((visibility("default")))
 int mhh_run_process(const double* src_xy, const double* dst_xy, const double* aff, int n,
@@ -519,6 +598,8 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetProposal(seed, hypotheses, max_models);
     mh.SetFixedIterations(fixed_iterations);
     mh.SetIterativeProposal(iter_hypotheses, iter_max_new < 0 ? 4 : iter_max_new);
+    mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
+    mh.SetDevice(g_device);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init
     if (init_H && n_init > 0) {
         std::vector<cv::Mat> hs;

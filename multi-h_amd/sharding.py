@@ -13,6 +13,9 @@ the engine's kernel (or, in the CPU tests only, the oracle standing in for it).
 """
 from __future__ import annotations
 
+import ctypes
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -69,3 +72,38 @@ def global_model_index(flat_index: int, sizes: list[int]) -> tuple[int, int]:
         flat_index -= sizes[r]
         r += 1
     return r, flat_index
+
+
+# Transport hook of the host class (MultiH::SetSharding, multi-h_amd/host/MultiH.h): the C++ side
+# hands over host buffers; the exchange itself is torch.distributed's all-gather — RCCL when the
+# process group is "nccl" (staged through a device tensor, 4*M/G bytes per rank, latency-bound),
+# gloo in the tests.
+ALLGATHER_CFUNC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+def make_allgather_hook(world: int, device: torch.device | None = None, group=None):
+    """ctypes callback for mhh_set_sharding / MultiH::SetSharding.  `device` = the rank's GPU for an
+    nccl group (None: exchange host tensors directly, gloo).  Keep the returned object alive for as
+    long as the host library may call it."""
+    stats = {"calls": 0, "bytes": 0}
+
+    def hook(_ctx, send, recv, nbytes):
+        try:
+            src = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(send))
+            dst = np.ctypeslib.as_array((ctypes.c_uint8 * (nbytes * world)).from_address(recv))
+            if device is None:
+                dist.all_gather_into_tensor(torch.from_numpy(dst), torch.from_numpy(src), group=group)
+            else:
+                out = torch.empty(nbytes * world, dtype=torch.uint8, device=device)
+                dist.all_gather_into_tensor(out, torch.from_numpy(src).to(device), group=group)
+                dst[:] = out.cpu().numpy()
+            stats["calls"] += 1
+            stats["bytes"] += nbytes * world
+            return 0
+        except Exception as exc:  # never let an exception cross the C boundary
+            print(f"[multi-h sharding] all-gather failed: {exc!r}", flush=True)
+            return 1
+
+    cb = ALLGATHER_CFUNC(hook)
+    cb.stats = stats
+    return cb

@@ -255,6 +255,48 @@ def test_fp64_division_and_sqrt_are_ieee(engine, synth, oracle):
     assert np.array_equal(R[~nan].view(np.uint64), R_ref[~nan].view(np.uint64))
 
 
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_shared_reciprocal_precondition_boundaries(engine, oracle, symmetric):
+    """The residual sweep replaces the two IEEE divisions by one shared reciprocal when per-model,
+    per-point and per-pair preconditions hold (csrc/mh_device.hpp) and falls back to the full
+    division otherwise.  Sit exactly on those boundaries — coefficients and coordinates around
+    2^120, targets around 2^-450, denominators around 2^-255 — and demand the oracle's bits on
+    both sides of each of them."""
+    rng = np.random.default_rng(4242)
+    n, m = 2048, 192
+    pe = np.array([-460, -451, -450, -449, -300, -20, 0, 0, 0, 7, 10, 118, 119, 120, 121, 300])
+    src = rng.uniform(1.0, 2.0, size=(n, 2)) * np.exp2(rng.choice(pe, size=(n, 2)).astype(np.float64))
+    dst = rng.uniform(1.0, 2.0, size=(n, 2)) * np.exp2(rng.choice(pe, size=(n, 2)).astype(np.float64))
+    src *= rng.choice([-1.0, 1.0], size=src.shape)
+    dst *= rng.choice([-1.0, 1.0], size=dst.shape)
+    src[:64] = rng.uniform(0, 1000, size=(64, 2)); dst[:64] = rng.uniform(0, 1000, size=(64, 2))   # ordinary pixels
+    src[64:72] = 0.0; dst[72:80] = 0.0
+    he = np.array([-300, -256, -255, -254, -60, -3, 0, 0, 0, 5, 60, 119, 120, 121, 256, 257, 258])
+    H = rng.normal(size=(m, 9)) * np.exp2(rng.choice(he, size=(m, 9)).astype(np.float64))
+    # denominators straddling 2^-255: s = h8 exactly (h6 = h7 = 0), |h8| = 2^-255 * {1-eps, 1, 1+eps}
+    for i, f in enumerate((1.0 - 2.0 ** -53, 1.0, 1.0 + 2.0 ** -52, -1.0, 2.0 ** -1, 2.0)):
+        H[i] = [1e-250, 0, 3e-252, 0, 1e-250, -2e-251, 0, 0, f * 2.0 ** -255]
+    H[8] = [1, 0, 0, 0, 1, 0, 0, 0, np.inf]
+    H[9] = [1, 0, 0, 0, np.nan, 0, 0, 0, 1]
+    engine.set_correspondences(src, dst)
+    engine.set_models(H)
+    engine.set_residual_mode(symmetric)
+    try:
+        with np.errstate(all="ignore"):
+            R, cnt = engine.residual_matrix(THR2)
+            R_ref = (oracle.residual_matrix_sym if symmetric else oracle.residual_matrix)(src, dst, H)
+            cnt2 = engine.score(THR2)
+    finally:
+        engine.set_residual_mode(False)
+    nan = np.isnan(R_ref)
+    assert np.array_equal(np.isnan(R), nan)
+    assert np.array_equal(R[~nan].view(np.uint64), R_ref[~nan].view(np.uint64))
+    with np.errstate(all="ignore"):
+        ref_cnt = (R_ref < THR2).sum(axis=1)
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(cnt2, ref_cnt)
+    assert 0.05 < np.isfinite(R_ref).mean() < 0.9999 and ref_cnt.sum() > 0     # both regimes present
+
+
 # ---- committed golden fixtures (labels pinned by the reference's own GCO build) -------------
 import os  # noqa: E402
 

@@ -89,3 +89,45 @@ def test_shard_arithmetic(mh):
         f, c = sh.shard_range(1000, 7, r)
         covered += list(range(f, f + c))
     assert covered == list(range(1000))
+
+
+def _hook_worker(rank, world, port, q):
+    import ctypes
+    sys.path.insert(0, ROOT)
+    sh = importlib.import_module("multi-h_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hook = sh.make_allgather_hook(world)
+        out = []
+        for n in (5, 9):          # int32 scores, then the 72-byte model record
+            send = (np.arange(n, dtype=np.int32) + 1000 * rank) if n == 5 else np.full(9, rank + 0.5)
+            recv = np.zeros(world * send.size, dtype=send.dtype)
+            rc = hook(None, send.ctypes.data_as(ctypes.c_void_p), recv.ctypes.data_as(ctypes.c_void_p), send.nbytes)
+            out.append((rc, recv.copy()))
+        q.put((rank, out, dict(hook.stats)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_hook_of_the_host_class(mh):
+    """The transport MultiH::SetSharding calls (multi-h_amd/host/MultiH.h): host buffers in, rank-ordered
+    concatenation out, status 0."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hook_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, stats in results:
+        (rc1, scores), (rc2, models) = out
+        assert rc1 == 0 and rc2 == 0 and stats["calls"] == 2
+        assert np.array_equal(scores, np.concatenate([np.arange(5, dtype=np.int32) + 1000 * r for r in range(world)]))
+        assert np.array_equal(models, np.concatenate([np.full(9, r + 0.5) for r in range(world)]))

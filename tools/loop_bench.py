@@ -1,8 +1,17 @@
 #!/usr/bin/env python3
-"""BASELINE configs[4]-style run on ONE GPU: the full propose -> {merge, label, re-estimate} loop
-through the host class MultiH (libmultih_host.so) with a fixed number of iterations.
-Prints wall time of the loop and label agreement with the synthetic ground truth."""
-import ctypes as C, importlib, os, sys, time
+"""BASELINE configs[4]: the full propose -> {merge, label, re-estimate} loop through the host class
+MultiH (libmultih_host.so) with a fixed number of iterations, on 1..G GPUs of one node.
+
+  python tools/loop_bench.py                                   # one GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 \
+         --master-port 29511 tools/loop_bench.py               # one process per GPU
+
+Multi-GPU: the propose stage shards (each rank owns M/G hypotheses of every batch; all-gather of
+the int32 scores per greedy round); labeling and re-estimation run replicated and
+deterministic.  Every rank must end with the same labels — checked here — and the result must not
+depend on G.  Env: N K ITERS HYP ITER_HYP; LOOP_BACKEND=gloo LOOP_DEVICE=0 put several ranks on one
+GPU (the parity test's setup)."""
+import ctypes as C, hashlib, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +19,25 @@ mh = importlib.import_module("multi-h_amd")
 N, K = int(os.environ.get("N", 50000)), int(os.environ.get("K", 10))
 ITERS, HYP = int(os.environ.get("ITERS", 20)), int(os.environ.get("HYP", 100000))
 ITER_HYP = int(os.environ.get("ITER_HYP", 0))
+rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+local_rank = int(os.environ.get("LOCAL_RANK", 0))
+device = int(os.environ.get("LOOP_DEVICE", local_rank))
+if world > 1:
+    # torch before the engine: the library then binds to the HIP runtime torch has already loaded
+    # (one runtime per process; loaded the other way round the second copy finds no device)
+    import torch, torch.distributed as dist
 host = C.CDLL(os.path.join(ROOT, "multi-h_amd", "libmultih_host.so"))
+host.mhh_set_device(device)
+hook = None
+if world > 1:
+    backend = os.environ.get("LOOP_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(device)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    sharding = importlib.import_module("multi-h_amd.sharding")
+    hook = sharding.make_allgather_hook(world, torch.device("cuda", device) if backend == "nccl" else None)
+    host.mhh_set_sharding(rank, world, hook, None)
+    dist.barrier()
 sc = mh.synth.make_scene(N, K, seed=1234, with_neighbours=False)
 dp = C.POINTER(C.c_double)
 labels = np.full(N, -7, dtype=np.int32); Hout = np.zeros((256, 9))
@@ -23,10 +50,24 @@ k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.cty
                          None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256,
                          C.byref(it), C.byref(en), C.byref(secs), ITER_HYP, 4)
 wall = time.time() - t0
+digest = hashlib.sha256(labels.tobytes() + Hout[:max(k, 0)].tobytes()).hexdigest()[:16]
+same = True
+if world > 1:
+    walls = [None] * world; digs = [None] * world
+    dist.all_gather_object(walls, wall); dist.all_gather_object(digs, digest)
+    wall = max(walls); same = len(set(digs)) == 1
 agree = 0
 for p in range(K):
     lp = labels[sc.gt_label == p]; lp = lp[lp >= 0]
     if lp.size: agree += np.bincount(lp).max()
-print(f"N={N} planes={K} hypotheses={HYP}: clusters={k} iterations={it.value} energy={en.value:.0f} "
-      f"loop={secs.value:.2f}s total={wall:.2f}s  inlier-agreement={agree/(sc.gt_label>=0).sum():.3f} "
-      f"outliers labelled -1: {(labels[sc.gt_label<0]==-1).mean():.3f}")
+if rank == 0:
+    print(f"N={N} planes={K} hypotheses={HYP} gpus={world}: clusters={k} iterations={it.value} energy={en.value:.0f} "
+          f"loop={secs.value:.2f}s total={wall:.2f}s  inlier-agreement={agree/(sc.gt_label>=0).sum():.3f} "
+          f"outliers labelled -1: {(labels[sc.gt_label<0]==-1).mean():.3f}")
+    print(json.dumps({"workload": "full_loop", "points": N, "planes": K, "hypotheses": HYP, "iterations": it.value,
+                      "iter_hypotheses": ITER_HYP, "n_gpus": world, "clusters": k, "energy": en.value,
+                      "loop_s": secs.value, "total_s": wall, "digest": digest, "ranks_identical": same,
+                      "exchanges": hook.stats["calls"] if hook else 0}))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if (k >= 0 and same) else 1)
