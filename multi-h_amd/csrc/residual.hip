@@ -178,7 +178,9 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                     c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0s < thr2) & okm[2 * c]);
                     c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1s < thr2) & okm[2 * c + 1]);
                 }
-                cnt += (lane == mi) ? c_m : 0;
+                // lane mi accumulates model mi: read-modify-write of that one lane through the scalar unit
+                const int c_new = __builtin_amdgcn_readlane(cnt, mi) + c_m;
+                asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(c_new), "s"(mi) : "m0");
             }
         }
     }
@@ -209,6 +211,11 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         psplit = (2048 + gx - 1) / gx;
         if (psplit > ntiles) psplit = ntiles;
         if (psplit < 1) psplit = 1;
+    } else if (ntiles >= 32) {
+        // many models and a long sweep: a workgroup that walks all N points runs for milliseconds and
+        // the last round of workgroups leaves CUs idle; four shorter slices per model block trim
+        // that tail (measured 7.95 -> 7.79 ms at 50k x 100k, tools/kernel_sweep.py RV=104)
+        psplit = 4;
     }
     if (force_psplit > 0) psplit = force_psplit < ntiles ? force_psplit : ntiles;
     if (psplit > 1) {
@@ -238,6 +245,8 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // MC 8
     case 6: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // MC 32
     case 7: return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);    // store-only calibration
+    case 8: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 8
+    case 9: return launch_rs<6, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 6
     default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);               // PPL 4, MC 16, plain 16-B stores
     }
 }
