@@ -72,7 +72,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "multih_hip.h"))
     cxx = os.environ.get("CXX", "g++")
-    flags = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-I" + os.path.join(ROOT, "include"),
+    flags = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-Wall", "-I" + os.path.join(ROOT, "include"),
              "-I" + HOST]
     if force or _newer(HOST_LIB, srcs + hdrs + [LIB]):
         if verbose:

@@ -2,8 +2,11 @@
 #include "merge_step.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 namespace multih {
 
@@ -381,8 +384,146 @@ bool Homography3PT(const double* pts1, const double* pts2, int n, const double F
 }
 
 // ---- HomographyCompatibilityCheck ----------------------------------------------------------
+// What the reference does per cluster (M/MultiH.cpp:128-196), and what its trial loop reduces to:
+//   * each trial erases 3 randomly indexed points from the cluster's vectors (:140-151) and appends
+//     them again at the end (:180-189) — only the ORDER of the points carries over between trials;
+//   * the distance buffer has N entries of which the trial rewrites the first N-3 (:158-173), then
+//     sorts all N (:175): the last three hold the three largest values of the previous trial's
+//     sorted buffer.  So trial t sees  new_t (N-3 values)  U  stale_t (3 values)  with
+//     stale_0 = {0,0,0} and stale_{t+1} = top3(new_t U stale_t);
+//   * its "median" is element rest/2 of that sorted buffer, or the mean of elements rest/2 and
+//     rest/2+1 when rest = N-3 is even (:176).
+// Hence: (1) replay the index shuffling alone (sequential, integers only); (2) per trial, on all
+// host cores, fit the 3-point homography and take from new_t only what the result can depend on —
+// the order statistics of ranks rest/2-3 .. rest/2+1 and the three largest values — with
+// std::nth_element instead of a full sort; (3) thread the three stale values through the trials.
+// Elements of new_t below rank rest/2-3 are <= everything kept and elements above rank rest/2+1 are
+// >= everything kept, so ranks rest/2 and rest/2+1 of the union are ranks 3 and 4 of the eight
+// kept values (five order statistics + three stale).
+namespace {
+
+struct TrialStats {
+    double mid[5];      // order statistics of new_t at ranks k-3 .. k+1 (k = rest/2)
+    double top[3];      // three largest values of new_t, ascending
+};
+
+// Squared transfer errors of the N-3 points trial `tri` did not draw (:154-173); NaN -> 1e300.
+void TrialDistances(const std::vector<double>& sx, const std::vector<double>& dx, const int* tri,
+                    const double F[9], double* dist)
+{
+    const int N = (int)(sx.size() / 2);
+    double ms[6], md[6];
+    for (int j = 0; j < 3; ++j) {
+        ms[2 * j] = sx[2 * tri[j]]; ms[2 * j + 1] = sx[2 * tri[j] + 1];
+        md[2 * j] = dx[2 * tri[j]]; md[2 * j + 1] = dx[2 * tri[j] + 1];
+    }
+    double Hc[9];
+    const bool ok = Homography3PTLinear(ms, md, 3, F, Hc);                    // do_numerical_refinement = false, :154
+    int w = 0;
+    for (int i = 0; i < N; ++i) {
+        if (i == tri[0] || i == tri[1] || i == tri[2]) continue;
+        double d2 = std::nan("");
+        if (ok) {
+            const double ox = sx[2 * i], oy = sx[2 * i + 1];
+            const double ss = Hc[6] * ox + Hc[7] * oy + Hc[8];
+            const double x1 = (Hc[0] * ox + Hc[1] * oy + Hc[2]) / ss;
+            const double y1 = (Hc[3] * ox + Hc[4] * oy + Hc[5]) / ss;
+            const double ddx = dx[2 * i] - x1, ddy = dx[2 * i + 1] - y1;
+            d2 = ddx * ddx + ddy * ddy;
+        }
+        dist[w++] = std::isnan(d2) ? 1e300 : d2;
+    }
+}
+
+void TrialSelect(std::vector<double>& dist, TrialStats& out)
+{
+    const int rest = (int)dist.size();
+    const int k = rest / 2;
+    const int lo = k - 3, hi = k + 1;                  // caller guarantees lo >= 0 and hi + 3 < rest
+    std::nth_element(dist.begin(), dist.begin() + lo, dist.end());
+    std::partial_sort(dist.begin() + lo + 1, dist.begin() + hi + 1, dist.end());
+    for (int j = 0; j < 5; ++j) out.mid[j] = dist[lo + j];
+    // everything from hi+1 on is >= dist[hi]; its three largest are the three largest overall
+    std::partial_sort(dist.begin() + hi + 1, dist.begin() + hi + 4, dist.end(), std::greater<double>());
+    out.top[0] = dist[hi + 3]; out.top[1] = dist[hi + 2]; out.top[2] = dist[hi + 1];
+}
+
+// Median-of-medians of one cluster (:128-194).  sx/dx: the cluster's points (x,y pairs) in label order.
+double ClusterMedian(const std::vector<double>& sx, const std::vector<double>& dx, const double F[9],
+                     uint64_t seed, uint64_t& counter)
+{
+    const int trials = 501;                                    // MAX(501, MIN(501, ...)), :128
+    const int N = (int)(sx.size() / 2);
+    const int rest = N - 3;
+    std::vector<double> distances(trials);
+
+    // (1) which three points each trial draws: positions in the current order, erased one by one
+    std::vector<int> order(N);
+    for (int i = 0; i < N; ++i) order[i] = i;
+    std::vector<int> tri(3 * (size_t)trials);
+    for (int t = 0; t < trials; ++t) {
+        for (int j = 0; j < 3; ++j) {
+            const double u = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
+            const int cur = (int)order.size();
+            const int idx = (int)((cur - 1) * u);                             // :142
+            tri[3 * (size_t)t + j] = order[idx];
+            order.erase(order.begin() + idx);                                 // :149-150
+        }
+        for (int j = 2; j >= 0; --j) order.push_back(0);                      // :180-189: sample j returns to slot N-j-1
+        for (int j = 0; j < 3; ++j) order[N - j - 1] = tri[3 * (size_t)t + j];
+    }
+
+    if (rest < 16) {
+        // tiny cluster: the literal buffer semantics
+        std::vector<double> dist(N, 0.0);
+        for (int t = 0; t < trials; ++t) {
+            TrialDistances(sx, dx, &tri[3 * (size_t)t], F, dist.data());      // first N-3 entries
+            std::sort(dist.begin(), dist.end());                              // all N entries, 3 of them stale (:175)
+            distances[t] = (rest % 2) ? dist[rest / 2] : 0.5 * (dist[rest / 2] + dist[rest / 2 + 1]);   // :176
+        }
+    } else {
+        // (2) per-trial statistics, independent of each other
+        std::vector<TrialStats> st(trials);
+        unsigned nthreads = std::thread::hardware_concurrency();
+        if (nthreads == 0) nthreads = 1;
+        if (nthreads > 32) nthreads = 32;
+        if ((size_t)N * trials < 200000) nthreads = 1;
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            std::vector<double> buf(rest);
+            for (;;) {
+                const int t = next.fetch_add(1);
+                if (t >= trials) break;
+                TrialDistances(sx, dx, &tri[3 * (size_t)t], F, buf.data());
+                TrialSelect(buf, st[t]);
+            }
+        };
+        if (nthreads == 1) work();
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(work);
+            for (auto& th : pool) th.join();
+        }
+        // (3) thread the three stale entries through the trials
+        double stale[3] = { 0.0, 0.0, 0.0 };
+        for (int t = 0; t < trials; ++t) {
+            double u[8] = { st[t].mid[0], st[t].mid[1], st[t].mid[2], st[t].mid[3], st[t].mid[4],
+                            stale[0], stale[1], stale[2] };
+            std::sort(u, u + 8);
+            distances[t] = (rest % 2) ? u[3] : 0.5 * (u[3] + u[4]);           // ranks rest/2 and rest/2+1 of the union
+            double v[6] = { st[t].top[0], st[t].top[1], st[t].top[2], stale[0], stale[1], stale[2] };
+            std::sort(v, v + 6);
+            stale[0] = v[3]; stale[1] = v[4]; stale[2] = v[5];
+        }
+    }
+    std::sort(distances.begin(), distances.end());
+    return trials % 2 ? distances[trials / 2] : 0.5 * (distances[trials / 2] + distances[trials / 2 + 1]);   // :193
+}
+
+} // namespace
+
 int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
-                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed)
+                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed, double* medians)
 {
     std::vector<std::vector<double>> src(nh), dst(nh);
     for (int i = 0; i < n; ++i) {
@@ -394,52 +535,12 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
     }
     std::vector<char> remove(nh, 0);
     uint64_t counter = 0;
-    const int trials = 501;                                    // MAX(501, MIN(501, ...)), :128
     for (int c = 0; c < nh; ++c) {
-        std::vector<double>& s = src[c];
-        std::vector<double>& d = dst[c];
-        const int N = (int)(s.size() / 2);
+        const int N = (int)(src[c].size() / 2);
+        if (medians) medians[c] = std::nan("");
         if (N >= std::max(min_inliers, 4)) {
-            std::vector<double> distances(trials), dist(N, 0.0), sorted;
-            for (int t = 0; t < trials; ++t) {
-                double ms[6], md[6];
-                for (int j = 0; j < 3; ++j) {
-                    const double u = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
-                    const int cur = (int)(s.size() / 2);
-                    const int idx = (int)((cur - 1) * u);                     // :142
-                    ms[2 * j] = s[2 * idx]; ms[2 * j + 1] = s[2 * idx + 1];
-                    md[2 * j] = d[2 * idx]; md[2 * j + 1] = d[2 * idx + 1];
-                    s.erase(s.begin() + 2 * idx, s.begin() + 2 * idx + 2);   // :149-150
-                    d.erase(d.begin() + 2 * idx, d.begin() + 2 * idx + 2);
-                }
-                double Hc[9];
-                const bool ok = Homography3PTLinear(ms, md, 3, F, Hc);        // do_numerical_refinement = false, :154
-                const int rest = N - 3;
-                for (int j = 0; j < rest; ++j) {
-                    double d2 = std::nan("");
-                    if (ok) {
-                        const double ox = s[2 * j], oy = s[2 * j + 1];
-                        const double ss = Hc[6] * ox + Hc[7] * oy + Hc[8];
-                        const double x1 = (Hc[0] * ox + Hc[1] * oy + Hc[2]) / ss;
-                        const double y1 = (Hc[3] * ox + Hc[4] * oy + Hc[5]) / ss;
-                        const double dx = d[2 * j] - x1, dy = d[2 * j + 1] - y1;
-                        d2 = dx * dx + dy * dy;
-                    }
-                    dist[j] = std::isnan(d2) ? 1e300 : d2;
-                }
-                std::sort(dist.begin(), dist.end());                          // all N entries, 3 of them stale (:175)
-                distances[t] = (rest % 2) ? dist[rest / 2] : 0.5 * (dist[rest / 2] + dist[rest / 2 + 1]);   // :176
-                s.resize(2 * (size_t)N);
-                d.resize(2 * (size_t)N);
-                for (int j = 0; j < 3; ++j) {                                 // :180-189
-                    const int p2 = N - j - 1;
-                    s[2 * p2] = ms[2 * j]; s[2 * p2 + 1] = ms[2 * j + 1];
-                    d[2 * p2] = md[2 * j]; d[2 * p2 + 1] = md[2 * j + 1];
-                }
-            }
-            std::sort(distances.begin(), distances.end());
-            const double median = trials % 2 ? distances[trials / 2]
-                                             : 0.5 * (distances[trials / 2] + distances[trials / 2 + 1]);
+            const double median = ClusterMedian(src[c], dst[c], F, seed, counter);
+            if (medians) medians[c] = median;
             remove[c] = median > sqr_thr * 81.0 / 16.0;                       // :195
         } else if (N < min_inliers) {
             remove[c] = 1;                                                    // :199-200
@@ -503,6 +604,15 @@ int mhh_compatibility_check(const double* src_xy, const double* dst_xy, int n, i
                             const double* F, double sqr_thr, int min_inliers, unsigned long long seed)
 {
     return multih::CompatibilityCheck(src_xy, dst_xy, n, labels, H, nh, F, sqr_thr, min_inliers, seed);
+}
+
+// same, also returning the per-cluster median-of-medians (NaN where the cluster was not tested)
+__attribute__((visibility("default")))
+int mhh_compatibility_medians(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
+                              const double* F, double sqr_thr, int min_inliers, unsigned long long seed,
+                              double* medians)
+{
+    return multih::CompatibilityCheck(src_xy, dst_xy, n, labels, H, nh, F, sqr_thr, min_inliers, seed, medians);
 }
 
 }

@@ -53,6 +53,7 @@ bool Homography3PT(const double* pts1, const double* pts2, int n, const double F
 // rand() (:142) is replaced by the engine's splitmix64 counter RNG.
 // labels: in/out (-1..nh-1); H: nh x 9 in, compacted in place; returns the new model count.
 int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
-                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed);
+                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed,
+                       double* medians = nullptr /* nh, optional: per-cluster median-of-medians */);
 
 } // namespace multih

@@ -186,3 +186,81 @@ def test_compatibility_check(host, synth):
     assert (lab[labels == 3] == -1).all() and (lab[labels == 4] == -1).all()
     for k in range(3):
         assert (lab[labels == k] == k).all()
+
+
+def _splitmix64(z):
+    m = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def _literal_cluster_median(host, s, d, F, seed, counter):
+    """HomographyCompatibilityCheck's trial loop as the reference writes it (M/MultiH.cpp:128-194):
+    vectors with erase/append, an N-entry distance buffer whose last three entries go stale, a full
+    sort per trial.  The host library does the same with selection and threads; this is the checker."""
+    s = [tuple(p) for p in s]
+    d = [tuple(p) for p in d]
+    n = len(s)
+    rest = n - 3
+    dist = np.zeros(n)
+    medians = []
+    for _ in range(501):
+        ms, md = [], []
+        for _j in range(3):
+            u = (_splitmix64((seed + counter) & ((1 << 64) - 1)) >> 11) * (1.0 / 9007199254740992.0)
+            counter += 1
+            idx = int((len(s) - 1) * u)
+            ms.append(s.pop(idx)); md.append(d.pop(idx))
+        H = np.zeros(9)
+        p1 = np.ascontiguousarray(np.array(ms, dtype=np.float64)); p2 = np.ascontiguousarray(np.array(md, dtype=np.float64))
+        ok = host.mhh_homography_3pt(p1.ctypes.data_as(_dp), p2.ctypes.data_as(_dp), 3, F.ctypes.data_as(_dp),
+                                     H.ctypes.data_as(_dp))
+        S = np.array(s); D = np.array(d)
+        with np.errstate(all="ignore"):
+            if ok:
+                ss = H[6] * S[:, 0] + H[7] * S[:, 1] + H[8]
+                x1 = (H[0] * S[:, 0] + H[1] * S[:, 1] + H[2]) / ss
+                y1 = (H[3] * S[:, 0] + H[4] * S[:, 1] + H[5]) / ss
+                dx = D[:, 0] - x1; dy = D[:, 1] - y1
+                d2 = dx * dx + dy * dy
+            else:
+                d2 = np.full(rest, np.nan)
+        dist[:rest] = np.where(np.isnan(d2), 1e300, d2)
+        dist.sort()
+        medians.append(dist[rest // 2] if rest % 2 else 0.5 * (dist[rest // 2] + dist[rest // 2 + 1]))
+        s += [None] * 3; d += [None] * 3
+        for j in range(3):
+            s[n - j - 1] = ms[j]; d[n - j - 1] = md[j]
+    medians.sort()
+    return medians[250], counter
+
+
+@pytest.mark.parametrize("sizes", [(700, 523, 64), (10, 21, 19)])
+def test_compatibility_medians_equal_the_literal_trial_loop(host, synth, sizes):
+    """The selection-based, threaded trial loop of host/merge_step.cpp gives, bit for bit, the
+    median-of-medians of the reference's literal loop (full sorts, stale buffer entries), for odd
+    and even cluster sizes, a cluster with scrambled matches and the tiny-cluster path."""
+    sc = synth.make_scene(2500, 3, seed=11, noise=0.4, outlier_frac=0.0, with_neighbours=False)
+    rng = np.random.default_rng(5)
+    labels = np.full(sc.n, -1, dtype=np.int32)
+    for c, sz in enumerate(sizes):
+        members = np.flatnonzero(sc.gt_label == c)[:sz]
+        labels[members] = c
+    scr = np.flatnonzero(labels == 2)
+    sc.dst[scr[::2]] = rng.uniform(0, 1000, size=(scr[::2].size, 2))           # cluster 2: half scrambled
+    src, dst, F = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.F))
+    H = sc.H_true.copy()
+    lab = labels.copy()
+    med = np.zeros(3)
+    seed = 99
+    host.mhh_compatibility_medians(src.ctypes.data_as(_dp), dst.ctypes.data_as(_dp), sc.n,
+                                   lab.ctypes.data_as(C.POINTER(C.c_int)), H.ctypes.data_as(_dp), 3,
+                                   F.ctypes.data_as(_dp), C.c_double(2.2 ** 2), 4, C.c_ulonglong(seed),
+                                   med.ctypes.data_as(_dp))
+    counter = 0
+    for c in range(3):
+        m = labels == c
+        want, counter = _literal_cluster_median(host, src[m], dst[m], F, seed, counter)
+        assert med[c] == want, f"cluster {c} (n={m.sum()}): {med[c]!r} != {want!r}"
