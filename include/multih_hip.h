@@ -177,8 +177,9 @@ MH_API int mh_data_cost(mh_engine* e, int* cost);
  * numbering.  energy: final int32 energy; cycles: executed cycles. */
 MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy, int* cycles);
 /* Counters of the last alpha-expansion: {cycles, moves, accepted moves, push-relabel launches,
- * global-relabel launches, host synchronisations}. */
-MH_API int mh_get_expand_stats(mh_engine* e, long long stats[6]);
+ * global-relabel launches, host synchronisations, dominance-reduction launches, moves that still
+ * needed push-relabel after the reduction}. */
+MH_API int mh_get_expand_stats(mh_engine* e, long long stats[8]);
 /* GetHomographyHAFNonminimal for every label (M/MultiH.cpp:913-989 + the 1/lambda rescale of
  * Homography_RefineHAFCallback.h:33-34).  labels: -1..Nh-1 per point.  Updates the current
  * model set in place; H_out (nullable) receives a host copy. */

@@ -306,9 +306,10 @@ class Engine:
         return labels, energy.value, cycles.value
 
     def expand_stats(self):
-        st = (C.c_longlong * 6)()
+        st = (C.c_longlong * 8)()
         self._check(self.lib.mh_get_expand_stats(self._h, st))
-        return dict(zip(("cycles", "moves", "accepted", "pr_launches", "bfs_launches", "host_syncs"), list(st)))
+        return dict(zip(("cycles", "moves", "accepted", "pr_launches", "bfs_launches", "host_syncs",
+                         "reduce_launches", "flow_moves"), list(st)))
 
     def reestimate(self, labels):
         labels = _i32(labels)

@@ -93,7 +93,7 @@ struct mh_engine {
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
-    DevBuf<int> ew_label, ew_cur, ew_cap, ew_excess, ew_sink, ew_height, ew_flags;
+    DevBuf<int> ew_label, ew_cur, ew_cap, ew_excess, ew_sink, ew_height, ew_decided, ew_flags;
     int cu_count = 256;
     DevBuf<long long> ew_acc;
     int* h_flags = nullptr;
@@ -107,6 +107,7 @@ struct mh_engine {
     int tune_residual_variant = 0;
     int tune_score_variant = 0;
     int residual_mode = MH_RESIDUAL_FORWARD;
+    int tune_reduce = 4;                     // dominance-reduction rounds per launch (0 = off)
     int tune_expand[4] = { 8, 3, 16, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
     ExpandStats last_expand{};
 
@@ -261,6 +262,7 @@ int ensure_expand_work(mh_engine* e)
     HIPCHK(e->ew_excess.reserve(n));
     HIPCHK(e->ew_sink.reserve(n));
     HIPCHK(e->ew_height.reserve(n));
+    HIPCHK(e->ew_decided.reserve(n));
     HIPCHK(e->ew_flags.reserve(16));
     HIPCHK(e->ew_acc.reserve(8));
     if (!e->h_flags) {
@@ -295,8 +297,9 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     if (rc) return rc;
     Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size() };
     ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_excess.p, e->ew_sink.p,
-                  e->ew_height.p, e->ew_flags.p, e->ew_acc.p, e->h_flags, e->h_acc, e->h_flags_dev,
-                  e->h_acc_dev, e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], e->tune_expand[3] };
+                  e->ew_height.p, e->ew_decided.p, e->ew_flags.p, e->ew_acc.p, e->h_flags, e->h_acc, e->h_flags_dev,
+                  e->h_acc_dev, e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], e->tune_expand[3],
+                  e->tune_reduce };
     const int potts = (int)std::round(100.0 * e->lambda);     // M/MultiH.h:41, MultiH.cpp:510
     ExpandStats st{};
     {
@@ -416,7 +419,7 @@ void mh_destroy(mh_engine* e)
     e->ms_votes.release(); e->ms_out.release(); e->ms_list.release(); e->ms_pcnt.release(); e->ms_partial.release();
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
-    e->ew_sink.release(); e->ew_height.release(); e->ew_flags.release(); e->ew_acc.release();
+    e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
     e->knn_tmp.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     if (e->h_acc) (void)hipHostFree(e->h_acc);
@@ -989,7 +992,7 @@ int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy
     return MH_OK;
 }
 
-int mh_get_expand_stats(mh_engine* e, long long stats[6])
+int mh_get_expand_stats(mh_engine* e, long long stats[8])
 {
     if (!e || !stats) return fail(MH_ERR_INVALID, "null argument");
     stats[0] = e->last_expand.cycles;
@@ -998,6 +1001,8 @@ int mh_get_expand_stats(mh_engine* e, long long stats[6])
     stats[3] = e->last_expand.pr_launches;
     stats[4] = e->last_expand.bfs_launches;
     stats[5] = e->last_expand.host_syncs;
+    stats[6] = e->last_expand.reduce_launches;
+    stats[7] = e->last_expand.flow_moves;
     return MH_OK;
 }
 
@@ -1110,6 +1115,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
     if (key == 1) { e->tune_score_variant = value; return MH_OK; }
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
+    if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
 }
 

@@ -105,6 +105,7 @@ struct ExpandWork {         // scratch owned by the engine
     int* excess;            // n
     int* sink_cap;          // n
     int* height;            // n
+    int* decided;           // n   0 undecided, 1 source side (takes alpha), 2 sink side (keeps its label), 3 not in the graph
     int* flags;             // device control words (see expand.hip)
     long long* acc;         // device 64-bit accumulators
     int* h_flags;           // pinned, device-mapped host mirror of flags (host address)
@@ -112,6 +113,7 @@ struct ExpandWork {         // scratch owned by the engine
     int* h_flags_dev;       // device addresses of the two mirrors
     long long* h_acc_dev;
     int bfs_rounds, bfs_batch, pr_cycles, pr_batch;   // schedule knobs (see expand.hip)
+    int reduce_rounds;      // dominance-reduction rounds per launch; 0 switches the reduction off (A/B)
 };
 
 struct ExpandStats {
@@ -119,6 +121,7 @@ struct ExpandStats {
     long long energy;
     int moves, accepted;
     long long pr_launches, bfs_launches, host_syncs;
+    long long reduce_launches, flow_moves;    // reduction launches; moves that still needed push-relabel
 };
 
 hipError_t run_expansion(const Graph& g, const int* cost /* n x L */, int L, int potts,

@@ -171,6 +171,33 @@ def test_expand_labels_bit_exact(engine, synth, oracle, n, k, seed, sym):
     assert energy_w == e_w_ref and np.array_equal(labels_w, lab_w_ref)
 
 
+@pytest.mark.parametrize("lam", [0.1, 0.5, 3.0])
+def test_dominance_reduction_changes_nothing(engine, synth, oracle, lam):
+    """The exact pre-solve of an alpha-move (k_reduce: sites decided by dominance, their n-links folded
+    into the neighbours' t-links) must leave labels, energy and cycle count exactly as push-relabel
+    alone — and as the oracle — finds them, from weak (lambda 0.1) to strong (3.0) smoothing."""
+    sc = synth.make_scene(4000, 4, seed=21, noise=1.0, outlier_frac=0.3)
+    H = _models(sc, np.random.default_rng(21), extra=4)
+    engine.set_params(2.6, THR, 0.005, lam, 20)
+    try:
+        _load(engine, sc)
+        engine.set_models(H)
+        cost = engine.data_cost()
+        lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(lam))
+        got = {}
+        for rounds in (0, 1, 4):
+            engine.set_tuning(6, rounds)
+            labels, energy, cycles = engine.expand()
+            st = engine.expand_stats()
+            assert (st["reduce_launches"] > 0) == (rounds > 0)
+            assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), f"reduce rounds {rounds}"
+            got[rounds] = st
+        assert got[4]["flow_moves"] <= got[0]["flow_moves"]
+    finally:
+        engine.set_tuning(6, 4)
+        engine.set_params(2.6, THR, 0.005, LAM, 20)
+
+
 def test_expand_without_neighbours_is_argmin(engine, synth, oracle):
     sc = synth.make_scene(500, 3, seed=2, with_neighbours=False)
     _load(engine, sc, neighbours=False)

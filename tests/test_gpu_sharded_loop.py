@@ -47,3 +47,41 @@ def test_sharded_loop_is_independent_of_world_size(iter_hyp):
         assert got["exchanges"] > 0, "the sharded propose stage never exchanged scores"
         assert got["digest"] == one["digest"] and got["clusters"] == one["clusters"]
         assert got["energy"] == one["energy"] and got["iterations"] == one["iterations"]
+
+
+_RCCL_PROBE = r'''
+import importlib, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MH_ROOT"])
+import bench
+mh = importlib.import_module("multi-h_amd")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+sc = mh.synth.make_scene(3000, 3, seed=2, with_neighbours=False)
+eng = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.set_correspondences(sc.src, sc.dst, sc.aff)
+eng.propose_dlt4(7, 0, 4096)
+eng.residual_matrix(2.2 ** 2, fetch_R=False, fetch_counts=False)
+ptr, nbytes = eng.device_buffer(0)
+counts = torch.as_tensor(bench._DevView(ptr, 4096, "<i4"), device=dev)     # zero-copy view of the engine's buffer
+out = torch.full((4096,), -5, dtype=torch.int32, device=dev)
+dist.all_gather_into_tensor(out, counts)                                     # RCCL on the engine's own memory
+torch.cuda.synchronize()
+want = eng.score(2.2 ** 2)
+assert np.array_equal(out.cpu().numpy(), want), "RCCL all-gather of the resident score buffer differs"
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_PROBE_OK", int(want.max()))
+'''
+
+
+def test_rccl_all_gather_reads_the_engine_score_buffer_in_place():
+    """bench.py's exchange on a real node: RCCL all-gathers straight out of the engine's resident
+    int32 score buffer (zero-copy view, engine on torch's stream).  One rank is all this box has,
+    but the collective, the external pointer and the stream ordering are the real ones."""
+    env = dict(os.environ, MH_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", _RCCL_PROBE], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_PROBE_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
