@@ -188,14 +188,6 @@ def test_compatibility_check(host, synth):
         assert (lab[labels == k] == k).all()
 
 
-def _splitmix64(z):
-    m = (1 << 64) - 1
-    z = (z + 0x9E3779B97F4A7C15) & m
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
-    return z ^ (z >> 31)
-
-
 def _literal_cluster_median(host, s, d, F, seed, counter):
     """HomographyCompatibilityCheck's trial loop as the reference writes it (M/MultiH.cpp:128-194):
     vectors with erase/append, an N-entry distance buffer whose last three entries go stale, a full
