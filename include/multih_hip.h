@@ -79,6 +79,13 @@ MH_API int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col,
 /* Exact k-NN hit list built on the GPU in float32 (x1,y1,x2,y2) space — the engine's own
  * replacement for the FLANN radius search (deviation documented). */
 MH_API int mh_build_neighbors_knn(mh_engine* e, int k);
+/* The reference's neighbourhood rule itself (M/MultiH.cpp:252-253, radiusMatch with maxDistance =
+ * 1/locality_lambda), answered exactly instead of by FLANN's randomised KD-trees: query i hits
+ * every j (itself included) whose float32 squared distance in (x1,y1,x2,y2) is <= radius^2.
+ * The hit count grows like n^2 * radius^4, so `max_hits` (0 = 2^31-1) bounds it: beyond the bound
+ * the call fails with MH_ERR_OVERFLOW and leaves the current graph untouched.  hits_out
+ * (nullable) receives the number of directed hits found. */
+MH_API int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, long long* hits_out);
 /* Copy the symmetric weighted graph the engine derived (rowptr n+1, col/w nnz).  Pass NULLs to
  * query nnz only. */
 MH_API int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz);

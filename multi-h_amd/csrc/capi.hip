@@ -529,6 +529,43 @@ int mh_build_neighbors_knn(mh_engine* e, int k)
     return upload_graph(e);
 }
 
+int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, long long* hits_out)
+{
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!(radius > 0.0)) return fail(MH_ERR_INVALID, "radius must be positive");
+    const int n = e->n;
+    const float r2 = (float)radius * (float)radius;
+    HIPCHK(e->knn_tmp.reserve((size_t)n + 1));
+    HIPCHK(launch_radius_count(e->pts(), r2, e->knn_tmp.p, e->stream));
+    std::vector<int> cnt(n), rowptr(n + 1, 0);
+    HIPCHK(hipMemcpyAsync(cnt.data(), e->knn_tmp.p, sizeof(int) * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    long long total = 0;
+    for (int i = 0; i < n; ++i) total += cnt[i];
+    if (hits_out) *hits_out = total;
+    const long long limit = max_hits > 0 ? max_hits : 0x7fffffffll;
+    if (total > limit || total > 0x7fffffffll) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "radius search yields %lld hits (limit %lld): use a smaller radius or k-NN", total, limit);
+        return fail(MH_ERR_OVERFLOW, msg);
+    }
+    for (int i = 0; i < n; ++i) rowptr[i + 1] = rowptr[i] + cnt[i];
+    struct Scratch { DevBuf<int> b; ~Scratch() { b.release(); } } s_rp, s_col;
+    DevBuf<int>&d_rp = s_rp.b, &d_col = s_col.b;
+    HIPCHK(d_rp.reserve((size_t)n + 1));
+    HIPCHK(d_col.reserve((size_t)std::max<long long>(total, 1)));
+    HIPCHK(hipMemcpyAsync(d_rp.p, rowptr.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(launch_radius_fill(e->pts(), r2, d_rp.p, d_col.p, e->stream));
+    std::vector<int> col((size_t)total);
+    if (total > 0)
+        HIPCHK(hipMemcpyAsync(col.data(), d_col.p, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    rc = build_sym_graph(e, rowptr.data(), col.data(), n);
+    if (rc) return rc;
+    return upload_graph(e);
+}
+
 int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
 {
     if (!e) return fail(MH_ERR_INVALID, "null engine");

@@ -133,5 +133,7 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 
 // --- knn.hip ----------------------------------------------------------------
 hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, hipStream_t s);
+hipError_t launch_radius_count(const Points& p, float r2, int* counts /* n */, hipStream_t s);
+hipError_t launch_radius_fill(const Points& p, float r2, const int* rowptr /* n+1 */, int* col /* nnz */, hipStream_t s);
 
 } // namespace mh

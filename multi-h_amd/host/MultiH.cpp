@@ -424,6 +424,10 @@ void MultiH::ClusterMergingAndLabeling()
             rowptr[i + 1] = static_cast<int>(col.size());
         }
         ok = Check(mh_set_neighbors_csr(engine, rowptr.data(), col.data(), N), "mh_set_neighbors_csr");
+    } else if (neighbour_radius > 0.0) {
+        long long hits = 0;
+        ok = Check(mh_build_neighbors_radius(engine, neighbour_radius, neighbour_max_hits, &hits), "mh_build_neighbors_radius");
+        if (ok && log_to_console) printf("[Multi-H] %lld neighbourhood hits within %.1f px\n", hits, neighbour_radius);
     } else {
         ok = Check(mh_build_neighbors_knn(engine, std::min(knn, N - 1)), "mh_build_neighbors_knn");
     }

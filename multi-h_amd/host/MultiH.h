@@ -72,6 +72,10 @@ public:
     // Without it Process() builds exact k-NN hits on the GPU (k = knn, default 16).
     void SetNeighbours(const std::vector<std::vector<int>>& hits);
     void SetNeighbourK(int k) { knn = k; }
+    // The reference's own rule instead: every correspondence within `radius` pixels in the float32
+    // (x1,y1,x2,y2) space is a hit (M/MultiH.cpp:252-253 passes 1/locality_lambda), found exactly on the
+    // GPU.  The hit list grows like N^2, so it is bounded by `max_hits`; beyond it Process() fails.
+    void SetNeighbourRadius(double radius, long long max_hits = 1ll << 28) { neighbour_radius = radius; neighbour_max_hits = max_hits; }
     // Initial cluster_homographies (what EstablishStablePointSets hands to the loop).
     void SetInitialHomographies(const std::vector<cv::Mat>& Hs);
     // How the initial models are made when SetInitialHomographies was not called:
@@ -134,6 +138,8 @@ protected:
     mh_engine* engine = nullptr;
     int device = 0;
     int knn = 16;
+    double neighbour_radius = 0.0;
+    long long neighbour_max_hits = 1ll << 28;
     uint64_t proposal_seed = 1234;
     int proposal_hypotheses = 10000;
     int proposal_max_models = 32;

@@ -7,6 +7,7 @@
 //   multih_harness <in_corr.txt> <out_result.txt> [--epipolar <file with F(9) e2x e2y>]
 //                  [--thrF 2.6] [--thrH 2.2] [--locality 0.005] [--lambda 0.5] [--min-inliers 20]
 //                  [--hypotheses 10000] [--max-models 32] [--seed 1234] [--iterations 0]
+//                  [--neighbourhood knn|radius]   (radius = the reference's rule, 1/locality pixels)
 // Defaults are the harness defaults of the reference (M/main.cpp:55-59).
 #include <cstdio>
 #include <cstdlib>
@@ -52,13 +53,13 @@ int main(int argc, char** argv)
     if (argc < 3) {
         std::cerr << "usage: multih_harness <in_corr.txt> <out_result.txt> [--epipolar file] [--thrF v] [--thrH v] "
                      "[--locality v] [--lambda v] [--min-inliers n] [--hypotheses n] [--max-models n] [--seed n] "
-                     "[--iterations n]\n";
+                     "[--iterations n] [--neighbourhood knn|radius]\n";
         return 2;
     }
     double thrF = 2.6, thrH = 2.2, locality = 0.005, lambda = 0.5;     // M/main.cpp:55-59
     int min_inliers = 20, hypotheses = 10000, max_models = 32, iterations = 0;
     unsigned long long seed = 1234;
-    std::string epi;
+    std::string epi, neighbourhood = "knn";
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
         const char* v = argv[i + 1];
@@ -72,6 +73,7 @@ int main(int argc, char** argv)
         else if (k == "--max-models") max_models = atoi(v);
         else if (k == "--seed") seed = strtoull(v, nullptr, 10);
         else if (k == "--iterations") iterations = atoi(v);
+        else if (k == "--neighbourhood") neighbourhood = v;
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
 
@@ -95,6 +97,7 @@ int main(int argc, char** argv)
     }
     multiH->SetProposal(seed, hypotheses, max_models);
     multiH->SetFixedIterations(iterations);
+    if (neighbourhood == "radius") multiH->SetNeighbourRadius(1.0 / locality);        // M/MultiH.cpp:252-253
     if (!multiH->Process(srcPointsOrig, dstPointsOrig, origAffines)) { delete multiH; return 1; }
 
     std::vector<int> labeling;

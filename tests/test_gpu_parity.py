@@ -264,6 +264,41 @@ def test_knn_builder(engine, synth):
         assert np.array_equal(w[rp[i]:rp[i + 1]], mult[i][js])
 
 
+def test_radius_neighbourhood_is_the_exact_reference_rule(mh, engine, synth, oracle):
+    """mh_build_neighbors_radius: the hit list radiusMatch(1/locality) asks for (M/MultiH.cpp:252-253),
+    exact: float32 squared distance <= r^2, self included; fed through the same setNeighbors
+    multiplicity rule as a caller-supplied list (oracle build_sym_graph).  The bound on the hit count
+    fails cleanly and leaves the previous graph in place."""
+    sc = synth.make_scene(1800, 3, seed=8, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    r = 60.0
+    pv = np.concatenate([sc.src, sc.dst], axis=1).astype(np.float32)
+    diff = pv[:, None, :] - pv[None, :, :]
+    sq = diff * diff
+    d = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]) + sq[..., 3]
+    hit = d <= np.float32(r) * np.float32(r)
+    assert hit.diagonal().all()
+    rowptr = np.concatenate([[0], np.cumsum(hit.sum(axis=1))]).astype(np.int32)
+    col = np.nonzero(hit)[1].astype(np.int32)
+    hits = engine.build_neighbors_radius(r)
+    assert hits == col.size
+    rp, cl, w = engine.get_sym_graph()
+    rp_o, cl_o, w_o = oracle.build_sym_graph(sc.n, rowptr, col)
+    assert np.array_equal(rp, rp_o) and np.array_equal(cl, cl_o) and np.array_equal(w, w_o)
+    assert (w == 2).all()                       # a radius rule is symmetric: every pair is found from both sides
+    with pytest.raises(mh.MultiHError) as ei:
+        engine.build_neighbors_radius(r, max_hits=col.size - 1)
+    assert ei.value.code == -5
+    rp2, cl2, _ = engine.get_sym_graph()
+    assert np.array_equal(rp2, rp) and np.array_equal(cl2, cl)
+    # and the labeling on that graph equals the oracle's on the same hit list
+    engine.set_models(_models(sc, np.random.default_rng(3), extra=2))
+    cost = engine.data_cost()
+    labels, energy, cycles = engine.expand()
+    lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, rowptr, col, oracle.potts(LAM))
+    assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref)
+
+
 def test_fp64_division_and_sqrt_are_ieee(engine, synth, oracle):
     """The bit-exactness argument rests on the device's FP64 divide being correctly rounded.
     Stress it through the residual kernel with adversarial magnitudes."""
@@ -487,6 +522,13 @@ def test_harness_file_formats(mh, synth, tmp_path):
     assert np.allclose(res[:, :2], sc.src, rtol=1e-5)
     labels = res[:, 8].astype(int)
     assert labels.min() >= -1 and labels.max() >= 2
+    # the reference's radius neighbourhood (1/locality = 40 px here) instead of k-NN
+    out2 = tmp_path / "result_radius.txt"
+    r = subprocess.run([exe, str(inp), str(out2), "--epipolar", str(epi), "--hypotheses", "5000",
+                        "--locality", "0.025", "--neighbourhood", "radius"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    res2 = np.loadtxt(out2)
+    assert res2.shape == (1500, 9) and res2[:, 8].max() >= 2
     # too few correspondences: the reference's error path
     np.savetxt(inp, np.concatenate([sc.src, sc.dst, sc.aff], axis=1)[:5], fmt="%.10g")
     r = subprocess.run([exe, str(inp), str(out)], capture_output=True, text=True, timeout=60)
