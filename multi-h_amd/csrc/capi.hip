@@ -108,7 +108,7 @@ struct mh_engine {
     int tune_score_variant = 0;
     int residual_mode = MH_RESIDUAL_FORWARD;
     int tune_reduce = 4;                     // dominance-reduction rounds per launch (0 = off)
-    int tune_expand[4] = { 8, 3, 16, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
+    int tune_expand[4] = { 16, 2, 32, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
     ExpandStats last_expand{};
 
     Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n }; }

@@ -99,6 +99,7 @@ k_argmin_labels(const int* __restrict__ cost, int L, int n, int* __restrict__ la
 // ---------------------------------------------------------------------------
 constexpr int LPN = 16;
 constexpr int SITES_PER_BLOCK = 256 / LPN;
+constexpr int SLOTS = 3;              // arcs per lane kept in registers by the relax / push kernels
 
 __device__ __forceinline__ int row_min(int v)
 {
@@ -244,20 +245,49 @@ k_bfs_relax(Graph g, const int* __restrict__ decided, const int* __restrict__ ca
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
     int hu = LD(&height[u]);
     bool any = false;
-    for (int r = 0; r < ROUNDS; ++r) {
-        if (hu <= 1) break;
-        int best = hu;
-        for (int k = k0 + sub; k < k1; k += LPN) {
-            if (cap[k] > 0) {
-                const int hv = LD(&height[g.col[k]]) + 1;
-                if (hv < best) best = hv;
+    if (k1 - k0 <= SLOTS * LPN) {
+        // The usual case (degree <= 48): each lane keeps its <= 3 residual arcs' heads in registers
+        // (capacities do not change while relaxation runs), so a round is ONE level of independent
+        // agent-scope loads instead of a cap -> col -> height chain.
+        int nb[SLOTS];
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int k = k0 + sub + q * LPN;
+            nb[q] = (k < k1 && cap[k] > 0) ? g.col[k] : -1;
+        }
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (hu <= 1) break;
+            int best = hu;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                if (nb[q] >= 0) {
+                    const int hv = LD(&height[nb[q]]) + 1;
+                    if (hv < best) best = hv;
+                }
+            }
+            best = row_min(best);
+            if (best < hu) {
+                hu = best;
+                if (sub == 0) ST(&height[u], hu);
+                any = true;
             }
         }
-        best = row_min(best);
-        if (best < hu) {                             // keep polling otherwise: a neighbour may still
-            hu = best;                               // drop inside this launch
-            if (sub == 0) ST(&height[u], hu);
-            any = true;
+    } else {
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (hu <= 1) break;
+            int best = hu;
+            for (int k = k0 + sub; k < k1; k += LPN) {
+                if (cap[k] > 0) {
+                    const int hv = LD(&height[g.col[k]]) + 1;
+                    if (hv < best) best = hv;
+                }
+            }
+            best = row_min(best);
+            if (best < hu) {                             // keep polling otherwise: a neighbour may still
+                hu = best;                               // drop inside this launch
+                if (sub == 0) ST(&height[u], hu);
+                any = true;
+            }
         }
     }
     if (any && sub == 0) flags[F_CHANGED] = 1;
@@ -288,6 +318,13 @@ k_push_relabel(Graph g, const int* __restrict__ decided, int* cap, int* excess,
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
     int hu = LD(&height[u]);
     int sc = sink_cap[u];
+    const bool fits = (k1 - k0) <= SLOTS * LPN;
+    int nb[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int k = k0 + sub + q * LPN;
+        nb[q] = (fits && k < k1) ? g.col[k] : -1;
+    }
     for (int cyc = 0; cyc < CYCLES; ++cyc) {
         if (hu >= n) break;
         // lane 0 reads the excess and broadcasts it: all lanes of the row act on ONE value
@@ -302,10 +339,27 @@ k_push_relabel(Graph g, const int* __restrict__ decided, int* cap, int* excess,
             if (e == 0) continue;
         }
         long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
-        for (int k = k0 + sub; k < k1; k += LPN) {
-            if (LD(&cap[k]) > 0) {
-                const long long cand = ((long long)LD(&height[g.col[k]]) << 32) | (unsigned int)k;
-                if (cand < key) key = cand;
+        if (fits) {
+            // heads preloaded: the capacity and the neighbour's height are independent loads
+            int cq[SLOTS], hq[SLOTS];
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                cq[q] = nb[q] >= 0 ? LD(&cap[k0 + sub + q * LPN]) : 0;
+                hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                if (cq[q] > 0) {
+                    const long long cand = ((long long)hq[q] << 32) | (unsigned int)(k0 + sub + q * LPN);
+                    if (cand < key) key = cand;
+                }
+            }
+        } else {
+            for (int k = k0 + sub; k < k1; k += LPN) {
+                if (LD(&cap[k]) > 0) {
+                    const long long cand = ((long long)LD(&height[g.col[k]]) << 32) | (unsigned int)k;
+                    if (cand < key) key = cand;
+                }
             }
         }
         key = row_min64(key);
@@ -425,7 +479,6 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 
 #define RET_IF(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-static long long g_syncs = 0;      // host synchronisations of the running expansion (stats only)
 
 // Control words travel to the host through device-mapped pinned memory: one 1-wave kernel copies
 // them (no hipMemcpy calls, which cost tens of microseconds each for 32 bytes), then the host
@@ -440,7 +493,7 @@ __global__ void k_publish(const int* __restrict__ flags, const long long* __rest
 
 static hipError_t fetch(ExpandWork& w, hipStream_t s)
 {
-    ++g_syncs;
+    ++w.host_syncs;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, w.flags, w.acc, w.h_flags_dev, w.h_acc_dev);
     RET_IF(hipGetLastError());
     return hipStreamSynchronize(s);
@@ -464,7 +517,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     const dim3 grid1((g.n + 255) / 256), blk(256);                          // one thread per site
     const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site
     ExpandStats stats = {};
-    g_syncs = 0;
+    w.host_syncs = 0;
     RET_IF(hipMemsetAsync(w.flags, 0, sizeof(int) * F_COUNT, s));
     RET_IF(hipMemsetAsync(w.acc, 0, sizeof(long long) * A_COUNT, s));
 
@@ -501,10 +554,14 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             if (w.reduce_rounds > 0) {
                 // dominance reduction to its fixed point: a launch that changed nothing ends it
                 for (;;) {
+                    // two launches per host check; only the second one's flag decides (a launch that
+                    // changed nothing is the fixed point)
+                    hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
+                                       w.flags, w.reduce_rounds);
                     RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
                     hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
                                        w.flags, w.reduce_rounds);
-                    ++stats.reduce_launches;
+                    stats.reduce_launches += 2;
                     RET_IF(hipMemsetAsync(&w.flags[F_UNDECIDED_EXCESS], 0, sizeof(int), s));
                     hipLaunchKernelGGL(k_count_undecided, grid1, blk, 0, s, g.n, w.excess, w.decided, w.flags);
                     RET_IF(hipGetLastError());
@@ -559,7 +616,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
         if (energy == old_energy) break;               // :1045
     }
     stats.energy = energy;
-    stats.host_syncs = g_syncs;
+    stats.host_syncs = w.host_syncs;
     stats.accepted = w.h_flags[F_ACCEPTED];
     if (st) *st = stats;
     return hipSuccess;

@@ -114,6 +114,7 @@ struct ExpandWork {         // scratch owned by the engine
     long long* h_acc_dev;
     int bfs_rounds, bfs_batch, pr_cycles, pr_batch;   // schedule knobs (see expand.hip)
     int reduce_rounds;      // dominance-reduction rounds per launch; 0 switches the reduction off (A/B)
+    long long host_syncs = 0;   // host synchronisations of the running expansion (stats)
 };
 
 struct ExpandStats {

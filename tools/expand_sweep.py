@@ -11,7 +11,9 @@ e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2); e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
 H = sc.H_true * (1.0 + np.random.default_rng(0).normal(0, 1e-4, size=sc.H_true.shape))
 ref = None
-for cfg in [(4,6,8,8),(8,3,8,8),(16,2,8,8),(8,3,16,4),(8,3,16,8),(16,2,32,4),(8,4,32,2),(32,1,16,4),(16,2,16,16),(16,2,64,2)]:
+CFGS = [(8,3,16,8),(16,2,32,8),(16,2,32,16),(16,2,64,8),(16,2,48,8),(12,2,32,8),(16,2,32,12),(24,2,32,8),(16,2,64,4),(16,2,32,8),(8,3,16,8)]
+if os.environ.get("CFGS"): CFGS = [tuple(int(x) for x in c.split(',')) for c in os.environ["CFGS"].split(';')]
+for cfg in CFGS:
     for k, v in enumerate(cfg): e.set_tuning(2 + k, v)
     e.set_models(H); e.data_cost(fetch=False)
     t0 = time.time(); lab, en, cyc = e.expand(); dt = time.time() - t0
