@@ -45,7 +45,8 @@
 
 namespace mh {
 
-enum { F_ACTIVE = 0, F_CHANGED = 1, F_EXCESS_NODES = 2, F_ACCEPTED = 3, F_OVERFLOW = 4, F_UNDECIDED_EXCESS = 5, F_COUNT = 8 };
+enum { F_ACTIVE = 0, F_CHANGED = 1, F_EXCESS_NODES = 2, F_ACCEPTED = 3, F_OVERFLOW = 4, F_UNDECIDED_EXCESS = 5,
+       F_SCRATCH = 7 /* write-only sink for launches whose 'changed' flag is not looked at */, F_COUNT = 8 };
 enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_COUNT = 4 };
 
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -131,6 +132,7 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
     if (i >= g.n) return;
     const int li = label[i];
     const int k0 = g.rowptr[i], k1 = g.rowptr[i + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[A_DELTA] = 0;     // k_delta of this move accumulates into it later
     if (sub == 0) decided[i] = (li == alpha) ? 3 : 0;
     if (li == alpha) {
         if (sub == 0) { excess[i] = 0; sink_cap[i] = 0; }
@@ -181,7 +183,8 @@ k_bfs_init(int n, const int* __restrict__ decided, const int* __restrict__ sink_
 // a decided site never writes again, so rounds may run chaotically: every verdict holds given any
 // subset of earlier verdicts (a stale "undecided" view only makes the tests stricter).
 __global__ void __launch_bounds__(256)
-k_reduce(Graph g, int* cap, int* excess, int* sink_cap, int* decided, int* __restrict__ flags, int ROUNDS)
+k_reduce(Graph g, int* cap, int* excess, int* sink_cap, int* decided, int* __restrict__ flags,
+         int* __restrict__ changed_flag, int ROUNDS)
 {
     const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
@@ -215,7 +218,7 @@ k_reduce(Graph g, int* cap, int* excess, int* sink_cap, int* decided, int* __res
         sink_cap[u] = net < 0 ? (int)(-net) : 0;
     }
     if (verdict) { ST(&decided[u], verdict); changed = true; }
-    if (changed) flags[F_CHANGED] = 1;
+    if (changed) *changed_flag = 1;
 }
 
 // Undecided sites that still hold excess: zero means the cut is already known.
@@ -236,7 +239,7 @@ k_count_undecided(int n, const int* __restrict__ excess, const int* __restrict__
 // (agent-scope loads/stores, which bypass the per-CU L1).
 __global__ void __launch_bounds__(256)
 k_bfs_relax(Graph g, const int* __restrict__ decided, const int* __restrict__ cap,
-            int* height, int* __restrict__ flags, int ROUNDS)
+            int* height, int* __restrict__ changed_flag, int ROUNDS)
 {
     const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
@@ -290,7 +293,7 @@ k_bfs_relax(Graph g, const int* __restrict__ decided, const int* __restrict__ ca
             }
         }
     }
-    if (any && sub == 0) flags[F_CHANGED] = 1;
+    if (any && sub == 0) *changed_flag = 1;
 }
 
 __global__ void __launch_bounds__(256)
@@ -483,12 +486,15 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 // Control words travel to the host through device-mapped pinned memory: one 1-wave kernel copies
 // them (no hipMemcpy calls, which cost tens of microseconds each for 32 bytes), then the host
 // waits for the stream.
-__global__ void k_publish(const int* __restrict__ flags, const long long* __restrict__ acc,
+__global__ void k_publish(int* __restrict__ flags, long long* __restrict__ acc,
                           int* __restrict__ h_flags, long long* __restrict__ h_acc)
 {
     const int t = threadIdx.x;
     if (t < F_COUNT) h_flags[t] = flags[t];
     if (t < A_COUNT) h_acc[t] = acc[t];
+    // the per-check words start the next batch from zero (saves a 4-byte memset launch per word)
+    if (t == F_ACTIVE || t == F_CHANGED || t == F_EXCESS_NODES || t == F_UNDECIDED_EXCESS) flags[t] = 0;
+    if (t == A_EXCESS_SUM) acc[t] = 0;
 }
 
 static hipError_t fetch(ExpandWork& w, hipStream_t s)
@@ -536,8 +542,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
         old_energy = energy;
         for (int alpha = 0; alpha < L; ++alpha) {
             ++stats.moves;
-            RET_IF(hipMemsetAsync(w.flags, 0, sizeof(int) * 3, s));     // ACTIVE, CHANGED, EXCESS_NODES
-            RET_IF(hipMemsetAsync(w.acc, 0, sizeof(long long), s));     // DELTA
+            // (ACTIVE, CHANGED, EXCESS_NODES, EXCESS_SUM were zeroed by the last k_publish; DELTA by k_move_setup)
             hipLaunchKernelGGL(k_move_setup, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
                                w.cur_cost, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
             RET_IF(hipGetLastError());
@@ -546,7 +551,6 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                 if (st) { stats.energy = -1; *st = stats; }
                 return hipErrorInvalidValue;           // int32 energy terms would overflow
             }
-            RET_IF(hipMemsetAsync(&w.acc[A_EXCESS_SUM], 0, sizeof(long long), s));
             // No excess anywhere: max-flow is 0, after == before, the move is rejected (:1259).
             if (w.h_flags[F_EXCESS_NODES] == 0) continue;
 
@@ -557,12 +561,10 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                     // two launches per host check; only the second one's flag decides (a launch that
                     // changed nothing is the fixed point)
                     hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
-                                       w.flags, w.reduce_rounds);
-                    RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
+                                       w.flags, &w.flags[F_SCRATCH], w.reduce_rounds);
                     hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
-                                       w.flags, w.reduce_rounds);
+                                       w.flags, &w.flags[F_CHANGED], w.reduce_rounds);
                     stats.reduce_launches += 2;
-                    RET_IF(hipMemsetAsync(&w.flags[F_UNDECIDED_EXCESS], 0, sizeof(int), s));
                     hipLaunchKernelGGL(k_count_undecided, grid1, blk, 0, s, g.n, w.excess, w.decided, w.flags);
                     RET_IF(hipGetLastError());
                     RET_IF(fetch(w, s));
@@ -586,12 +588,10 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                 // in the same batch: it is only trusted when that last launch changed nothing.
                 for (;;) {
                     for (int b = 0; b < w.bfs_batch; ++b) {
-                        if (b == w.bfs_batch - 1) RET_IF(hipMemsetAsync(&w.flags[F_CHANGED], 0, sizeof(int), s));
-                        hipLaunchKernelGGL(k_bfs_relax, grid, blk, 0, s, g, w.decided,
-                                           w.cap, w.height, w.flags, w.bfs_rounds);
+                        hipLaunchKernelGGL(k_bfs_relax, grid, blk, 0, s, g, w.decided, w.cap, w.height,
+                                           &w.flags[b == w.bfs_batch - 1 ? F_CHANGED : F_SCRATCH], w.bfs_rounds);
                         ++stats.bfs_launches;
                     }
-                    RET_IF(hipMemsetAsync(&w.flags[F_ACTIVE], 0, sizeof(int), s));
                     hipLaunchKernelGGL(k_count_active, grid1, blk, 0, s, g.n, w.excess, w.height, w.decided, w.flags);
                     RET_IF(hipGetLastError());
                     RET_IF(fetch(w, s));
