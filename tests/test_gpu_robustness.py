@@ -1,0 +1,77 @@
+"""Degenerate and hostile inputs through the whole Process() pipeline: nothing may hang, crash or
+raise across the C ABI; the class answers like the reference does (false / few or no clusters).
+Each case runs in a child process under a timeout so that a hang fails the test instead of the box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+_CHILD = r'''
+import ctypes as C, importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["MH_ROOT"])
+mh = importlib.import_module("multi-h_amd")
+host = C.CDLL(os.path.join(os.environ["MH_ROOT"], "multi-h_amd", "libmultih_host.so"))
+case = sys.argv[1]
+rng = np.random.default_rng(3)
+sc = mh.synth.make_scene(600, 2, seed=4, with_neighbours=False)
+src, dst, aff = sc.src.copy(), sc.dst.copy(), sc.aff.copy()
+F, e2 = sc.F.copy(), sc.e2.copy()
+give_F = True
+if case == "seven_points":
+    src, dst, aff = src[:7], dst[:7], aff[:7]
+elif case == "eight_points":
+    src, dst, aff = src[:8], dst[:8], aff[:8]
+elif case == "identical_points":
+    src[:] = src[0]; dst[:] = dst[0]; aff[:] = aff[0]
+elif case == "collinear":
+    t = np.linspace(0, 1000, src.shape[0])
+    src = np.stack([t, 0.5 * t + 3], axis=1); dst = np.stack([t + 5, 0.5 * t + 1], axis=1)
+elif case == "nan_and_inf":
+    src[::7] = np.nan; dst[3::11] = np.inf; aff[5::13] = np.nan
+elif case == "huge_coordinates":
+    src *= 1e12; dst *= 1e12
+elif case == "pure_noise":
+    src = rng.uniform(0, 1000, size=src.shape); dst = rng.uniform(0, 1000, size=dst.shape)
+elif case == "pure_noise_no_F":
+    src = rng.uniform(0, 1000, size=src.shape); dst = rng.uniform(0, 1000, size=dst.shape); give_F = False
+elif case == "zero_affines":
+    aff[:] = 0.0
+n = src.shape[0]
+src, dst, aff = (np.ascontiguousarray(a, dtype=np.float64) for a in (src, dst, aff))
+dp = C.POINTER(C.c_double)
+labels = np.full(max(n, 1), -7, dtype=np.int32); Hout = np.zeros((64, 9))
+it, en, secs = C.c_int(0), C.c_double(0), C.c_double(0)
+k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n,
+                         F.ctypes.data_as(dp) if give_F else None, e2.ctypes.data_as(dp) if give_F else None,
+                         C.c_double(2.6), C.c_double(2.2), C.c_double(0.005), C.c_double(0.5), 20,
+                         C.c_ulonglong(5), 2000, 16, 0, None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)),
+                         Hout.ctypes.data_as(dp), 64, C.byref(it), C.byref(en), C.byref(secs), 0, 4)
+lab = labels[:n]
+print("RESULT", case, k, int(it.value), int((lab >= 0).sum()), int(lab.max()) if n else -1)
+assert k >= -1 and k <= 64
+if k >= 0:
+    assert lab.max() < max(k, 1) and lab.min() >= -7
+'''
+
+CASES = ["seven_points", "eight_points", "identical_points", "collinear", "nan_and_inf", "huge_coordinates",
+         "pure_noise", "pure_noise_no_F", "zero_affines"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_process_survives(case):
+    env = dict(os.environ, MH_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", _CHILD, case], env=env, capture_output=True, text=True, timeout=300)
+    tail = out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.returncode == 0, tail
+    res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert res, tail
+    k = int(res[0].split()[2])
+    if case == "seven_points":
+        assert k == -1 and "Features are not set" in out.stderr          # M/MultiH.cpp:44-50
+    if case in ("pure_noise", "identical_points"):
+        assert k <= 2
