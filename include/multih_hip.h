@@ -208,7 +208,10 @@ enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K
 MH_API int mh_profile_enable(mh_engine* e, int on);
 MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);
-/* Selects a tuning variant of the residual kernel (bench sweeps); 0 = default. */
+/* Tuning knobs for the sweeps of tools/ (defaults are the measured optima; results never depend on
+ * them): key 0 residual-kernel variant, 1 score-kernel variant, 2..5 alpha-expansion schedule (relax
+ * rounds per launch, relax launches per check, push cycles per launch, push launches per round),
+ * 6 dominance-reduction rounds per launch (0 = off), 7 mean-shift iterations per host round trip. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);
 
 #ifdef __cplusplus

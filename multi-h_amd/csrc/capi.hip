@@ -97,6 +97,9 @@ struct mh_engine {
     int cu_count = 256;
     DevBuf<long long> ew_acc;
     int* h_flags = nullptr;
+    MeanShiftResultBlock* h_ms = nullptr;      // mapped pinned result block of the mean-shift climbs
+    MeanShiftResultBlock* h_ms_dev = nullptr;
+    int* h_ms_list = nullptr;                  // pinned staging for the first MS_LIST_PREFIX (row, votes) pairs
     long long* h_acc = nullptr;
     int* h_flags_dev = nullptr;
     long long* h_acc_dev = nullptr;
@@ -107,6 +110,7 @@ struct mh_engine {
     int tune_residual_variant = 0;
     int tune_score_variant = 0;
     int residual_mode = MH_RESIDUAL_FORWARD;
+    int tune_ms_batch = 6;                   // mean-shift climb iterations per host round trip
     int tune_reduce = 4;                     // dominance-reduction rounds per launch (0 = off)
     int tune_expand[4] = { 16, 2, 32, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
     ExpandStats last_expand{};
@@ -422,6 +426,8 @@ void mh_destroy(mh_engine* e)
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
     e->knn_tmp.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
+    if (e->h_ms) (void)hipHostFree(e->h_ms);
+    if (e->h_ms_list) (void)hipHostFree(e->h_ms_list);
     if (e->h_acc) (void)hipHostFree(e->h_acc);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -735,7 +741,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     HIPCHK(e->ms_mean.reserve(16));
     HIPCHK(e->ms_votes.reserve(n));
     HIPCHK(e->ms_out.reserve(4));
-    HIPCHK(e->ms_list.reserve(2 * (size_t)n));
+    HIPCHK(e->ms_list.reserve(std::max<size_t>(2 * (size_t)n, 4096)));       // >= the prefix the host always copies
     HIPCHK(e->ms_partial.reserve(64 * 16));
     HIPCHK(e->ms_pcnt.reserve(64));
     HIPCHK(hipMemcpyAsync(e->ms_data.p, data, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, e->stream));
@@ -744,8 +750,31 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                      e->ms_partial.p, e->ms_pcnt.p };
     const double band_sq = band_width * band_width;                 // MeanShiftClustering.h:31
     const double stop_thresh = 1e-3 * band_width;                   // :48
-    std::vector<int> init(n), visited(n, 0), list;
-    for (int i = 0; i < n; ++i) init[i] = i;
+    constexpr int MS_LIST_PREFIX = 2048;
+    if (!e->h_ms) {
+        HIPCHK(hipHostMalloc((void**)&e->h_ms, sizeof(MeanShiftResultBlock), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_ms_dev, e->h_ms, 0));
+    }
+    if (!e->h_ms_list) HIPCHK(hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * MS_LIST_PREFIX, hipHostMallocDefault));
+
+    // `init` of the reference (:125-130) is the ascending list of unvisited rows, rebuilt after every
+    // climb; a Fenwick tree over the unvisited flags answers "the k-th unvisited row" in O(log n).
+    std::vector<int> fen(n + 1, 0), visited(n, 0), list;
+    for (int i = 1; i <= n; ++i) { fen[i] += 1; const int j = i + (i & -i); if (j <= n) fen[j] += fen[i]; }
+    int top = 1;
+    while (top * 2 <= n) top *= 2;
+    auto kth_unvisited = [&](int k) {                               // 0-based k
+        int pos = 0, rem = k + 1;
+        for (int step = top; step > 0; step >>= 1)
+            if (pos + step <= n && fen[pos + step] < rem) { pos += step; rem -= fen[pos]; }
+        return pos;                                                 // 0-based row index
+    };
+    auto mark_visited = [&](int row) {
+        if (visited[row]) return;
+        visited[row] = 1;
+        for (int i = row + 1; i <= n; i += i & -i) fen[i] -= 1;
+    };
+    int unvisited = n;
     std::vector<std::vector<double>> cent;
     std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: sorted (row, votes)
     unsigned long long counter = 0;
@@ -754,39 +783,39 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         for (int j = 0; j < dd; ++j) { const double x = a[j] - b[j]; s = s + x * x; }
         return std::sqrt(s);
     };
-    while (!init.empty()) {
+    while (unvisited > 0) {
         unsigned long long z = seed + counter++;                    // splitmix64
         z += 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z = z ^ (z >> 31);
         const double rnd = (double)(z >> 11) * (1.0 / 9007199254740992.0);
-        const int st = init[(int)std::round(rnd * (double)(init.size() - 1))];          // :55-56
-        HIPCHK(hipMemcpyAsync(e->ms_mean.p, data + (size_t)st * d, sizeof(double) * d, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemsetAsync(e->ms_out.p, 0, sizeof(int) * 4, e->stream));
-        int out[4];
-        double mean[16];
-        for (int batch = 0; batch < 20000; ++batch) {               // batches of 6 device-side iterations
-            HIPCHK(launch_ms_iterations(w, band_sq, stop_thresh, 6, e->stream));
-            HIPCHK(hipMemcpyAsync(out, e->ms_out.p, sizeof(out), hipMemcpyDeviceToHost, e->stream));
+        const int st = kth_unvisited((int)std::round(rnd * (double)(unvisited - 1)));     // :55-56
+        const int* out = e->h_ms->out;
+        const double* mean = e->h_ms->mean;
+        for (int batch = 0; batch < 20000; ++batch) {               // batches of device-side iterations
+            HIPCHK(launch_ms_climb(w, batch == 0 ? st : -1, band_sq, stop_thresh, e->tune_ms_batch, e->h_ms_dev, e->stream));
+            HIPCHK(hipMemcpyAsync(e->h_ms_list, e->ms_list.p, sizeof(int) * 2 * MS_LIST_PREFIX, hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             if (out[1] || out[3]) break;
         }
-        HIPCHK(launch_ms_collect(w, e->stream));
-        HIPCHK(hipMemcpyAsync(out, e->ms_out.p, sizeof(out), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipMemcpyAsync(mean, e->ms_mean.p, sizeof(double) * d, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
         const int len = out[2];
         list.resize(2 * (size_t)len);
-        if (len) {
-            HIPCHK(hipMemcpyAsync(list.data(), e->ms_list.p, sizeof(int) * 2 * len, hipMemcpyDeviceToHost, e->stream));
+        const int head = std::min(len, MS_LIST_PREFIX);
+        std::copy(e->h_ms_list, e->h_ms_list + 2 * (size_t)head, list.begin());
+        if (len > head) {
+            HIPCHK(hipMemcpyAsync(list.data() + 2 * (size_t)head, e->ms_list.p + 2 * (size_t)head,
+                                  sizeof(int) * 2 * (size_t)(len - head), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
         }
         std::vector<std::pair<int, int>> mine(len);
-        for (int k = 0; k < len; ++k) { mine[k] = { list[2 * k], list[2 * k + 1] }; visited[list[2 * k]] = 1; }
+        for (int k = 0; k < len; ++k) {
+            mine[k] = { list[2 * k], list[2 * k + 1] };
+            if (!visited[list[2 * k]]) { mark_visited(list[2 * k]); --unvisited; }
+        }
         std::sort(mine.begin(), mine.end());
         if (!out[1]) {
-            visited[st] = 1;                                        // climb that captured no row
+            if (!visited[st]) { mark_visited(st); --unvisited; }    // climb that captured no row
         } else {
             int merge_with = -1;
             for (size_t cn = 0; cn < cent.size(); ++cn)
@@ -807,8 +836,6 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                 votes.push_back(mine);
             }
         }
-        init.clear();                                               // :125-130
-        for (int i = 0; i < n; ++i) if (!visited[i]) init.push_back(i);
     }
     std::vector<int> best_votes(n, 0);
     for (int i = 0; i < n; ++i) assign[i] = -1;
@@ -1153,6 +1180,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 1) { e->tune_score_variant = value; return MH_OK; }
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
+    if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
 }
 

@@ -101,6 +101,52 @@ k_ms_collect(MeanShiftWork w)
     }
 }
 
+__global__ void __launch_bounds__(64)
+k_ms_seed(MeanShiftWork w, int start)
+{
+    const int j = threadIdx.x;
+    if (j < w.d) w.mean[j] = w.data[(size_t)start * w.d + j];        // :58  myMean = data.row(stInd)
+    if (j < 4) w.out[j] = 0;
+}
+
+// k_ms_collect, run only once the climb has ended (converged or dead end)
+__global__ void __launch_bounds__(256)
+k_ms_collect_if_done(MeanShiftWork w)
+{
+    if (!(w.out[1] || w.out[3])) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w.n) return;
+    const int v = w.votes[i];
+    if (v > 0) {
+        const int pos = atomicAdd(&w.out[2], 1);
+        w.list[2 * pos] = i;
+        w.list[2 * pos + 1] = v;
+        w.votes[i] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_ms_publish(MeanShiftWork w, MeanShiftResultBlock* r)
+{
+    const int j = threadIdx.x;
+    if (j < 4) r->out[j] = w.out[j];
+    if (j < MS_MAXD) r->mean[j] = j < w.d ? w.mean[j] : 0.0;
+}
+
+hipError_t launch_ms_climb(const MeanShiftWork& w, int start, double band_sq, double stop_thresh, int iterations,
+                           MeanShiftResultBlock* result_dev, hipStream_t s)
+{
+    if (w.d > MS_MAXD) return hipErrorInvalidValue;
+    if (start >= 0) hipLaunchKernelGGL(k_ms_seed, dim3(1), dim3(64), 0, s, w, start);
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(k_ms_partial, dim3(MS_GROUPS), dim3(256), 0, s, w, band_sq);
+        hipLaunchKernelGGL(k_ms_update, dim3(1), dim3(64), 0, s, w, stop_thresh);
+    }
+    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256), dim3(256), 0, s, w);
+    hipLaunchKernelGGL(k_ms_publish, dim3(1), dim3(64), 0, s, w, result_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_ms_iterations(const MeanShiftWork& w, double band_sq, double stop_thresh, int iterations,
                                 hipStream_t s)
 {

@@ -88,6 +88,12 @@ struct MeanShiftWork {
 hipError_t launch_ms_iterations(const MeanShiftWork& w, double band_sq, double stop_thresh, int iterations,
                                 hipStream_t s);
 hipError_t launch_ms_collect(const MeanShiftWork& w, hipStream_t s);
+// One climb without host round trips in between: seed the mean with row `start`, `iterations` climb
+// iterations, then — only if the climb has ended — compact the votes; finally the control words and
+// the mean are written to `result` (device address of a mapped pinned block: int out[4], double mean[16]).
+struct MeanShiftResultBlock { int out[4]; double mean[16]; };
+hipError_t launch_ms_climb(const MeanShiftWork& w, int start /* -1: continue the running climb */, double band_sq,
+                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, hipStream_t s);
 
 // --- expand.hip -------------------------------------------------------------
 struct Graph {              // symmetric weighted CSR in HBM

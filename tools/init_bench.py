@@ -10,6 +10,7 @@ e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2)
 t0 = time.time(); H, feat = e.local_homographies(0.005); t1 = time.time() - t0
 feat = np.where(np.isfinite(feat), feat, 1e300)
+if "MS_BATCH" in os.environ: e.set_tuning(7, int(os.environ["MS_BATCH"]))
 t0 = time.time(); modes, assign, k = e.mean_shift(feat, 2.2, 99); t2 = time.time() - t0
 sizes = np.bincount(assign[assign >= 0], minlength=k)
 print(f"N={N}: local homographies {t1*1e3:.1f} ms; mean shift {t2:.2f} s -> {k} modes, {int((sizes>=3).sum())} with >=3 points, largest {np.sort(sizes)[-5:]}")
