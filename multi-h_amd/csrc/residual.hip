@@ -76,7 +76,14 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     int cnt = 0;                                // lane mi of each wave counts model m0+mi
     static_assert(MC <= 64, "one counting lane per model");
 
-    for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
+    // psplit > 0: slice y takes tiles y, y+psplit, ...; psplit < 0 (tuning variant): -psplit contiguous slices
+    const int nslices = psplit > 0 ? psplit : -psplit;
+    const int ntiles_all = (N + TILE - 1) / TILE;
+    const int per_slice = (ntiles_all + nslices - 1) / nslices;
+    const int base0 = psplit > 0 ? blockIdx.y * TILE : blockIdx.y * per_slice * TILE;
+    const int base_end = psplit > 0 ? N : min(N, (int)(blockIdx.y + 1) * per_slice * TILE);
+    const int base_step = psplit > 0 ? psplit * TILE : TILE;
+    for (int base = base0; base < base_end; base += base_step) {
         double px[PPL], py[PPL], qx[PPL], qy[PPL];
         bool ok[PPL], pok[PPL], pokb[SYM ? PPL : 1];
         unsigned long long okm[PPL];            // ok[] as wave masks: the inlier ballot is (d2 < thr2) & okm
@@ -191,7 +198,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     if (threadIdx.x < MC && m0 + (int)threadIdx.x < M) {
         const int t = threadIdx.x;
         const int c = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
-        if (psplit == 1) counts[m0 + t] = c;
+        if (nslices == 1) counts[m0 + t] = c;
         else atomicAdd(&counts[m0 + t], c);           // integer: order-independent
     }
 }
@@ -218,13 +225,15 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         psplit = 4;
     }
     if (force_psplit > 0) psplit = force_psplit < ntiles ? force_psplit : ntiles;
+    bool contiguous = false;
+    if (force_psplit < 0) { psplit = -force_psplit < ntiles ? -force_psplit : ntiles; contiguous = true; }
     if (psplit > 1) {
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
         if (e != hipSuccess) return e;
     }
     dim3 grid(gx, psplit);
     hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM>), grid, dim3(256), 0, s, p.x1, p.y1,
-                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit);
+                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit);
     return hipGetLastError();
 }
 
@@ -233,6 +242,8 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
 {
     if (variant == -1)          // symmetric transfer error (north_star wording; extension)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant >= 200)         // 200 + s: s contiguous point slices instead of interleaved tiles (tuning)
+        return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, -(variant - 200));
     if (variant >= 100) {       // 100 + psplit: default kernel with a forced point split (tuning)
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 100);
     }
