@@ -9,9 +9,9 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, f"{tag}_rocprof_summary.txt"))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, f"{tag}_bench_under_trace.json"))
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if stats:        # gpurun merges into gpurun_out/, so older runs may still lie there: newest wins
+    shutil.copy(stats[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bench = os.path.join(ROOT, "gpurun_out", f"bench_{tag}.json")
 if os.path.exists(bench):
     shutil.copy(bench, os.path.join(dst, f"{tag}_bench.json"))
