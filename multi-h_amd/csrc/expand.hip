@@ -321,14 +321,91 @@ k_push_relabel(Graph g, const int* __restrict__ decided, int* cap, int* excess,
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
     int hu = LD(&height[u]);
     int sc = sink_cap[u];
-    const bool fits = (k1 - k0) <= SLOTS * LPN;
-    int nb[SLOTS];
+    if ((k1 - k0) <= SLOTS * LPN) {
+        // The usual case (degree <= 48).  Each lane keeps its <= 3 arcs (head, reverse arc) in registers
+        // and, while the site is active, fetches the next cycle's excess, capacities and neighbour
+        // heights TOGETHER at the end of the current cycle: one memory round trip per active cycle
+        // instead of three (excess -> capacity/height -> capacity again).  The lane that owns the
+        // chosen arc issues the capacity updates itself; lane 0 remains the only one that lowers
+        // excess[u], so its next load is ordered behind its own atomic.  Values read one cycle early
+        // are only ever conservative: cap(u->*) is lowered by this site alone, heights only guide.
+        int nb[SLOTS], rv[SLOTS], cq[SLOTS], hq[SLOTS];
 #pragma unroll
-    for (int q = 0; q < SLOTS; ++q) {
-        const int k = k0 + sub + q * LPN;
-        nb[q] = (fits && k < k1) ? g.col[k] : -1;
+        for (int q = 0; q < SLOTS; ++q) {
+            const int k = k0 + sub + q * LPN;
+            nb[q] = k < k1 ? g.col[k] : -1;
+            rv[q] = k < k1 ? g.rev[k] : 0;
+            cq[q] = 0; hq[q] = 0;
+        }
+        bool arcs_valid = false;
+        int e_next = (sub == 0) ? LD(&excess[u]) : 0;
+        for (int cyc = 0; cyc < CYCLES; ++cyc) {
+            if (hu >= n) break;
+            int e = __shfl(e_next, 0, LPN);
+            if (e > 0 && sc > 0) {                      // t-link: h(t) = 0, h(u) = 1
+                const int d = e < sc ? e : sc;
+                sc -= d;
+                if (sub == 0) { sink_cap[u] = sc; atomicSub(&excess[u], d); }
+                e -= d;
+            }
+            if (e <= 0) {                               // idle (or drained into the sink): just poll
+                e_next = (sub == 0) ? LD(&excess[u]) : 0;
+                arcs_valid = false;
+                continue;
+            }
+            if (!arcs_valid) {
+#pragma unroll
+                for (int q = 0; q < SLOTS; ++q) {
+                    cq[q] = nb[q] >= 0 ? LD(&cap[k0 + sub + q * LPN]) : 0;
+                    hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
+                }
+            }
+            long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                if (cq[q] > 0) {
+                    const long long cand = ((long long)hq[q] << 32) | (unsigned int)(k0 + sub + q * LPN);
+                    if (cand < key) key = cand;
+                }
+            }
+            key = row_min64(key);
+            if (key == 0x7fffffffffffffffll) {          // no way out at all
+                hu = n;
+                if (sub == 0) ST(&height[u], hu);
+                break;
+            }
+            const int hmin = (int)(key >> 32), kmin = (int)(key & 0xffffffffll);
+            if (hu > hmin) {
+                const int off = kmin - k0, owner = off % LPN, slot = off / LPN;
+                int c_mine = cq[0], v_mine = nb[0], r_mine = rv[0];
+#pragma unroll
+                for (int q = 1; q < SLOTS; ++q)
+                    if (slot == q) { c_mine = cq[q]; v_mine = nb[q]; r_mine = rv[q]; }
+                const int c = __shfl(c_mine, owner, LPN);
+                const int d = e < c ? e : c;
+                if (sub == owner) {
+                    atomicSub(&cap[kmin], d);
+                    atomicAdd(&cap[r_mine], d);
+                    atomicAdd(&excess[v_mine], d);
+                }
+                if (sub == 0) atomicSub(&excess[u], d);
+            } else {
+                hu = hmin + 1;
+                if (hu > n) hu = n;
+                if (sub == 0) ST(&height[u], hu);
+            }
+            // next cycle's inputs, all in flight together
+            e_next = (sub == 0) ? LD(&excess[u]) : 0;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                cq[q] = nb[q] >= 0 ? LD(&cap[k0 + sub + q * LPN]) : 0;
+                hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
+            }
+            arcs_valid = true;
+        }
+        return;
     }
-    for (int cyc = 0; cyc < CYCLES; ++cyc) {
+    for (int cyc = 0; cyc < CYCLES; ++cyc) {            // generic path: any degree
         if (hu >= n) break;
         // lane 0 reads the excess and broadcasts it: all lanes of the row act on ONE value
         int e = (sub == 0) ? LD(&excess[u]) : 0;
@@ -342,27 +419,10 @@ k_push_relabel(Graph g, const int* __restrict__ decided, int* cap, int* excess,
             if (e == 0) continue;
         }
         long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
-        if (fits) {
-            // heads preloaded: the capacity and the neighbour's height are independent loads
-            int cq[SLOTS], hq[SLOTS];
-#pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                cq[q] = nb[q] >= 0 ? LD(&cap[k0 + sub + q * LPN]) : 0;
-                hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
-            }
-#pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                if (cq[q] > 0) {
-                    const long long cand = ((long long)hq[q] << 32) | (unsigned int)(k0 + sub + q * LPN);
-                    if (cand < key) key = cand;
-                }
-            }
-        } else {
-            for (int k = k0 + sub; k < k1; k += LPN) {
-                if (LD(&cap[k]) > 0) {
-                    const long long cand = ((long long)LD(&height[g.col[k]]) << 32) | (unsigned int)k;
-                    if (cand < key) key = cand;
-                }
+        for (int k = k0 + sub; k < k1; k += LPN) {
+            if (LD(&cap[k]) > 0) {
+                const long long cand = ((long long)LD(&height[g.col[k]]) << 32) | (unsigned int)k;
+                if (cand < key) key = cand;
             }
         }
         key = row_min64(key);
