@@ -597,6 +597,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 
     long long energy = 0, old_energy = 0;
     RET_IF(total_energy(g, potts, w, &energy, s));     // :1036
+    int bfs_need = w.bfs_batch;                        // relax launches before the first check of a relabel
 
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         old_energy = energy;
@@ -606,37 +607,34 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             hipLaunchKernelGGL(k_move_setup, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
                                w.cur_cost, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
             RET_IF(hipGetLastError());
-            RET_IF(fetch(w, s));
-            if (w.h_flags[F_OVERFLOW] || w.h_acc[A_EXCESS_SUM] > 0x7fffffffll) {
-                if (st) { stats.energy = -1; *st = stats; }
-                return hipErrorInvalidValue;           // int32 energy terms would overflow
-            }
-            // No excess anywhere: max-flow is 0, after == before, the move is rejected (:1259).
-            if (w.h_flags[F_EXCESS_NODES] == 0) continue;
-
-            bool flow_needed = true;
-            if (w.reduce_rounds > 0) {
-                // dominance reduction to its fixed point: a launch that changed nothing ends it
-                for (;;) {
-                    // two launches per host check; only the second one's flag decides (a launch that
+            // The first host check of the move looks at the set-up counters (overflow, number of sites
+            // with excess) and, in the same round trip, at the first batch of the dominance reduction.
+            bool flow_needed = true, first_check = true, skip_move = false;
+            for (;;) {
+                if (w.reduce_rounds > 0) {
+                    // four launches per host check; only the last one's flag decides (a launch that
                     // changed nothing is the fixed point)
-                    hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
-                                       w.flags, &w.flags[F_SCRATCH], w.reduce_rounds);
-                    hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
-                                       w.flags, &w.flags[F_CHANGED], w.reduce_rounds);
-                    stats.reduce_launches += 2;
+                    for (int b = 0; b < 4; ++b)
+                        hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
+                                           w.flags, &w.flags[b == 3 ? F_CHANGED : F_SCRATCH], w.reduce_rounds);
+                    stats.reduce_launches += 4;
                     hipLaunchKernelGGL(k_count_undecided, grid1, blk, 0, s, g.n, w.excess, w.decided, w.flags);
                     RET_IF(hipGetLastError());
-                    RET_IF(fetch(w, s));
-                    if (w.h_flags[F_OVERFLOW]) {
-                        if (st) { stats.energy = -1; *st = stats; }
-                        return hipErrorInvalidValue;
-                    }
-                    if (!w.h_flags[F_CHANGED]) break;
                 }
+                RET_IF(fetch(w, s));
+                if (w.h_flags[F_OVERFLOW] || (first_check && w.h_acc[A_EXCESS_SUM] > 0x7fffffffll)) {
+                    if (st) { stats.energy = -1; *st = stats; }
+                    return hipErrorInvalidValue;       // int32 energy terms would overflow
+                }
+                // No excess anywhere: max-flow is 0, after == before, the move is rejected (:1259).
+                if (first_check && w.h_flags[F_EXCESS_NODES] == 0) { skip_move = true; break; }
+                first_check = false;
+                if (w.reduce_rounds <= 0) break;
                 // no undecided site holds excess: nothing can flow any more, the residual graph is final
                 flow_needed = w.h_flags[F_UNDECIDED_EXCESS] != 0;
+                if (!w.h_flags[F_CHANGED]) break;
             }
+            if (skip_move) continue;
             if (flow_needed) ++stats.flow_moves;
 
             for (int round = 0; round < 100000; ++round) {
@@ -646,17 +644,24 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                 // Batches of relaxation launches; the flag of the LAST launch of a batch decides
                 // (a launch that lowered nothing is a fixed point).  The active count is taken
                 // in the same batch: it is only trusted when that last launch changed nothing.
-                for (;;) {
-                    for (int b = 0; b < w.bfs_batch; ++b) {
+                // The first batch is as long as the previous relabel needed (relabels of one move, and of
+                // neighbouring moves, converge in similar numbers of launches): usually one host check.
+                int launched = 0;
+                for (int batch = bfs_need;; batch = w.bfs_batch) {
+                    for (int b = 0; b < batch; ++b) {
                         hipLaunchKernelGGL(k_bfs_relax, grid, blk, 0, s, g, w.decided, w.cap, w.height,
-                                           &w.flags[b == w.bfs_batch - 1 ? F_CHANGED : F_SCRATCH], w.bfs_rounds);
+                                           &w.flags[b == batch - 1 ? F_CHANGED : F_SCRATCH], w.bfs_rounds);
                         ++stats.bfs_launches;
                     }
+                    launched += batch;
                     hipLaunchKernelGGL(k_count_active, grid1, blk, 0, s, g.n, w.excess, w.height, w.decided, w.flags);
                     RET_IF(hipGetLastError());
                     RET_IF(fetch(w, s));
                     if (!w.h_flags[F_CHANGED]) break;
                 }
+                bfs_need = launched > bfs_need ? launched : bfs_need - 1;
+                if (bfs_need < w.bfs_batch) bfs_need = w.bfs_batch;
+                if (bfs_need > 12) bfs_need = 12;
                 if (w.h_flags[F_ACTIVE] == 0) break;
                 for (int b = 0; b < w.pr_batch; ++b) {
                     hipLaunchKernelGGL(k_push_relabel, grid, blk, 0, s, g, w.decided,
