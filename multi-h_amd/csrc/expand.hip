@@ -189,9 +189,10 @@ k_reduce(Graph g, int* cap, int* excess, int* sink_cap, int* decided, int* __res
     const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
     if (u >= g.n) return;
-    if (LD(&decided[u]) != 0) return;
+    const int du = LD(&decided[u]);                 // first-level loads issued together
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
     long long net = (long long)excess[u] - sink_cap[u];
+    if (du != 0) return;
     bool dirty = false, changed = false;
     int verdict = 0;
     for (int r = 0; r < ROUNDS; ++r) {
@@ -244,9 +245,11 @@ k_bfs_relax(Graph g, const int* __restrict__ decided, const int* __restrict__ ca
     const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
     if (u >= g.n) return;
-    if (decided[u] != 0) return;
+    // all first-level loads issued together (the early return must not serialise them)
+    const int du = decided[u];
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
     int hu = LD(&height[u]);
+    if (du != 0) return;
     bool any = false;
     if (k1 - k0 <= SLOTS * LPN) {
         // The usual case (degree <= 48): each lane keeps its <= 3 residual arcs' heads in registers
@@ -316,11 +319,12 @@ k_push_relabel(Graph g, const int* __restrict__ decided, int* cap, int* excess,
     const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
     if (u >= g.n) return;
-    if (decided[u] != 0) return;
     const int n = g.n;
+    const int du = decided[u];                      // first-level loads issued together
     const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
     int hu = LD(&height[u]);
     int sc = sink_cap[u];
+    if (du != 0) return;
     if ((k1 - k0) <= SLOTS * LPN) {
         // The usual case (degree <= 48).  Each lane keeps its <= 3 arcs (head, reverse arc) in registers
         // and, while the site is active, fetches the next cycle's excess, capacities and neighbour
