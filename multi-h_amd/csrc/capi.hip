@@ -120,6 +120,22 @@ struct mh_engine {
 
 namespace {
 
+// No exception may cross the C ABI (include/multih_hip.h): host-side allocation failures and
+// anything else thrown by the standard library become a status code with the text in mh_last_error.
+template <typename Fn>
+int guarded(Fn&& fn)
+{
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        return fail(MH_ERR_INVALID, "out of host memory");
+    } catch (const std::exception& ex) {
+        return fail(MH_ERR_INVALID, std::string("internal error: ") + ex.what());
+    } catch (...) {
+        return fail(MH_ERR_INVALID, "internal error");
+    }
+}
+
 struct ScopedTimer {
     mh_engine* e;
     int k;
@@ -383,6 +399,7 @@ int mh_device_count(void)
 
 int mh_create(mh_engine** out, int device)
 {
+    return guarded([&]() -> int {
     if (!out) return fail(MH_ERR_INVALID, "out is null");
     *out = nullptr;
     int c = 0;
@@ -404,6 +421,7 @@ int mh_create(mh_engine** out, int device)
     e->stream = e->own_stream;
     *out = e;
     return MH_OK;
+    });
 }
 
 void mh_destroy(mh_engine* e)
@@ -435,36 +453,43 @@ void mh_destroy(mh_engine* e)
 
 int mh_set_params(mh_engine* e, double thr_F, double thr_H, double locality, double lambda, int min_inliers)
 {
+    return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (!(thr_H > 0.0) || !(lambda > 0.0)) return fail(MH_ERR_INVALID, "thr_hom and lambda must be positive");
     e->thr_F = thr_F; e->thr_H = thr_H; e->locality = locality; e->lambda = lambda;
     e->min_inliers = min_inliers;
     e->cost_L = 0;
     return MH_OK;
+    });
 }
 
 int mh_set_stream(mh_engine* e, void* hip_stream, int external)
 {
+    return guarded([&]() -> int {
     int rc0 = enter(e);
     if (rc0) return rc0;
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     e->stream = external ? (hipStream_t)hip_stream : e->own_stream;
     return MH_OK;
+    });
 }
 
 int mh_synchronize(mh_engine* e)
 {
+    return guarded([&]() -> int {
     int rc0 = enter(e);
     if (rc0) return rc0;
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     return MH_OK;
+    });
 }
 
 int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst_xy,
                            const double* affines, int n)
 {
+    return guarded([&]() -> int {
     int rc0 = enter(e);
     if (rc0) return rc0;
     if (!src_xy || !dst_xy || n <= 0) return fail(MH_ERR_INVALID, "src/dst must be non-null and n > 0");
@@ -496,20 +521,24 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
     e->g_rowptr.clear(); e->g_col.clear(); e->g_w.clear(); e->g_rev.clear();
     e->cost_L = 0;
     return MH_OK;
+    });
 }
 
 int mh_set_epipolar(mh_engine* e, const double F[9], const double e2[2])
 {
+    return guarded([&]() -> int {
     if (!e || !F || !e2) return fail(MH_ERR_INVALID, "null argument");
     for (int i = 0; i < 9; ++i) e->epi.F[i] = F[i];
     e->epi.ex = e2[0];
     e->epi.ey = e2[1];
     e->have_epi = true;
     return MH_OK;
+    });
 }
 
 int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col, int n)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!rowptr || n != e->n) return fail(MH_ERR_INVALID, "rowptr null or n != number of correspondences");
@@ -517,10 +546,12 @@ int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col, int n)
     rc = build_sym_graph(e, rowptr, col, n);
     if (rc) return rc;
     return upload_graph(e);
+    });
 }
 
 int mh_build_neighbors_knn(mh_engine* e, int k)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (k < 1 || k > 32 || k >= e->n) return fail(MH_ERR_INVALID, "k must be in [1, 32] and < n");
@@ -533,10 +564,12 @@ int mh_build_neighbors_knn(mh_engine* e, int k)
     rc = build_sym_graph(e, rowptr.data(), col.data(), e->n);
     if (rc) return rc;
     return upload_graph(e);
+    });
 }
 
 int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, long long* hits_out)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!(radius > 0.0)) return fail(MH_ERR_INVALID, "radius must be positive");
@@ -570,10 +603,12 @@ int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, l
     rc = build_sym_graph(e, rowptr.data(), col.data(), n);
     if (rc) return rc;
     return upload_graph(e);
+    });
 }
 
 int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
 {
+    return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (!e->have_graph) return fail(MH_ERR_NOT_SET, "neighbour graph is not set");
     if (nnz) *nnz = (int)e->g_col.size();
@@ -581,10 +616,12 @@ int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
     if (col) std::copy(e->g_col.begin(), e->g_col.end(), col);
     if (w) std::copy(e->g_w.begin(), e->g_w.end(), w);
     return MH_OK;
+    });
 }
 
 int mh_propose_fund8(mh_engine* e, unsigned long long seed, long long first, int m)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (m <= 0) return fail(MH_ERR_INVALID, "m must be positive");
@@ -595,10 +632,12 @@ int mh_propose_fund8(mh_engine* e, unsigned long long seed, long long first, int
     HIPCHK(launch_fund8(e->pts(), seed, first, m, e->fund_samples.p, e->fund.p, e->stream));
     e->fm = m;
     return MH_OK;
+    });
 }
 
 int mh_get_fund_hypotheses(mh_engine* e, double* F, int* idx)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (e->fm <= 0) return fail(MH_ERR_NOT_SET, "no fundamental-matrix hypotheses; call mh_propose_fund8");
@@ -606,10 +645,12 @@ int mh_get_fund_hypotheses(mh_engine* e, double* F, int* idx)
     if (idx) HIPCHK(hipMemcpyAsync(idx, e->fund_samples.p, sizeof(int) * 8 * e->fm, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_score_sampson(mh_engine* e, double thr2, int* counts)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (e->fm <= 0) return fail(MH_ERR_NOT_SET, "no fundamental-matrix hypotheses; call mh_propose_fund8");
@@ -619,11 +660,13 @@ int mh_score_sampson(mh_engine* e, double thr2, int* counts)
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return MH_OK;
+    });
 }
 
 int mh_refit_fundamental(mh_engine* e, const double F_in[9], double thr2, int iterations, double F_out[9],
                          unsigned char* inlier_mask, int* inliers)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!F_in || !F_out || iterations < 1) return fail(MH_ERR_INVALID, "null F or iterations < 1");
@@ -641,10 +684,12 @@ int mh_refit_fundamental(mh_engine* e, const double F_in[9], double thr2, int it
     if (inliers) HIPCHK(hipMemcpyAsync(inliers, e->fund_inl.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_epipoles(mh_engine*, const double F[9], double e1[2], double e2[2])
 {
+    return guarded([&]() -> int {
     if (!F || !e1 || !e2) return fail(MH_ERR_INVALID, "null argument");
     for (int which = 0; which < 2; ++which) {
         double A[9], V[9], D[3];
@@ -664,11 +709,13 @@ int mh_epipoles(mh_engine*, const double F[9], double e1[2], double e2[2])
         out[1] = V[1 * 3 + jm] / V[2 * 3 + jm];
     }
     return MH_OK;
+    });
 }
 
 int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypotheses, double thr, double F[9],
                             double e2[2], unsigned char* inlier_mask, int* inliers)
 {
+    return guarded([&]() -> int {
     if (!F || !e2) return fail(MH_ERR_INVALID, "null output");
     int rc = mh_propose_fund8(e, seed, 0, hypotheses);
     if (rc) return rc;
@@ -688,11 +735,13 @@ int mh_estimate_fundamental(mh_engine* e, unsigned long long seed, int hypothese
     if (rc) return rc;
     double e1[2];
     return mh_epipoles(e, F, e1, e2);                  // M/MultiH.cpp:786-799
+    });
 }
 
 int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2], const double e2[2],
                               const unsigned char* in_mask, unsigned char* keep, double* refined)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!F || !e1 || !e2 || !keep || !refined) return fail(MH_ERR_INVALID, "null argument");
@@ -712,10 +761,12 @@ int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2
     HIPCHK(hipMemcpyAsync(refined, e->ref_out.p, sizeof(double) * 8 * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_local_homographies(mh_engine* e, double locality, double* H_out, double* feat_out)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!e->have_aff) return fail(MH_ERR_NOT_SET, "affinities are not set");
@@ -728,11 +779,13 @@ int mh_local_homographies(mh_engine* e, double locality, double* H_out, double* 
     if (feat_out) HIPCHK(hipMemcpyAsync(feat_out, e->loc_feat.p, sizeof(double) * 10 * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_width,
                   unsigned long long seed, double* modes, int max_modes, int* assign, int* n_modes)
 {
+    return guarded([&]() -> int {
     int rc = enter(e);
     if (rc) return rc;
     if (!data || n <= 0 || d <= 0 || d > 16 || !assign || !n_modes)
@@ -847,10 +900,12 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         for (int c = 0; c < (int)cent.size() && c < max_modes; ++c)
             for (int j = 0; j < d; ++j) modes[(size_t)c * d + j] = cent[c][j];
     return MH_OK;
+    });
 }
 
 int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int m)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (m <= 0) return fail(MH_ERR_INVALID, "m must be positive");
@@ -866,10 +921,12 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int 
     e->have_samples = true;
     e->cost_L = 0;
     return MH_OK;
+    });
 }
 
 int mh_set_models(mh_engine* e, const double* H, int m)
 {
+    return guarded([&]() -> int {
     if (!e || !H || m <= 0) return fail(MH_ERR_INVALID, "null argument or m <= 0");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(e->H.reserve((size_t)m * 9));
@@ -880,45 +937,55 @@ int mh_set_models(mh_engine* e, const double* H, int m)
     e->have_samples = false;
     e->cost_L = 0;
     return MH_OK;
+    });
 }
 
 int mh_get_models(mh_engine* e, double* H)
 {
+    return guarded([&]() -> int {
     if (!e || !H) return fail(MH_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(e->device));
     if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
     HIPCHK(hipMemcpyAsync(H, e->H.p, sizeof(double) * 9 * e->m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_get_model_count(mh_engine* e, int* m)
 {
+    return guarded([&]() -> int {
     if (!e || !m) return fail(MH_ERR_INVALID, "null argument");
     *m = e->m;
     return MH_OK;
+    });
 }
 
 int mh_get_samples(mh_engine* e, int* idx)
 {
+    return guarded([&]() -> int {
     if (!e || !idx) return fail(MH_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(e->device));
     if (!e->have_samples) return fail(MH_ERR_NOT_SET, "no sampled batch; call mh_propose_dlt4");
     HIPCHK(hipMemcpyAsync(idx, e->samples.p, sizeof(int) * 4 * e->m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_set_residual_mode(mh_engine* e, int mode)
 {
+    return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (mode != MH_RESIDUAL_FORWARD && mode != MH_RESIDUAL_SYMMETRIC) return fail(MH_ERR_INVALID, "unknown residual mode");
     e->residual_mode = mode;
     return MH_OK;
+    });
 }
 
 int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* counts)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     HIPCHK(e->counts.reserve(e->m));
@@ -938,10 +1005,12 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return MH_OK;
+    });
 }
 
 int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     e->ldr = residual_ld(e->n);
@@ -960,10 +1029,12 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
         HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
     if (R_host || counts) HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     if (!e->R.p || e->ldr <= 0) return fail(MH_ERR_NOT_SET, "residual matrix has not been computed");
@@ -974,10 +1045,12 @@ int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
                             hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int* labels)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     if (idx < 0 || idx >= e->m || !labels) return fail(MH_ERR_INVALID, "bad model index or null labels");
@@ -987,10 +1060,12 @@ int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_value, int
     HIPCHK(hipMemcpyAsync(labels, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int label_value, int* labels)
 {
+    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!H || !labels) return fail(MH_ERR_INVALID, "null homography or labels");
@@ -1002,10 +1077,12 @@ int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int lab
     HIPCHK(hipMemcpyAsync(labels, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_inlier_moments(mh_engine* e, double thr2, double* moments, double* min_eig)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     HIPCHK(e->moments.reserve((size_t)e->m * 6));
@@ -1017,10 +1094,12 @@ int mh_inlier_moments(mh_engine* e, double thr2, double* moments, double* min_ei
         HIPCHK(hipMemcpyAsync(min_eig, e->min_eig.p, sizeof(double) * e->m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+    });
 }
 
 int mh_data_cost(mh_engine* e, int* cost)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     rc = do_data_cost(e);
@@ -1030,10 +1109,12 @@ int mh_data_cost(mh_engine* e, int* cost)
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return MH_OK;
+    });
 }
 
 int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy, int* cycles)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     const int* init_dev = nullptr;
@@ -1054,10 +1135,12 @@ int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return MH_OK;
+    });
 }
 
 int mh_get_expand_stats(mh_engine* e, long long stats[8])
 {
+    return guarded([&]() -> int {
     if (!e || !stats) return fail(MH_ERR_INVALID, "null argument");
     stats[0] = e->last_expand.cycles;
     stats[1] = e->last_expand.moves;
@@ -1068,10 +1151,12 @@ int mh_get_expand_stats(mh_engine* e, long long stats[8])
     stats[6] = e->last_expand.reduce_launches;
     stats[7] = e->last_expand.flow_moves;
     return MH_OK;
+    });
 }
 
 int mh_reestimate(mh_engine* e, const int* labels, double* H_out)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     if (!labels) return fail(MH_ERR_INVALID, "labels is null");
@@ -1091,10 +1176,12 @@ int mh_reestimate(mh_engine* e, const int* labels, double* H_out)
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return MH_OK;
+    });
 }
 
 int mh_labeling_step(mh_engine* e, int warm, int* labeling, double* energy, int* cycles)
 {
+    return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
     if (!labeling) return fail(MH_ERR_INVALID, "labeling is null");
@@ -1128,10 +1215,12 @@ int mh_labeling_step(mh_engine* e, int warm, int* labeling, double* energy, int*
     HIPCHK(hipStreamSynchronize(e->stream));
     if (energy) *energy = (double)en;
     return MH_OK;
+    });
 }
 
 int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long* bytes)
 {
+    return guarded([&]() -> int {
     if (!e || !ptr_dev || !bytes) return fail(MH_ERR_INVALID, "null argument");
     switch (which) {
     case MH_BUF_COUNTS: *ptr_dev = e->counts.p; *bytes = sizeof(int) * (size_t)e->m; break;
@@ -1143,27 +1232,33 @@ int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long
     }
     if (!*ptr_dev) return fail(MH_ERR_NOT_SET, "buffer has not been produced yet");
     return MH_OK;
+    });
 }
 
 int mh_profile_enable(mh_engine* e, int on)
 {
+    return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     e->profiling = on != 0;
     return MH_OK;
+    });
 }
 
 int mh_profile_reset(mh_engine* e)
 {
+    return guarded([&]() -> int {
     int rc0 = enter(e);
     if (rc0) return rc0;
     HIPCHK(hipStreamSynchronize(e->stream));
     resolve_timers(e);
     for (int k = 0; k < MH_K_COUNT_; ++k) { e->timers[k].launches = 0; e->timers[k].total_ms = 0.0; }
     return MH_OK;
+    });
 }
 
 int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms)
 {
+    return guarded([&]() -> int {
     if (!e || kernel < 0 || kernel >= MH_K_COUNT_) return fail(MH_ERR_INVALID, "bad kernel id");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1171,10 +1266,12 @@ int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms)
     if (launches) *launches = e->timers[kernel].launches;
     if (total_ms) *total_ms = e->timers[kernel].total_ms;
     return MH_OK;
+    });
 }
 
 int mh_set_tuning(mh_engine* e, int key, int value)
 {
+    return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
     if (key == 1) { e->tune_score_variant = value; return MH_OK; }
@@ -1182,6 +1279,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
+    });
 }
 
 } // extern "C"
