@@ -222,6 +222,8 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        which = ("BASELINE configs[2]" if (N, a.models, a.planes) == (50000, 100000, 10) else
+                 "BASELINE configs[1]" if (N, a.models, a.planes) == (5000, 10000, 3) else "custom size")
         out = {
             "metric": "scored homography hypotheses/sec (50k pts x 100k models)",
             "value": total_hyp / dt,
@@ -236,7 +238,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{N} correspondences / {a.planes} planes, {M} DLT hypotheses per GPU per step "
-                                   f"(BASELINE configs[2]); propose+residual-matrix+score"
+                                   f"({which}); propose+residual-matrix+score"
                                    + ("+all-gather" if world > 1 else "") + "+argmax",
                        "points": N, "models_per_gpu": M, "planes": a.planes, "thr": thr,
                        "parallelism": f"hypothesis-sharded x{world}", "residual_variant": a.variant},
