@@ -205,6 +205,21 @@ def main():
     n_sc, ms_sc = eng.profile_get(2)         # MH_K_SCORE
     eng.profile_enable(False)
     fused_ms = ms_sc / max(n_sc, 1)
+    # Also outside the timed region: the same residual kernel with fused multiply-adds (tuning variant 10,
+    # 20 instead of 28 FP64 operations per pair).  It is NOT bit-exact with the reference and never the
+    # product path; it is measured to show what the exact-rounding requirement costs.
+    eng.set_tuning(0, 10)
+    eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
+    eng.synchronize()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for _ in range(5):
+        eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
+    eng.synchronize()
+    n_ct, ms_ct = eng.profile_get(1)
+    eng.profile_enable(False)
+    eng.set_tuning(0, a.variant)
+    contracted_ms = ms_ct / max(n_ct, 1)
     avg_res_ms = ms_res / max(n_res, 1)
     alg_bytes = 8.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
     achieved = alg_bytes / (avg_res_ms * 1e-3) / 1e9
@@ -246,6 +261,11 @@ def main():
             "pair_evals_per_s": total_hyp * N / dt,
             "kernel_ms": {"k_residual": avg_res_ms, "k_dlt4": ms_dlt / max(n_dlt, 1), "k_score_fused": fused_ms},
             "fused_score_hypotheses_per_s_per_gpu": M / (fused_ms * 1e-3),
+            "residual_kernel_relaxed_rounding": {"ms": contracted_ms, "GBps": alg_bytes / (contracted_ms * 1e-3) / 1e9,
+                                                 "frac_of_hbm_peak": alg_bytes / (contracted_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                 "bit_exact": False,
+                                                 "note": "fused multiply-adds, 20 instead of 28 FP64 ops per pair; "
+                                                         "measurement only, never the product path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes},

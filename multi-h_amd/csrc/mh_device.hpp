@@ -107,6 +107,34 @@ __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, d
     return d2;
 }
 
+// NOT the product arithmetic: the same residual with fused multiply-adds (20 FP64 operations per
+// pair instead of 28).  It rounds differently from the reference (last-bit differences in d2, and
+// therefore possibly different inlier decisions within an ulp of the threshold), so it exists only
+// as tuning variant 10 of the residual kernel, to measure what the exact-rounding requirement costs
+// (DESIGN.md section 7).
+__device__ __forceinline__ double fwd_d2_contracted(double h0, double h1, double h2, double h3, double h4,
+                                                    double h5, double h6, double h7, double h8, double x,
+                                                    double y, double x2, double y2)
+{
+    const double s = __builtin_fma(h6, x, __builtin_fma(h7, y, h8));
+    const double nx = __builtin_fma(h0, x, __builtin_fma(h1, y, h2));
+    const double ny = __builtin_fma(h3, x, __builtin_fma(h4, y, h5));
+    double r = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = nx * r;
+    double d = __builtin_fma(-s, q, nx);
+    const double u = __builtin_fma(d, r, q);
+    q = ny * r;
+    d = __builtin_fma(-s, q, ny);
+    const double v = __builtin_fma(d, r, q);
+    const double dx = x2 - u;
+    const double dy = y2 - v;
+    return __builtin_fma(dx, dx, dy * dy);
+}
+
 // Cyclic Jacobi eigen-solver for a small symmetric matrix (n <= 4), run by a
 // single thread.  Stands where the reference calls cv::eigen on 3x3 / 4x4
 // matrices (M/MultiH.cpp:459, :973).  a: n*n row-major (destroyed);

@@ -32,7 +32,7 @@ namespace mh {
 // WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
 // NT: non-temporal stores for the R stream.  FAST: shared-reciprocal division (mh_device.hpp).
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false>
+          bool SYM = false, bool CONTRACT = false>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -149,11 +149,15 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                         continue;
                     }
                     double d0s, d1s;
-                    const double d0 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                    const double d0 = CONTRACT ? fwd_d2_contracted(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                                                   py[2 * c], qx[2 * c], qy[2 * c])
+                                      : FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
                                                          py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c] && hok)
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
                                                     py[2 * c], qx[2 * c], qy[2 * c]);
-                    const double d1 = FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                    const double d1 = CONTRACT ? fwd_d2_contracted(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                                                   py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1])
+                                      : FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
                                                          py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1] && hok)
                                            : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
                                                     py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
@@ -204,7 +208,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false>
+          bool SYM = false, bool CONTRACT = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0)
@@ -232,7 +236,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         if (e != hipSuccess) return e;
     }
     dim3 grid(gx, psplit);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit);
     return hipGetLastError();
 }
@@ -256,6 +260,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // MC 8
     case 6: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // MC 32
     case 7: return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);    // store-only calibration
+    case 10: return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // fused multiply-adds: NOT bit-exact, measurement only
     case 8: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 8
     case 9: return launch_rs<6, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 6
     default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);               // PPL 4, MC 16, plain 16-B stores

@@ -359,6 +359,28 @@ def test_shared_reciprocal_precondition_boundaries(engine, oracle, symmetric):
     assert 0.05 < np.isfinite(R_ref).mean() < 0.9999 and ref_cnt.sum() > 0     # both regimes present
 
 
+def test_contracted_variant_is_close_but_not_the_product(engine, synth, oracle):
+    """Tuning variant 10 of the residual kernel uses fused multiply-adds (measurement of what exact
+    rounding costs).  It must stay a close approximation — and the default
+    must stay bit-exact whatever was selected before."""
+    sc = synth.make_scene(3000, 3, seed=31, with_neighbours=False)
+    H = _models(sc, np.random.default_rng(31), extra=20)
+    _load(engine, sc, neighbours=False)
+    engine.set_models(H)
+    R_ref = oracle.residual_matrix(sc.src, sc.dst, H)
+    try:
+        engine.set_tuning(0, 10)
+        R_c, cnt_c = engine.residual_matrix(THR2)
+    finally:
+        engine.set_tuning(0, 0)
+    R, cnt = engine.residual_matrix(THR2)
+    assert np.array_equal(R.view(np.uint64), R_ref.view(np.uint64))
+    rel = np.abs(R_c - R_ref) / np.maximum(R_ref, 1e-300)
+    assert np.nanmax(rel) < 1e-6 and np.median(rel) < 1e-14
+    assert not np.array_equal(R_c.view(np.uint64), R_ref.view(np.uint64))       # it really is different arithmetic
+    assert np.abs(cnt_c - cnt).max() <= 2
+
+
 # ---- committed golden fixtures (labels pinned by the reference's own GCO build) -------------
 import os  # noqa: E402
 
