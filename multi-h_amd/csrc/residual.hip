@@ -38,14 +38,18 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
            const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
            long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
-           int psplit)
+           int psplit, int swapxy)
 {
     constexpr int CH = PPL / 2;                 // 16-B chunks per lane
     constexpr int WAVE_PTS = 64 * PPL;          // points per wave per tile
     constexpr int TILE = 4 * WAVE_PTS;          // points per workgroup per tile
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * MC;
+    // swapxy (tuning): slice index in blockIdx.x, so that consecutive workgroups write neighbouring
+    // chunks of the same rows of R
+    const int bx = swapxy ? blockIdx.y : blockIdx.x;
+    const int by = swapxy ? blockIdx.x : blockIdx.y;
+    const int m0 = bx * MC;
 
     // Stage this workgroup's MC x 9 coefficients in LDS once; the sweep reads them
     // back with wave-uniform (broadcast) ds_reads.  Keeping them in SGPRs instead
@@ -80,8 +84,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     const int nslices = psplit > 0 ? psplit : -psplit;
     const int ntiles_all = (N + TILE - 1) / TILE;
     const int per_slice = (ntiles_all + nslices - 1) / nslices;
-    const int base0 = psplit > 0 ? blockIdx.y * TILE : blockIdx.y * per_slice * TILE;
-    const int base_end = psplit > 0 ? N : min(N, (int)(blockIdx.y + 1) * per_slice * TILE);
+    const int base0 = psplit > 0 ? by * TILE : by * per_slice * TILE;
+    const int base_end = psplit > 0 ? N : min(N, (by + 1) * per_slice * TILE);
     const int base_step = psplit > 0 ? psplit * TILE : TILE;
     for (int base = base0; base < base_end; base += base_step) {
         double px[PPL], py[PPL], qx[PPL], qy[PPL];
@@ -211,7 +215,7 @@ template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, b
           bool SYM = false, bool CONTRACT = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
-                            int force_psplit = 0)
+                            int force_psplit = 0, int swapxy = 0)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     const int gx = (M + MC - 1) / MC;
@@ -236,8 +240,9 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         if (e != hipSuccess) return e;
     }
     dim3 grid(gx, psplit);
+    if (swapxy) grid = dim3(psplit, gx);
     hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT>), grid, dim3(256), 0, s, p.x1, p.y1,
-                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit);
+                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy);
     return hipGetLastError();
 }
 
@@ -246,6 +251,8 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
 {
     if (variant == -1)          // symmetric transfer error (north_star wording; extension)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant >= 300)         // 300 + s: s interleaved slices with the slice index as the fastest grid dimension (tuning)
+        return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 300, 1);
     if (variant >= 200)         // 200 + s: s contiguous point slices instead of interleaved tiles (tuning)
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, -(variant - 200));
     if (variant >= 100) {       // 100 + psplit: default kernel with a forced point split (tuning)
