@@ -19,7 +19,8 @@ s = open(os.path.join(src, "summary.txt")).read()
 
 
 def grab(counter):
-    m = re.search(r"k_residual<4, 16, true.*?%s\s+launches=\s*(\d+)\s+avg=([0-9.e+]+)" % counter, s)
+    # the product kernel: <PPL 4, MC 16, WRITE_R, !MASK, !NT, FAST, !CALIB, !HSGPR, !SYM, !CONTRACT>
+    m = re.search(r"k_residual<4, 16, true, false, false, true, false, false, false, false>\s+%s\s+launches=\s*(\d+)\s+avg=([0-9.e+]+)" % counter, s)
     return float(m.group(2)), int(m.group(1))
 
 

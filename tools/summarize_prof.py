@@ -14,10 +14,12 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         agg = collections.defaultdict(lambda: [0, 0.0])
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                k = (row.get("Kernel_Name", "?")[:60], row.get("Counter_Name", "?"))
+                name = row.get("Kernel_Name", "?")
+                name = name[:name.index("(")] if "(" in name else name      # keep the template arguments: variants differ there
+                k = (name.replace("void ", "")[:100], row.get("Counter_Name", "?"))
                 agg[k][0] += 1
                 agg[k][1] += float(row.get("Counter_Value", 0) or 0)
         print("== PMC:", os.path.relpath(f, out))
         for (kn, cn), (n, tot) in sorted(agg.items()):
             if "k_residual" in kn or "k_dlt4" in kn:
-                print(f"   {kn:60s} {cn:24s} launches={n:4d} avg={tot/n:.6g}")
+                print(f"   {kn:92s} {cn:24s} launches={n:4d} avg={tot/n:.6g}")
