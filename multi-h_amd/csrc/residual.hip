@@ -249,8 +249,10 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s)
 {
-    if (variant == -1)          // symmetric transfer error (north_star wording; extension, see DESIGN.md)
+    if (variant == -2)          // symmetric mode at PPL 2 (tuning; PPL 4 measured 3 % faster)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant == -1)          // symmetric transfer error (north_star wording; extension, see DESIGN.md)
+        return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     if (variant >= 300)         // 300 + s: s interleaved slices with the slice index as the fastest grid dimension (tuning)
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 300, 1);
     if (variant >= 200)         // 200 + s: s contiguous point slices instead of interleaved tiles (tuning)
@@ -278,8 +280,8 @@ hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
                         const unsigned char* mask, int* counts, int variant, hipStream_t s)
 {
     if (variant == -1) {
-        if (mask) return launch_rs<2, 16, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
-        return launch_rs<2, 16, false, false, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+        if (mask) return launch_rs<4, 16, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
+        return launch_rs<4, 16, false, false, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
     }
     if (mask) return launch_rs<4, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
     switch (variant) {
