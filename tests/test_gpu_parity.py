@@ -453,6 +453,23 @@ def test_full_size_properties_50k_x_100k(engine, synth, oracle):
         assert np.array_equal(a[both].view(np.uint64), b[both].view(np.uint64))
 
 
+def test_full_size_labeling_equals_the_reference_gco(engine, synth, oracle):
+    """BASELINE's 50 000 correspondences / 10 planes: one LabelingStep on the GPU (data cost, alpha-
+    expansion with 0.9 M neighbour hits, label shift) against the reference's own GCoptimization
+    sources compiled unmodified (oracle/_ref) with its callback data cost — labels and energy
+    identical."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    sc = synth.make_scene(50000, 10, seed=1234)
+    _load(engine, sc)
+    H = sc.H_true * (1.0 + np.random.default_rng(0).normal(0, 1e-4, size=sc.H_true.shape))
+    engine.set_models(H)
+    lab, energy, cycles = engine.labeling_step(False, np.full(sc.n, -1, np.int32))
+    lab_r, e_r = oracle.ref_expand_formula(sc.src, sc.dst, H, LAM, THR2, sc.hit_rowptr, sc.hit_col)
+    assert int(energy) == e_r and np.array_equal(lab_r - 1, lab)
+    assert cycles >= 2 and (lab >= 0).sum() > 30000
+
+
 # ---- host class MultiH over the C ABI (integration) -----------------------------------------
 def test_host_multih_process_loop(mh, engine_lib, synth):
     import ctypes as C
