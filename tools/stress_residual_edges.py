@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Randomised stress of the residual sweep's shared-reciprocal preconditions (csrc/mh_device.hpp): many
+seeds of coordinates and coefficients spread over hundreds of binades, forward and symmetric mode,
+GPU vs oracle bit for bit (NaN-ness compared as such).  Exits non-zero on the first mismatch."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+mh = importlib.import_module("multi-h_amd")
+import oracle_lib as O
+budget = float(os.environ.get("SECONDS", 120))
+rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
+e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+thr2 = 2.2 ** 2
+t0 = time.time(); runs = 0
+pe = np.array([-1030, -600, -460, -451, -450, -449, -300, -256, -255, -254, -20, 0, 0, 0, 0, 7, 10, 118, 119, 120, 121, 257, 300, 600, 1000])
+while time.time() - t0 < budget:
+    n, m = int(rng.integers(1, 3000)), int(rng.integers(1, 200))
+    src = rng.uniform(1.0, 2.0, size=(n, 2)) * np.exp2(rng.choice(pe, size=(n, 2)).astype(np.float64)) * rng.choice([-1.0, 1.0], size=(n, 2))
+    dst = rng.uniform(1.0, 2.0, size=(n, 2)) * np.exp2(rng.choice(pe, size=(n, 2)).astype(np.float64)) * rng.choice([-1.0, 1.0], size=(n, 2))
+    k = n // 3
+    src[:k] = rng.uniform(0, 1000, size=(k, 2)); dst[:k] = rng.uniform(0, 1000, size=(k, 2))
+    H = rng.normal(size=(m, 9)) * np.exp2(rng.choice(pe, size=(m, 9)).astype(np.float64))
+    H[: m // 2] = rng.normal(size=(m // 2, 9)) * np.array([1, 1, 100, 1, 1, 100, 1e-3, 1e-3, 1])
+    sym = bool(rng.integers(0, 2))
+    e.set_correspondences(src, dst); e.set_models(H); e.set_residual_mode(sym)
+    with np.errstate(all="ignore"):
+        R, cnt = e.residual_matrix(thr2)
+        cnt2 = e.score(thr2)
+        R_ref = (O.residual_matrix_sym if sym else O.residual_matrix)(src, dst, H)
+        ref_cnt = (R_ref < thr2).sum(axis=1)
+    nan = np.isnan(R_ref)
+    ok = np.array_equal(np.isnan(R), nan) and np.array_equal(R[~nan].view(np.uint64), R_ref[~nan].view(np.uint64)) \
+        and np.array_equal(cnt, ref_cnt) and np.array_equal(cnt2, ref_cnt)
+    if not ok:
+        print("MISMATCH", dict(n=n, m=m, sym=sym, run=runs)); sys.exit(1)
+    runs += 1
+e.set_residual_mode(False)
+print(f"residual edge stress ok: {runs} random problems in {time.time() - t0:.0f} s")
