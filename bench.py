@@ -135,7 +135,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            except TypeError:                            # a torch without the device_id argument
+                dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
