@@ -10,9 +10,16 @@ One "step" = one pass of the propose-score hot path over one hypothesis batch:
 Workload at N=1 = BASELINE.json configs[2]: 50 000 correspondences / 10 planes,
 100 000 hypotheses (the configuration the metric is quoted on; it fits one GPU:
 R is 40 GB of the 288 GB).  Inputs are resident in HBM before the timed region.
-Multi-GPU is weak scaling: every rank owns its own batch of M hypotheses
-(disjoint RNG counters), correspondences are replicated, the only collective is
-the all-gather of scores.
+Multi-GPU (`--gpus N`): the headline is BASELINE configs[3] — ONE batch of 100 000
+hypotheses split across the ranks (`"scaling": "strong"`: the total work per step is the
+same for every N), correspondences replicated, the only collective the RCCL all-gather of
+the int32 scores.  The same run also times the weak-scaling variant (every rank owns its
+own 100 000-hypothesis batch, disjoint RNG counters) and reports it as `"weak_scaling"`.
+`--scaling weak` swaps the two.
+
+Launching: the driver starts one process per GPU with torch.distributed.run.  Run by hand
+as `python bench.py --gpus N` (no WORLD_SIZE in the environment) the script spawns the N
+ranks itself — before torch or the GPU is touched — and exits non-zero if any rank fails.
 
 Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` for
 the dominant kernel (k_residual, HBM-write bound) and `cpu_baseline` (the oracle
@@ -31,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+HBM_WRITE_CEILING_GBPS = 6240.0  # best pure streaming-store kernel on this chip (profiles/r01_store_bw.txt)
 
 
 def parse():
@@ -42,8 +50,9 @@ def parse():
     ap.add_argument("--planes", type=int, default=10)
     ap.add_argument("--models", type=int, default=100000, help="hypotheses per GPU per step")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--variant", type=int, default=0, help="residual-kernel tuning variant (0 = default)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="headline mode for N > 1: strong = one batch of --models split over the ranks (BASELINE "
+                         "configs[3]); weak = --models per rank.  The other mode is timed too and reported alongside.")
     ap.add_argument("--cpu-sample", type=int, default=150000, help="hypotheses in the CPU baseline sample (about 13 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -111,8 +120,43 @@ def labeling_extra(mh, eng, a, thr2, lam):
     return out
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of a
+    parent that never touches torch or the GPU (no re-exec of a process that has).  Rank 0 inherits
+    stdout, so its JSON line is this command's output.  Any failing rank ends the run non-zero."""
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,32 +189,12 @@ def main():
     thr, lam = 2.2, 0.5                      # harness defaults, M/main.cpp:55-59
     thr2 = thr * thr
     sc = mh.synth.make_scene(a.points, a.planes, seed=a.seed, with_neighbours=False)
-    if a.scaling == "weak":
-        sizes = [a.models] * world                       # every GPU scores its own batch of M
-    else:
-        sizes = sharding.shard_counts(a.models, world)   # one batch of M split across the GPUs
-    M = sizes[rank]
     N = sc.n
 
     eng = mh.Engine(local_rank, 2.6, thr, 0.005, lam, 20)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_correspondences(sc.src, sc.dst, sc.aff)
     eng.set_epipolar(sc.F, sc.e2)
-    eng.set_tuning(0, a.variant)
-
-    gathered = torch.empty(sum(sizes), dtype=torch.int32, device=dev) if world > 1 else None
-
-    def step(i: int):
-        if a.scaling == "weak":
-            first = sharding.batch_first(i, world, rank, M)     # disjoint RNG counters per (step, rank)
-        else:
-            first = i * a.models + sharding.shard_range(a.models, world, rank)[0]
-        eng.propose_dlt4(a.seed, first, M)
-        eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
-        ptr, nbytes = eng.device_buffer(0)
-        counts = torch.as_tensor(_DevView(ptr, M, "<i4"), device=dev)
-        scores = sharding.gather_scores(counts, world, out=gathered, sizes=sizes)
-        return sharding.select_best(scores)
 
     def fence():
         torch.cuda.synchronize()
@@ -178,26 +202,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    fence()
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    last = None
-    for i in range(a.steps):
-        last = step(a.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    eng.profile_enable(False)
+    def run_mode(scaling: str, steps: int, warmup: int):
+        """`warmup` untimed steps, then exactly `steps` timed ones between two fences; max over ranks."""
+        if scaling == "weak":
+            sizes = [a.models] * world                       # every GPU scores its own batch of M
+        else:
+            sizes = sharding.shard_counts(a.models, world)   # one batch of M split across the GPUs (configs[3])
+        M = sizes[rank]
+        gathered = torch.empty(sum(sizes), dtype=torch.int32, device=dev) if world > 1 else None
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        def step(i: int):
+            if scaling == "weak":
+                first = sharding.batch_first(i, world, rank, M)     # disjoint RNG counters per (step, rank)
+            else:
+                first = i * a.models + sharding.shard_range(a.models, world, rank)[0]
+            eng.propose_dlt4(a.seed, first, M)
+            eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
+            ptr, _ = eng.device_buffer(0)
+            counts = torch.as_tensor(_DevView(ptr, M, "<i4"), device=dev)
+            scores = sharding.gather_scores(counts, world, out=gathered, sizes=sizes)
+            return sharding.select_best(scores), scores
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        eng.profile_reset()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last = step(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        eng.profile_enable(False)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        n_res, ms_res = eng.profile_get(1)       # MH_K_RESIDUAL
+        n_dlt, ms_dlt = eng.profile_get(0)       # MH_K_DLT4
+        (best, score), scores = last
+        import hashlib
+        return {"sizes": sizes, "M": M, "dt": float(tt.item()), "res_ms": ms_res / max(n_res, 1),
+                "dlt_ms": ms_dlt / max(n_dlt, 1), "best_model": int(best.item()), "best_score": int(score.item()),
+                "scores_sha256": hashlib.sha256(scores.cpu().numpy().tobytes()).hexdigest()[:16]}
+
+    head = run_mode(a.scaling, a.steps, a.warmup)
+    other = None
     if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+        other = run_mode("weak" if a.scaling == "strong" else "strong", a.steps, a.warmup)
+    M, sizes, dt = head["M"], head["sizes"], head["dt"]
 
-    n_res, ms_res = eng.profile_get(1)       # MH_K_RESIDUAL
-    n_dlt, ms_dlt = eng.profile_get(0)       # MH_K_DLT4
     # Outside the timed region: the store-free fused score kernel on the last batch (SURVEY §8(d)
     # "fused score kernel: not HBM-bound"), reported next to the headline for context.
     eng.profile_reset()
@@ -208,29 +262,13 @@ def main():
     n_sc, ms_sc = eng.profile_get(2)         # MH_K_SCORE
     eng.profile_enable(False)
     fused_ms = ms_sc / max(n_sc, 1)
-    # Also outside the timed region: the same residual kernel with fused multiply-adds (tuning variant 10,
-    # 20 instead of 28 FP64 operations per pair).  It is NOT bit-exact with the reference and never the
-    # product path; it is measured to show what the exact-rounding requirement costs.
-    eng.set_tuning(0, 10)
-    eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
-    eng.synchronize()
-    eng.profile_reset()
-    eng.profile_enable(True)
-    for _ in range(5):
-        eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
-    eng.synchronize()
-    n_ct, ms_ct = eng.profile_get(1)
-    eng.profile_enable(False)
-    eng.set_tuning(0, a.variant)
-    contracted_ms = ms_ct / max(n_ct, 1)
-    avg_res_ms = ms_res / max(n_res, 1)
+    avg_res_ms = head["res_ms"]
     alg_bytes = 8.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
     achieved = alg_bytes / (avg_res_ms * 1e-3) / 1e9
 
-    out = None
     if rank == 0:
         total_hyp = float(sum(sizes)) * a.steps
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "residual_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -238,10 +276,14 @@ def main():
                     tj = json.load(f)
                 if tj.get("points") == N and tj.get("models") == M:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/residual_traffic.json (rocprofv3 --pmc passes of this command, tools/profile_bench.sh; not measured in this run)"
             except Exception:
                 traffic = None
-        which = ("BASELINE configs[2]" if (N, a.models, a.planes) == (50000, 100000, 10) else
-                 "BASELINE configs[1]" if (N, a.models, a.planes) == (5000, 10000, 3) else "custom size")
+        which = ("BASELINE configs[2]" if (N, a.models, a.planes, world) == (50000, 100000, 10, 1) else
+                 "BASELINE configs[3]" if (N, a.models, a.planes) == (50000, 100000, 10) and a.scaling == "strong" else
+                 "BASELINE configs[1]" if (N, a.models, a.planes, world) == (5000, 10000, 3, 1) else "custom size")
+        per = (f"one batch of {a.models} DLT hypotheses per step split over {world} GPU(s) ({M} on rank 0)"
+               if a.scaling == "strong" else f"{M} DLT hypotheses per GPU per step")
         out = {
             "metric": "scored homography hypotheses/sec (50k pts x 100k models)",
             "value": total_hyp / dt,
@@ -255,25 +297,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{N} correspondences / {a.planes} planes, {M} DLT hypotheses per GPU per step "
-                                   f"({which}); propose+residual-matrix+score"
-                                   + ("+all-gather" if world > 1 else "") + "+argmax",
-                       "points": N, "models_per_gpu": M, "planes": a.planes, "thr": thr,
-                       "parallelism": f"hypothesis-sharded x{world}", "residual_variant": a.variant},
+            "config": {"workload": f"{N} correspondences / {a.planes} planes, {per} ({which}); "
+                                   f"propose+residual-matrix+score" + ("+all-gather" if world > 1 else "") + "+argmax",
+                       "points": N, "models_per_step": int(sum(sizes)), "models_rank0": M, "planes": a.planes, "thr": thr,
+                       "parallelism": f"hypothesis-sharded x{world}"},
             "residual_kernel_GBps": achieved,
             "pair_evals_per_s": total_hyp * N / dt,
-            "kernel_ms": {"k_residual": avg_res_ms, "k_dlt4": ms_dlt / max(n_dlt, 1), "k_score_fused": fused_ms},
+            "kernel_ms": {"k_residual": avg_res_ms, "k_dlt4": head["dlt_ms"], "k_score_fused": fused_ms},
             "fused_score_hypotheses_per_s_per_gpu": M / (fused_ms * 1e-3),
-            "residual_kernel_relaxed_rounding": {"ms": contracted_ms, "GBps": alg_bytes / (contracted_ms * 1e-3) / 1e9,
-                                                 "frac_of_hbm_peak": alg_bytes / (contracted_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                 "bit_exact": False,
-                                                 "note": "fused multiply-adds, 20 instead of 28 FP64 ops per pair; "
-                                                         "measurement only, never the product path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes},
-            "best_model": int(last[0].item()), "best_score": int(last[1].item()),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes,
+                         "measured_write_ceiling_GBps": HBM_WRITE_CEILING_GBPS,
+                         "frac_of_measured_write_ceiling": achieved / HBM_WRITE_CEILING_GBPS},
+            "best_model": head["best_model"], "best_score": head["best_score"], "scores_sha256": head["scores_sha256"],
         }
+        if other is not None:
+            o_total = float(sum(other["sizes"])) * a.steps
+            out["weak_scaling" if a.scaling == "strong" else "strong_scaling"] = {
+                "value": o_total / other["dt"], "unit": "hypotheses/s", "ms_per_step": other["dt"] / a.steps * 1e3,
+                "models_per_step": int(sum(other["sizes"])), "kernel_ms": {"k_residual": other["res_ms"], "k_dlt4": other["dlt_ms"]},
+                "steps": a.steps, "warmup": a.warmup}
         if world == 1 and not a.no_cpu_baseline:
             cb, Hs, cs = cpu_baseline(sc, thr2, a.cpu_sample, a.seed)
             out["cpu_baseline"] = cb

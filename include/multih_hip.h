@@ -183,10 +183,17 @@ MH_API int mh_data_cost(mh_engine* e, int* cost);
  * labels: in = initial labeling in GCO numbering 0..Nh (NULL = all zero), out = result in GCO
  * numbering.  energy: final int32 energy; cycles: executed cycles. */
 MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy, int* cycles);
-/* Counters of the last alpha-expansion: {cycles, moves, accepted moves, push-relabel launches,
- * global-relabel launches, host synchronisations, dominance-reduction launches, moves that still
- * needed push-relabel after the reduction}. */
-MH_API int mh_get_expand_stats(mh_engine* e, long long stats[8]);
+/* Counters of the last alpha-expansion: {0 cycles, 1 moves, 2 accepted moves, 3 push phases, 4 relaxation
+ * intervals, 5 host synchronisations, 6 dominance-reduction launches, 7 moves that still needed
+ * push-relabel after the reduction, 8 kernel launches, 9 moves actually run (the others were skipped on the
+ * device as provably idempotent), 10 moves whose undecided core was not empty, 11 sum and 12 maximum of the
+ * core sizes, 13 grid barriers, 14 global relabels, 15 microseconds spent inside the solver launches, of which
+ * 16 inside grid barriers, 17 in global relabels and 18 in push phases (both including their barriers), 19 reserved}. */
+MH_API int mh_get_expand_stats(mh_engine* e, long long stats[20]);
+/* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
+ * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid
+ * barriers, 100 MHz ticks inside the launch, of which inside barriers}; all zero for moves that were skipped or had an empty core. */
+MH_API int mh_get_expand_trace(mh_engine* e, int* trace /* moves x 8 */, int moves);
 /* GetHomographyHAFNonminimal for every label (M/MultiH.cpp:913-989 + the 1/lambda rescale of
  * Homography_RefineHAFCallback.h:33-34).  labels: -1..Nh-1 per point.  Updates the current
  * model set in place; H_out (nullable) receives a host copy. */
@@ -210,8 +217,9 @@ MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);
 /* Tuning knobs for the sweeps of tools/ (defaults are the measured optima; results never depend on
  * them): key 0 residual-kernel variant, 1 score-kernel variant, 2..5 alpha-expansion schedule (relax
- * rounds per launch, relax launches per check, push cycles per launch, push launches per round),
- * 6 dominance-reduction rounds per launch (0 = off), 7 mean-shift iterations per host round trip. */
+ * rounds per barrier interval, most push cycles per phase, push phases per global relabel, workgroups of the solver
+ * launch), 6 dominance-reduction rounds per launch (0 = off), 7 mean-shift iterations per host round trip, 8 moves
+ * logged by mh_get_expand_trace (0 = off). */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);
 
 #ifdef __cplusplus

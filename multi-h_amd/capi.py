@@ -27,7 +27,7 @@ SYMBOLS = [
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
-    "mh_get_expand_stats", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
+    "mh_get_expand_stats", "mh_get_expand_trace", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
 
@@ -311,10 +311,17 @@ class Engine:
         return labels, energy.value, cycles.value
 
     def expand_stats(self):
-        st = (C.c_longlong * 8)()
+        st = (C.c_longlong * 20)()
         self._check(self.lib.mh_get_expand_stats(self._h, st))
-        return dict(zip(("cycles", "moves", "accepted", "pr_launches", "bfs_launches", "host_syncs",
-                         "reduce_launches", "flow_moves"), list(st)))
+        return dict(zip(("cycles", "moves", "accepted", "push_phases", "relax_intervals", "host_syncs",
+                         "reduce_launches", "flow_moves", "launches", "moves_run", "moves_solved",
+                         "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us"),
+                        list(st)))
+
+    def expand_trace(self, moves: int):
+        out = np.zeros((int(moves), 8), dtype=np.int32)
+        self._check(self.lib.mh_get_expand_trace(self._h, _p(out, C.c_int), int(moves)))
+        return out
 
     def reestimate(self, labels):
         labels = _i32(labels)

@@ -93,7 +93,10 @@ struct mh_engine {
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
-    DevBuf<int> ew_label, ew_cur, ew_cap, ew_excess, ew_sink, ew_height, ew_decided, ew_flags;
+    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_aux, ew_trace;
+    int trace_moves = 0;                     // > 0: k_solve logs 8 ints per move (mh_set_tuning key 8)
+    int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
+    DevBuf<unsigned char> ew_took;
     int cu_count = 256;
     DevBuf<long long> ew_acc;
     int* h_flags = nullptr;
@@ -112,7 +115,8 @@ struct mh_engine {
     int residual_mode = MH_RESIDUAL_FORWARD;
     int tune_ms_batch = 6;                   // mean-shift climb iterations per host round trip
     int tune_reduce = 4;                     // dominance-reduction rounds per launch (0 = off)
-    int tune_expand[4] = { 16, 2, 32, 8 };   // relax rounds/launch, relax launches/check, push cycles/launch, push launches/round
+    int tune_expand[4] = { 128, 256, 1, 256 };
+    int tune_push_mult = 4;                  // push cycles per phase = this x (depth of the last relabel + 3)  // solver: relax rounds per barrier interval, push cycles per phase, push phases per relabel, workgroups
     ExpandStats last_expand{};
 
     Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n }; }
@@ -279,18 +283,22 @@ int ensure_expand_work(mh_engine* e)
     HIPCHK(e->ew_label.reserve(n));
     HIPCHK(e->ew_cur.reserve(n));
     HIPCHK(e->ew_cap.reserve(nnz));
+    HIPCHK(e->ew_sent.reserve(nnz));
     HIPCHK(e->ew_excess.reserve(n));
     HIPCHK(e->ew_sink.reserve(n));
     HIPCHK(e->ew_height.reserve(n));
+    HIPCHK(e->ew_aux.reserve(2 * (size_t)n));
     HIPCHK(e->ew_decided.reserve(n));
-    HIPCHK(e->ew_flags.reserve(16));
-    HIPCHK(e->ew_acc.reserve(8));
+    HIPCHK(e->ew_flags.reserve(EXPAND_FLAG_WORDS));
+    HIPCHK(e->ew_acc.reserve(EXPAND_ACC_WORDS));
+    HIPCHK(e->ew_took.reserve((size_t)n + 2));
+    HIPCHK(e->ew_core.reserve((size_t)EXPAND_CORE_SHARDS * n));
     if (!e->h_flags) {
-        HIPCHK(hipHostMalloc((void**)&e->h_flags, sizeof(int) * 16, hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void**)&e->h_flags, sizeof(int) * EXPAND_HOST_WORDS, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_flags_dev, e->h_flags, 0));
     }
     if (!e->h_acc) {
-        HIPCHK(hipHostMalloc((void**)&e->h_acc, sizeof(long long) * 8, hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void**)&e->h_acc, sizeof(long long) * 16, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_acc_dev, e->h_acc, 0));
     }
     return MH_OK;
@@ -316,10 +324,21 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     int rc = ensure_expand_work(e);
     if (rc) return rc;
     Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size() };
-    ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_excess.p, e->ew_sink.p,
-                  e->ew_height.p, e->ew_decided.p, e->ew_flags.p, e->ew_acc.p, e->h_flags, e->h_acc, e->h_flags_dev,
-                  e->h_acc_dev, e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], e->tune_expand[3],
-                  e->tune_reduce };
+    // the solver launch must be resident as a whole (it synchronises through a grid barrier): at most half
+    // the CUs, so that engines of other processes sharing the GPU can never starve each other's launches
+    const int solve_grid = std::max(1, std::min(e->tune_expand[3], e->cu_count));
+    ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_sent.p, e->ew_excess.p, e->ew_sink.p,
+                  e->ew_height.p, e->ew_aux.p, e->ew_decided.p, e->ew_took.p, e->ew_core.p, e->ew_flags.p, e->ew_acc.p,
+                  e->h_flags, e->h_acc, e->h_flags_dev, e->h_acc_dev,
+                  e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], solve_grid, e->tune_push_mult, e->tune_reduce,
+                  nullptr, 0, -1 };
+    if (e->trace_moves > 0) {
+        HIPCHK(e->ew_trace.reserve(8 * (size_t)e->trace_moves + 4 * 2048));
+        HIPCHK(hipMemsetAsync(e->ew_trace.p, 0, sizeof(int) * (8 * (size_t)e->trace_moves + 4 * 2048), e->stream));
+        w.detail_move = e->detail_move;
+        w.trace = e->ew_trace.p;
+        w.trace_moves = e->trace_moves;
+    }
     const int potts = (int)std::round(100.0 * e->lambda);     // M/MultiH.h:41, MultiH.cpp:510
     ExpandStats st{};
     {
@@ -328,6 +347,11 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         hipError_t he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
         if (he == hipErrorInvalidValue && st.energy == -1)
             return fail(MH_ERR_OVERFLOW, "int32 energy term overflow in alpha-expansion");
+        if (he == hipErrorLaunchTimeOut && st.energy == -2)
+            return fail(MH_ERR_HIP, "alpha-expansion: the solver's grid barrier timed out (its workgroups were not all resident; "
+                                    "is the GPU shared with other persistent launches?)");
+        if (he == hipErrorLaunchTimeOut && st.energy == -3)
+            return fail(MH_ERR_HIP, "alpha-expansion: push-relabel did not converge within its iteration bound");
         HIPCHK(he);
     }
     e->last_expand = st;
@@ -442,6 +466,7 @@ void mh_destroy(mh_engine* e)
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
+    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_aux.release(); e->ew_trace.release();
     e->knn_tmp.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     if (e->h_ms) (void)hipHostFree(e->h_ms);
@@ -1138,18 +1163,46 @@ int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy
     });
 }
 
-int mh_get_expand_stats(mh_engine* e, long long stats[8])
+int mh_get_expand_stats(mh_engine* e, long long stats[20])
 {
     return guarded([&]() -> int {
     if (!e || !stats) return fail(MH_ERR_INVALID, "null argument");
-    stats[0] = e->last_expand.cycles;
-    stats[1] = e->last_expand.moves;
-    stats[2] = e->last_expand.accepted;
-    stats[3] = e->last_expand.pr_launches;
-    stats[4] = e->last_expand.bfs_launches;
-    stats[5] = e->last_expand.host_syncs;
-    stats[6] = e->last_expand.reduce_launches;
-    stats[7] = e->last_expand.flow_moves;
+    const ExpandStats& x = e->last_expand;
+    stats[0] = x.cycles;
+    stats[1] = x.moves;
+    stats[2] = x.accepted;
+    stats[3] = x.push_phases;
+    stats[4] = x.relax_intervals;
+    stats[5] = x.host_syncs;
+    stats[6] = x.reduce_launches;
+    stats[7] = x.flow_moves;
+    stats[8] = x.launches;
+    stats[9] = x.moves_run;
+    stats[10] = x.moves_solved;
+    stats[11] = x.core_sites;
+    stats[12] = x.core_max;
+    stats[13] = x.barriers;
+    stats[14] = x.outer_iterations;
+    stats[15] = (long long)(x.solve_ms * 1000.0);      // microseconds inside the solver launches
+    stats[16] = (long long)(x.barrier_ms * 1000.0);
+    stats[17] = (long long)(x.relax_ms * 1000.0);
+    stats[18] = (long long)(x.push_ms * 1000.0);
+    stats[19] = 0;
+    return MH_OK;
+    });
+}
+
+int mh_get_expand_trace(mh_engine* e, int* trace, int moves)
+{
+    return guarded([&]() -> int {
+    int rc = enter(e);
+    if (rc) return rc;
+    if (!trace || moves <= 0) return fail(MH_ERR_INVALID, "null trace or moves <= 0");
+    if (e->trace_moves <= 0 || !e->ew_trace.p) return fail(MH_ERR_NOT_SET, "tracing is off (mh_set_tuning key 8) or no expansion has run");
+    // rows [0, trace_moves): the moves; rows behind them: the relabel log of the detail move (key 9), two relabels per row
+    const int m = std::min(moves, e->trace_moves + 1024);
+    HIPCHK(hipMemcpyAsync(trace, e->ew_trace.p, sizeof(int) * 8 * (size_t)m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
     });
 }
@@ -1278,6 +1331,9 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
+    if (key == 8 && value >= 0 && value <= (1 << 20)) { e->trace_moves = value; return MH_OK; }
+    if (key == 9 && value >= -1) { e->detail_move = value; return MH_OK; }
+    if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -7,50 +7,102 @@
 // graph.h:478-488).  Energies are int32 like the reference's
 // (GCoptimization.h:166-170); totals are accumulated in int64 and checked.
 //
-// Per move (label alpha, fixed order 0..L-1, :1285-1286):
-//   k_move_setup   builds the binary energy's s-t graph on the PERSISTENT
-//                  symmetric CSR (only capacities change per move):
+// The whole sweep is driven from the device: the host enqueues FIVE launches per move and looks at
+// the control words once per cycle (the energy test of :1045).
+//
+// Per move (label alpha, fixed order 0..L-1, :1285-1286; t = running move index):
+//   k_move_setup   applies the previous accepted move (labels are updated lazily, see below), then
+//                  builds the binary energy's s-t graph on the PERSISTENT symmetric CSR (only
+//                  capacities change per move):
 //                    t-links  : add_term1(i, E0=cost(i,alpha), E1=cost(i,cur))   (:336-342)
 //                               + Potts terms against neighbours already at alpha (:360-362)
 //                               + the D part of add_term2 for j<i with different labels (energy.h:220)
 //                    n-links  : for active pair i>j: cap(i->j)=w*potts,
 //                               cap(j->i)= (l_i==l_j) ? w*potts : 0              (energy.h:221-252)
-//                  and turns t-links into excess / sink capacity (Graph::add_tweights keeps
-//                  only the difference).
-//   k_reduce       dominance reduction (exact): a site whose net source surplus exceeds the total
+//                  turns t-links into excess / sink capacity (Graph::add_tweights keeps only the
+//                  difference) and takes the first dominance verdict from the site's own numbers.
+//   k_reduce x2    dominance reduction (exact): a site whose net source surplus exceeds the total
 //                  capacity of its outgoing n-links is on the source side of EVERY minimum cut; one
 //                  whose net sink surplus exceeds its incoming capacity can always reach the sink.
 //                  Such sites are decided, their n-links are folded into the neighbours' t-links,
-//                  and the test cascades to a fixed point.  At 50k sites / 11 labels it settles
-//                  70-95 % of the sites of a move before any flow is pushed (the rest — points that
-//                  are inliers of both the current and the candidate plane — go to push-relabel).
-//   push-relabel   lock-free preflow push (one thread per site, agent-scope atomics on
-//                  excess and residual capacities, heights written only by their owner),
-//                  interleaved with exact global relabelling (chaotic min-relaxation from
-//                  the sink to a fixed point).  Finished when, right after a global
-//                  relabel, no site with positive excess can still reach the sink.
-//   cut read-out   the sites that cannot reach the sink in the residual graph
-//                  (height == n after the final relabel) are the SOURCE side and take
-//                  alpha (var 0, :429-433).  This is BK's what_segment rule (free nodes
-//                  default to SOURCE, graph.h:478-488) = the unique minimal sink side of
+//                  and the test cascades.  At 50k sites / 11 labels it settles 70-95 % of the sites
+//                  of a move before any flow is pushed.  The second launch appends the sites that
+//                  are still undecided to a compact list (the "core": points that are inliers of
+//                  both the current and the candidate plane, a few thousand sites).
+//   k_solve        ONE persistent launch over the core only (8 lanes per site, arcs in registers,
+//                  phases separated by a grid barrier): finishes the reduction cascade, then
+//                  alternates exact global relabelling (chaotic min-relaxation from the sink to a
+//                  fixed point) with lock-free preflow pushes (agent-scope atomics on excess and
+//                  residual capacities, heights written only by their owner) until, right after a
+//                  global relabel, no site with positive excess can still reach the sink.
+//                  Cut read-out: the sites that cannot reach the sink in the residual graph are the
+//                  SOURCE side and take alpha (var 0, :429-433).  This is BK's what_segment rule
+//                  (free nodes default to SOURCE, graph.h:478-488) = the unique minimal sink side of
 //                  any maximum (pre)flow, so labels are solver-independent (SURVEY A-1).
-//   k_delta/apply  accept iff the total energy strictly decreases (:1259,1273),
-//                  decided on the device from the int64 energy difference.
+//   k_delta        int64 energy difference of the candidate labeling; the last workgroup to finish
+//                  accepts the move iff the energy strictly decreases (:1259,1273) and records it in
+//                  the control words.  The labels themselves are rewritten by the NEXT launch that
+//                  walks the sites (the next k_move_setup, or k_apply_pending at the end of a cycle).
+//
+// Idempotent moves are skipped on the device: the expansion on alpha of a labeling that has not
+// changed since the previous expansion on alpha completed cannot lower the energy (every expansion
+// of f' = move_alpha(f) is an expansion of f, and f' was the minimum over those), so the reference
+// rejects it (:1259) and leaves the labels untouched.  Every launch of such a move returns at once.
+// The last cycle of every expansion (the one that confirms convergence) consists of such moves.
+//
 // A cycle ends with k_energy; the loop stops when the energy is unchanged (:1045).
 //
-// Roofline: irregular, latency/atomic bound (no dense tile anywhere); reported as
-// moves/s and launches per move, not as a bandwidth fraction.
+// Roofline: irregular, latency/atomic bound (no dense tile anywhere); reported as time per
+// LabelingStep, launches and grid barriers, not as a bandwidth fraction.
 
 #include "mh_kernels.hpp"
 
 namespace mh {
 
-enum { F_ACTIVE = 0, F_CHANGED = 1, F_EXCESS_NODES = 2, F_ACCEPTED = 3, F_OVERFLOW = 4, F_UNDECIDED_EXCESS = 5,
-       F_SCRATCH = 7 /* write-only sink for launches whose 'changed' flag is not looked at */, F_COUNT = 8 };
-enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_COUNT = 4 };
+// control words (int); the first EXPAND_HOST_WORDS are mirrored to the host
+enum { C_TLAST = 0,        // index of the last accepted move, -1 before the first
+       C_PEND = 1,         // alpha of an accepted move whose labels are not yet written, -1 none
+       C_ERROR = 2,        // sticky: ERR_*
+       C_ACCEPTED = 3,
+       C_EXCESS_NODES = 4,
+       C_ARRIVE = 5,       // arrivals at the first (flat) grid barrier of the running k_solve
+       C_TICKET = 6,       // finished workgroups of the running k_delta
+       C_FLOW_MOVES = 7,
+       C_CORE = 8,         // 8 shard counters of the core list
+       C_MOVES_SOLVED = 16, C_CORE_MAX = 17, C_MOVES_RUN = 18, C_XCD_USED = 19,
+       // grid barrier of k_solve, one 128-B line per XCD and one for the top level:
+       //   line + 0 census (workgroups on this XCD), + 2 .. 9 four 64-bit {arrivals, changed, active} words, + 10 .. 13 four hmax words
+       C_XCD = 64, C_LINE = 32, C_TOP = C_XCD + 8 * C_LINE,
+       // k_delta's "last workgroup" ticket, two levels: 16 sub-tickets (one line each), then C_TICKET
+       C_SUBTICKET = C_TOP + C_LINE, SUBTICKETS = 16,
+       C_COUNT = EXPAND_FLAG_WORDS };
+static_assert(C_SUBTICKET + SUBTICKETS * C_LINE <= C_COUNT, "control block too small");
+// 64-bit accumulators
+// (sums that every workgroup of a whole-graph launch contributes to are striped over STRIPES words, each on a
+// 128-B line of its own, so that the adds of a launch do not queue behind ONE address: 3 000 adds to one word
+// took 36 us; the reader adds the stripes up)
+constexpr int STRIPES = 64, STRIPE_LL = 16;
+enum { A_DELTA_S = 64, A_ENERGY_S = A_DELTA_S + STRIPES * STRIPE_LL, A_EXCESS_S = A_ENERGY_S + STRIPES * STRIPE_LL,
+       A_TOTAL = A_EXCESS_S + STRIPES * STRIPE_LL };
+static_assert(A_TOTAL <= EXPAND_ACC_WORDS, "accumulator block too small");
+enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_CORE_SUM = 3, A_OUTER = 4, A_RELAX = 5, A_PUSH = 6,
+       A_BARRIERS = 7, A_TICKS = 8, A_T_BAR = 9, A_T_RELAX = 10, A_T_PUSH = 11, A_COUNT = 16 /* mirrored to the host */ };
+enum { ERR_OVERFLOW = 1, ERR_BARRIER_TIMEOUT = 2, ERR_NO_CONVERGENCE = 3 };
 
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// Every launch of a move evaluates this on words that only EARLIER launches wrote.
+__device__ __forceinline__ bool move_is_skipped(const int* flags, int t, int L)
+{
+    return flags[C_ERROR] != 0 || (t >= L && flags[C_TLAST] <= t - L);
+}
+
+__global__ void k_ctl_init(int* __restrict__ flags, long long* __restrict__ acc)
+{
+    for (int t = threadIdx.x; t < C_COUNT; t += blockDim.x) flags[t] = (t == C_TLAST || t == C_PEND) ? -1 : 0;
+    for (int t = threadIdx.x; t < A_TOTAL; t += blockDim.x) acc[t] = 0;
+}
 
 __global__ void __launch_bounds__(256)
 k_init_labeling(const int* __restrict__ cost, int L, int n, const int* __restrict__ init,
@@ -86,427 +138,802 @@ k_argmin_labels(const int* __restrict__ cost, int L, int n, int* __restrict__ la
         if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd((unsigned long long*)&acc[A_ENERGY], (unsigned long long)s[0]);
+    if (threadIdx.x == 0)
+        atomicAdd((unsigned long long*)&acc[A_ENERGY_S + (blockIdx.x % STRIPES) * STRIPE_LL], (unsigned long long)s[0]);
 }
 
 // ---------------------------------------------------------------------------
-// Site-parallel kernels.  A site's arcs are contiguous in the CSR, so LPN = 16 consecutive lanes
-// (one DPP row; four sites per wavefront) scan them together: coalesced 64-B reads of col/cap,
-// one or two dependent load latencies per pass instead of one per arc, and width-16 shuffles for
-// the reductions.  With one thread per site these kernels took ~40 us each at N = 50k (eighteen
-// serialised uncached loads per thread at <1 wave per SIMD); the lane-parallel form is what
-// makes a move cost milliseconds.  All lanes of a site keep identical copies of the site's
-// scalars (height, excess, sink capacity); lane 0 alone writes.
+// Whole-graph kernels.  A site's arcs are contiguous in the CSR, so LPN = 16 consecutive lanes
+// (one DPP row; four sites per wavefront) scan them together: coalesced 64-B reads of col/cap and
+// width-16 shuffles for the reductions.  All lanes of a site keep identical copies of the site's
+// scalars; lane 0 alone writes.
 // ---------------------------------------------------------------------------
 constexpr int LPN = 16;
 constexpr int SITES_PER_BLOCK = 256 / LPN;
-constexpr int SLOTS = 3;              // arcs per lane kept in registers by the relax / push kernels
 
+template <int W>
 __device__ __forceinline__ int row_min(int v)
 {
 #pragma unroll
-    for (int m = LPN / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, LPN); v = o < v ? o : v; }
+    for (int m = W / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, W); v = o < v ? o : v; }
     return v;
 }
+template <int W>
 __device__ __forceinline__ long long row_min64(long long v)
 {
 #pragma unroll
-    for (int m = LPN / 2; m >= 1; m >>= 1) { const long long o = __shfl_xor(v, m, LPN); v = o < v ? o : v; }
+    for (int m = W / 2; m >= 1; m >>= 1) { const long long o = __shfl_xor(v, m, W); v = o < v ? o : v; }
     return v;
 }
+template <int W>
 __device__ __forceinline__ long long row_sum64(long long v)
 {
 #pragma unroll
-    for (int m = LPN / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPN);
+    for (int m = W / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, W);
     return v;
 }
 
+// `label` is read (neighbours) and written (own site, pending move) in the same launch: a neighbour
+// j with took[j] reads as `pa` whether or not its row has already stored the new label.
 __global__ void __launch_bounds__(256)
-k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
-             const int* __restrict__ label, const int* __restrict__ cur_cost,
+k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int t, int reduce_on,
+             int* label, int* __restrict__ cur_cost, const unsigned char* __restrict__ took,
              int* __restrict__ cap, int* __restrict__ excess, int* __restrict__ sink_cap,
              int* __restrict__ decided, int* __restrict__ flags, long long* __restrict__ acc)
 {
     const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
     if (i >= g.n) return;
-    const int li = label[i];
+    const int pa = flags[C_PEND];
+    int li = label[i];
+    int cc = cur_cost[i];
+    if (pa >= 0 && took[i]) {                        // applyNewLabeling of the previous move, :423-441
+        li = pa;
+        cc = cost[(size_t)i * L + pa];
+        if (sub == 0) { label[i] = pa; cur_cost[i] = cc; }
+    }
+    if (move_is_skipped(flags, t, L)) return;
     const int k0 = g.rowptr[i], k1 = g.rowptr[i + 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) acc[A_DELTA] = 0;     // k_delta of this move accumulates into it later
-    if (sub == 0) decided[i] = (li == alpha) ? 3 : 0;
     if (li == alpha) {
-        if (sub == 0) { excess[i] = 0; sink_cap[i] = 0; }
+        if (sub == 0) { decided[i] = 3; excess[i] = 0; sink_cap[i] = 0; }
         for (int k = k0 + sub; k < k1; k += LPN) cap[k] = 0;
         return;
     }
-    long long S = 0;
+    long long S = 0, out = 0, in = 0;
     for (int k = k0 + sub; k < k1; k += LPN) {
         const int j = g.col[k];
         const int wk = g.w[k] * potts;
-        const int lj = label[j];
+        int lj = label[j];
+        if (pa >= 0 && took[j]) lj = pa;
         if (lj == alpha) { S += wk; cap[k] = 0; }
-        else if (j < i) { if (li != lj) S += wk; cap[k] = wk; }
-        else { cap[k] = (li == lj) ? wk : 0; }
+        else if (j < i) { if (li != lj) S += wk; cap[k] = wk; out += wk; if (li == lj) in += wk; }
+        else { const int c = (li == lj) ? wk : 0; cap[k] = c; out += c; in += wk; }
     }
-    S = row_sum64(S) + cur_cost[i];
+    S = row_sum64<LPN>(S) + cc;
+    out = row_sum64<LPN>(out);
+    in = row_sum64<LPN>(in);
     if (sub != 0) return;
     const long long K = cost[(size_t)i * L + alpha];
     const long long tr = S - K;
-    if (tr > 0x7fffffffll || -tr > 0x7fffffffll) atomicExch(&flags[F_OVERFLOW], 1);
+    if (tr > 0x7fffffffll || -tr > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
     const int ex = tr > 0 ? (int)tr : 0;
     excess[i] = ex;
     sink_cap[i] = tr < 0 ? (int)(-tr) : 0;
-    if (ex > 0) {
-        atomicAdd(&flags[F_EXCESS_NODES], 1);
-        atomicAdd((unsigned long long*)&acc[A_EXCESS_SUM], (unsigned long long)ex);
+    // first dominance test (see k_reduce): nothing is decided yet, so there is nothing to fold
+    int verdict = 0;
+    if (reduce_on) {
+        if (tr > out) verdict = 1;
+        else if (-tr > in) verdict = 2;
     }
+    decided[i] = verdict;
+    // total excess of the move (the reference's flow counter is an int: Graph<int,int,int>), striped
+    if (ex > 0) atomicAdd((unsigned long long*)&acc[A_EXCESS_S + (blockIdx.x % STRIPES) * STRIPE_LL], (unsigned long long)ex);
 }
 
-__global__ void __launch_bounds__(256)
-k_bfs_init(int n, const int* __restrict__ decided, const int* __restrict__ sink_cap,
-           int* __restrict__ height)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int d = decided[i];
-    // decided sites keep their verdict: sink side -> 1 (< n, keeps its label), source side -> n
-    height[i] = (d == 2 || (d == 0 && sink_cap[i] > 0)) ? 1 : n;
-}
-
-// Dominance reduction to a fixed point (see the header).  net(u) = excess - sink_cap.  An undecided
-// site first folds its decided neighbours into its own t-link — a source-side neighbour v delivers
-// cap(v->u), a sink-side neighbour absorbs cap(u->v) — and clears both arcs, then tests
+// Dominance reduction (see the header).  net(u) = excess - sink_cap.  An undecided site first folds its
+// decided neighbours into its own t-link — a source-side neighbour v delivers cap(v->u), a sink-side
+// neighbour absorbs cap(u->v) — and clears both arcs, then tests
 //     net >  sum of cap(u->w) over undecided w   ->  source side in every minimum cut
 //    -net >  sum of cap(w->u) over undecided w   ->  residual sink capacity survives every max flow
 // Strict inequalities: ties stay undecided and go to push-relabel, so the minimal sink side (BK's
 // read-out, SURVEY A-1) is untouched.  Arcs between two undecided sites are never written here and
 // a decided site never writes again, so rounds may run chaotically: every verdict holds given any
 // subset of earlier verdicts (a stale "undecided" view only makes the tests stricter).
-__global__ void __launch_bounds__(256)
-k_reduce(Graph g, int* cap, int* excess, int* sink_cap, int* decided, int* __restrict__ flags,
-         int* __restrict__ changed_flag, int ROUNDS)
+// The fixed point is reached inside k_solve; these launches take the bulk of the cascade off it.
+// COMPACT: sites still undecided when their row finishes are appended to the core list.
+template <bool COMPACT>
+__global__ void __launch_bounds__(1024)
+k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decided,
+         int* __restrict__ flags, long long* __restrict__ acc, int* __restrict__ core, int ROUNDS)
 {
-    const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int u = blockIdx.x * (blockDim.x / LPN) + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
-    if (u >= g.n) return;
-    const int du = LD(&decided[u]);                 // first-level loads issued together
-    const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
-    long long net = (long long)excess[u] - sink_cap[u];
-    if (du != 0) return;
-    bool dirty = false, changed = false;
-    int verdict = 0;
-    for (int r = 0; r < ROUNDS; ++r) {
-        long long add = 0, out = 0, in = 0;
-        for (int k = k0 + sub; k < k1; k += LPN) {
-            const int kr = g.rev[k];
-            const int co = cap[k], ci = cap[kr];
-            if ((co | ci) == 0) continue;
-            const int dv = LD(&decided[g.col[k]]);
-            if (dv == 1) { add += ci; cap[k] = 0; cap[kr] = 0; }
-            else if (dv == 2) { add -= co; cap[k] = 0; cap[kr] = 0; }
-            else { out += co; in += ci; }
-        }
-        add = row_sum64(add); out = row_sum64(out); in = row_sum64(in);
-        if (add != 0) { net += add; dirty = true; changed = true; }
-        if (net > out) verdict = 1;
-        else if (-net > in) verdict = 2;
-        if (verdict) break;
+    __shared__ int s_skip;                               // one evaluation per workgroup: C_ERROR may be raised meanwhile
+    if (threadIdx.x == 0) s_skip = move_is_skipped(flags, t, L) ? 1 : 0;
+    __syncthreads();
+    const bool skipped = s_skip != 0;
+    if (!COMPACT && blockIdx.x == 0 && threadIdx.x == 0) {
+        // housekeeping of the move, for the launches behind this one
+        flags[C_PEND] = -1;                              // k_move_setup has applied it
+        for (int s = 0; s < EXPAND_CORE_SHARDS; ++s) flags[C_CORE + s] = 0;
+        for (int s = C_XCD; s < C_TOP + C_LINE; ++s) flags[s] = 0;      // k_solve's barrier state
+        flags[C_ARRIVE] = 0;
+        flags[C_TICKET] = 0;
+        for (int s = 0; s < SUBTICKETS; ++s) flags[C_SUBTICKET + s * C_LINE] = 0;
+        long long ex = 0;
+        for (int s = 0; s < STRIPES; ++s) { ex += acc[A_EXCESS_S + s * STRIPE_LL]; acc[A_EXCESS_S + s * STRIPE_LL] = 0; acc[A_DELTA_S + s * STRIPE_LL] = 0; }
+        if (!skipped && ex > 0x7fffffffll) flags[C_ERROR] = ERR_OVERFLOW;
     }
-    if (sub != 0) return;
-    if (dirty) {
-        if (net > 0x7fffffffll || -net > 0x7fffffffll) atomicExch(&flags[F_OVERFLOW], 1);
-        excess[u] = net > 0 ? (int)net : 0;
-        sink_cap[u] = net < 0 ? (int)(-net) : 0;
-    }
-    if (verdict) { ST(&decided[u], verdict); changed = true; }
-    if (changed) *changed_flag = 1;
-}
-
-// Undecided sites that still hold excess: zero means the cut is already known.
-__global__ void __launch_bounds__(256)
-k_count_undecided(int n, const int* __restrict__ excess, const int* __restrict__ decided, int* __restrict__ flags)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool act = (i < n) && decided[i] == 0 && excess[i] > 0;
-    const unsigned long long b = __ballot(act);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&flags[F_UNDECIDED_EXCESS], __popcll(b));
-
-}
-
-// Chaotic min-relaxation towards exact residual distances to the sink.  Values are
-// always upper bounds realised by residual paths and only decrease, so any schedule
-// converges to the BFS distances; `changed` is raised when a launch lowered anything.
-// Residual capacities are constant while relaxation kernels run (plain loads); heights move
-// (agent-scope loads/stores, which bypass the per-CU L1).
-__global__ void __launch_bounds__(256)
-k_bfs_relax(Graph g, const int* __restrict__ decided, const int* __restrict__ cap,
-            int* height, int* __restrict__ changed_flag, int ROUNDS)
-{
-    const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
-    const int sub = threadIdx.x % LPN;
-    if (u >= g.n) return;
-    // all first-level loads issued together (the early return must not serialise them)
-    const int du = decided[u];
-    const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
-    int hu = LD(&height[u]);
-    if (du != 0) return;
-    bool any = false;
-    if (k1 - k0 <= SLOTS * LPN) {
-        // The usual case (degree <= 48): each lane keeps its <= 3 residual arcs' heads in registers
-        // (capacities do not change while relaxation runs), so a round is ONE level of independent
-        // agent-scope loads instead of a cap -> col -> height chain.
-        int nb[SLOTS];
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) {
-            const int k = k0 + sub + q * LPN;
-            nb[q] = (k < k1 && cap[k] > 0) ? g.col[k] : -1;
-        }
-        for (int r = 0; r < ROUNDS; ++r) {
-            if (hu <= 1) break;
-            int best = hu;
-#pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                if (nb[q] >= 0) {
-                    const int hv = LD(&height[nb[q]]) + 1;
-                    if (hv < best) best = hv;
+    if (skipped) return;
+    bool mine = false;
+    if (u < g.n) {
+        const int du = LD(&decided[u]);
+        if (du == 0) {
+            const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
+            long long net = (long long)excess[u] - sink_cap[u];
+            bool dirty = false;
+            int verdict = 0;
+            for (int r = 0; r < ROUNDS; ++r) {
+                long long add = 0, out = 0, in = 0;
+                for (int k = k0 + sub; k < k1; k += LPN) {
+                    const int kr = g.rev[k];
+                    const int co = cap[k], ci = cap[kr];
+                    if ((co | ci) == 0) continue;
+                    const int dv = LD(&decided[g.col[k]]);
+                    if (dv == 1) { add += ci; cap[k] = 0; cap[kr] = 0; }
+                    else if (dv == 2) { add -= co; cap[k] = 0; cap[kr] = 0; }
+                    else { out += co; in += ci; }
                 }
+                add = row_sum64<LPN>(add); out = row_sum64<LPN>(out); in = row_sum64<LPN>(in);
+                if (add != 0) { net += add; dirty = true; }
+                if (net > out) verdict = 1;
+                else if (-net > in) verdict = 2;
+                if (verdict) break;
             }
-            best = row_min(best);
-            if (best < hu) {
-                hu = best;
-                if (sub == 0) ST(&height[u], hu);
-                any = true;
-            }
-        }
-    } else {
-        for (int r = 0; r < ROUNDS; ++r) {
-            if (hu <= 1) break;
-            int best = hu;
-            for (int k = k0 + sub; k < k1; k += LPN) {
-                if (cap[k] > 0) {
-                    const int hv = LD(&height[g.col[k]]) + 1;
-                    if (hv < best) best = hv;
+            if (sub == 0) {
+                if (dirty) {
+                    if (net > 0x7fffffffll || -net > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                    excess[u] = net > 0 ? (int)net : 0;
+                    sink_cap[u] = net < 0 ? (int)(-net) : 0;
                 }
+                if (verdict) ST(&decided[u], verdict);
             }
-            best = row_min(best);
-            if (best < hu) {                             // keep polling otherwise: a neighbour may still
-                hu = best;                               // drop inside this launch
-                if (sub == 0) ST(&height[u], hu);
-                any = true;
-            }
+            mine = verdict == 0;
         }
     }
-    if (any && sub == 0) *changed_flag = 1;
+    if (COMPACT) {
+        __shared__ int s_cnt, s_base;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        int off = 0;
+        if (mine && sub == 0) off = atomicAdd(&s_cnt, 1);
+        __syncthreads();
+        const int shard = blockIdx.x % EXPAND_CORE_SHARDS;
+        if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(&flags[C_CORE + shard], s_cnt);
+        __syncthreads();
+        if (mine && sub == 0) core[(size_t)shard * g.n + s_base + off] = u;
+    }
 }
 
-__global__ void __launch_bounds__(256)
-k_count_active(int n, const int* __restrict__ excess, const int* __restrict__ height,
-               const int* __restrict__ decided, int* __restrict__ flags)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool act = (i < n) && decided[i] == 0 && excess[i] > 0 && height[i] < n;
-    const unsigned long long b = __ballot(act);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&flags[F_ACTIVE], __popcll(b));
-}
+// ---------------------------------------------------------------------------
+// k_solve — the flow problem of one move on the compacted core, in ONE launch.
+//
+// SLPN = 8 lanes per site, SSLOTS = 6 arcs per lane in registers (degree <= 48; larger sites walk
+// their arcs in memory), 512 threads = 64 sites per workgroup, P = ceil(K / 64) workgroups take part
+// (the rest of the launch returns at once).  When K exceeds what the launch can hold one site per
+// row, rows walk several sites and reload them at every visit.
+//
+// The cost of this kernel is the number of uncoalesced agent-scope requests a CU issues per round
+// (about one 64-B request per clock and CU, whatever the payload) times the rounds a move needs, so
+// both phases are written as "poll ONE word per site, act only when it changed":
+//   * global relabel = frontier BFS from the sink: a site whose height word dropped since it last
+//     told its neighbours lowers THEIR words with atomicMin (no return value) along the arcs that
+//     are residual towards it.  Idle sites cost one load per round; every height drops a few times.
+//   * push: what other sites have sent to u accumulates in excess[u] (atomicAdd without return, issued
+//     by the pusher); what u itself has spent — sent on or drained into the sink — is a register of
+//     its owner.  An idle site polls excess[u]; only a site that owns excess loads its neighbours'
+//     heights and the counters of the reverse arcs.
+// Arc state is SINGLE-WRITER: arc k = (u->v) carries the cumulative counter sent[k] that only u's
+// row writes, and r(u->v) = cap[k] - sent[k] + sent[rev k].  A counter read late only under-states
+// the residual capacity, so a row never pushes more than an arc holds; it never pushes more than it
+// owns either, because only arrivals are asynchronous.  Per cycle a site with excess pushes along
+// ALL its downhill residual arcs at once (lanes share the excess through a row prefix sum) or lifts
+// itself just above its lowest residual neighbour — Hong's lock-free push-relabel rule per arc.
+// (Earlier versions: atomics on shared excess/capacity words with the owner's atomic -> load chain,
+// 35-57 ms of solver time per LabelingStep at 50k sites; every lane loading all its neighbours'
+// words every cycle, 66 ms.)
+//
+// Everything another row may read is written with agent-scope (sc1) stores or atomics and read with
+// agent-scope loads; before a barrier every wave drains its memory operations (s_waitcnt vmcnt(0)),
+// so no cache maintenance is needed (MI355X_MICROARCH.md, valid hand-off forms).  The barrier is one
+// monotonic arrival counter polled by one lane per workgroup; the reductions every phase needs ("did
+// any row change anything", "how many rows are active", "largest finite height") travel through a
+// ring of four slots.
+// ---------------------------------------------------------------------------
+constexpr int SLPN = 8;
+constexpr int SSLOTS = 6;
+constexpr int SOLVE_THREADS = 512;
+constexpr int SOLVE_ROWS = SOLVE_THREADS / SLPN;
+constexpr int H_SHIFT = 24, H_MASK = (1 << H_SHIFT) - 1, H_EPOCHS = 126;   // height word = (H_EPOCHS - epoch) << 24 | height
 
-// Lock-free push-relabel (Hong's formulation): the owner (lane 0 of the site's row) is the only
-// one that lowers excess[u], lowers cap[u->*], touches sink_cap[u] or writes height[u]; other
-// sites only ADD to excess[u] and to cap[u->*] (reverse arcs of their pushes).
-__global__ void __launch_bounds__(256)
-k_push_relabel(Graph g, const int* __restrict__ decided, int* cap, int* excess,
-               int* __restrict__ sink_cap, int* height, int CYCLES)
+struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer; };
+
+// Grid barrier with reductions, two levels: the workgroups of one XCD meet on a line of their own, the last
+// arriver of each XCD carries the XCD's reductions to the top line and arrives there, everybody polls the top
+// counter.  Which XCD a workgroup runs on is read from the hardware (HW_REG_XCC_ID); the census of the first
+// barrier (a flat one) tells every workgroup how many partners its XCD has.  Placement only affects speed.
+struct GridBarrier {
+    int* flags;
+    int* s_red;          // shared int[8]: wg changed, wg active, wg hmax, out changed, out active, out hmax, abort
+    int P;               // participating workgroups
+    int xcd, xcd_wgs, xcds;
+    unsigned seq;        // barriers passed on the two-level counters
+    unsigned long long ticks;
+};
+
+__device__ __forceinline__ bool spin_until(const int* word, int target, int* flags)
 {
-    const int u = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
-    const int sub = threadIdx.x % LPN;
-    if (u >= g.n) return;
-    const int n = g.n;
-    const int du = decided[u];                      // first-level loads issued together
-    const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
-    int hu = LD(&height[u]);
-    int sc = sink_cap[u];
-    if (du != 0) return;
-    if ((k1 - k0) <= SLOTS * LPN) {
-        // The usual case (degree <= 48).  Each lane keeps its <= 3 arcs (head, reverse arc) in registers
-        // and, while the site is active, fetches the next cycle's excess, capacities and neighbour
-        // heights TOGETHER at the end of the current cycle: one memory round trip per active cycle
-        // instead of three (excess -> capacity/height -> capacity again).  The lane that owns the
-        // chosen arc issues the capacity updates itself; lane 0 remains the only one that lowers
-        // excess[u], so its next load is ordered behind its own atomic.  Values read one cycle early
-        // are only ever conservative: cap(u->*) is lowered by this site alone, heights only guide.
-        int nb[SLOTS], rv[SLOTS], cq[SLOTS], hq[SLOTS];
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) {
-            const int k = k0 + sub + q * LPN;
-            nb[q] = k < k1 ? g.col[k] : -1;
-            rv[q] = k < k1 ? g.rev[k] : 0;
-            cq[q] = 0; hq[q] = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    while (LD(word) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {          // 3 s: a workgroup of this launch is not resident
+            atomicExch(&flags[C_ERROR], ERR_BARRIER_TIMEOUT);
+            return false;
         }
-        bool arcs_valid = false;
-        int e_next = (sub == 0) ? LD(&excess[u]) : 0;
-        for (int cyc = 0; cyc < CYCLES; ++cyc) {
-            if (hu >= n) break;
-            int e = __shfl(e_next, 0, LPN);
-            if (e > 0 && sc > 0) {                      // t-link: h(t) = 0, h(u) = 1
-                const int d = e < sc ? e : sc;
-                sc -= d;
-                if (sub == 0) { sink_cap[u] = sc; atomicSub(&excess[u], d); }
-                e -= d;
+    }
+    return true;
+}
+
+// First barrier of a launch: flat, doubles as the census.
+__device__ __forceinline__ bool grid_sync_first(GridBarrier& b)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b.s_red[6] = 0;
+        atomicAdd(&b.flags[C_XCD + b.xcd * C_LINE], 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicAdd(&b.flags[C_ARRIVE], 1);
+        if (!spin_until(&b.flags[C_ARRIVE], b.P, b.flags)) b.s_red[6] = 1;
+        int used = 0;
+        for (int x = 0; x < 8; ++x) used += LD(&b.flags[C_XCD + x * C_LINE]) > 0 ? 1 : 0;
+        b.s_red[3] = used;
+        b.s_red[4] = LD(&b.flags[C_XCD + b.xcd * C_LINE]);
+    }
+    __syncthreads();
+    b.xcds = b.s_red[3];
+    b.xcd_wgs = b.s_red[4];
+    return b.s_red[6] == 0;
+}
+
+// c_changed: any lane of the workgroup; c_active: counted per lane (a site contributes through ONE lane);
+// c_hmax: any lane (largest value wins; a scheduling hint only, so it travels outside the ordered path).
+// Arrival and reductions share ONE 64-bit word per level and barrier (bits 0-15 arrivals, 16-31 workgroups that
+// changed something, 32-63 active sites): a workgroup pays one returning atomic, the last of an XCD one more, and
+// the load that sees the last arrival also carries the sums.
+__device__ __forceinline__ bool grid_sync(GridBarrier& b, bool c_changed, bool c_active, int c_hmax,
+                                          int& any_changed, int& n_active, int& hmax)
+{
+    typedef unsigned long long u64;
+    const u64 t_in = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every wave: my stores and atomics have landed
+    if (threadIdx.x == 0) { b.s_red[0] = 0; b.s_red[1] = 0; b.s_red[2] = 0; }
+    __syncthreads();
+    if (__ballot(c_changed) && (threadIdx.x & 63) == 0) b.s_red[0] = 1;
+    { const u64 b1 = __ballot(c_active); if (b1 && (threadIdx.x & 63) == 0) atomicAdd(&b.s_red[1], __popcll(b1)); }
+    if (c_hmax > 0) atomicMax(&b.s_red[2], c_hmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int slot = (int)(b.seq & 3u), next = (int)((b.seq + 2u) & 3u);
+        int* mine = b.flags + C_XCD + b.xcd * C_LINE;
+        int* top = b.flags + C_TOP;
+        u64* xs = (u64*)(mine + 2);
+        u64* ts = (u64*)(top + 2);
+        if (b.s_red[2]) {
+            atomicMax(&top[10 + slot], b.s_red[2]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const u64 me = 1ull | ((u64)(b.s_red[0] ? 1 : 0) << 16) | ((u64)(unsigned)b.s_red[1] << 32);
+        const bool flat = b.P <= 32;                            // few workgroups: one level is a round trip shorter
+        if (flat) {
+            atomicAdd(&ts[slot], me);
+        } else {
+            const u64 old = atomicAdd(&xs[slot], me);
+            if ((int)(old & 0xffffull) + 1 == b.xcd_wgs) {      // last of my XCD: carry its sums up
+                atomicAdd(&ts[slot], ((old + me) & ~0xffffull) | 1ull);
+                ST(&xs[next], 0ull);                            // my XCD's word of the barrier after next
             }
-            if (e <= 0) {                               // idle (or drained into the sink): just poll
-                e_next = (sub == 0) ? LD(&excess[u]) : 0;
-                arcs_valid = false;
-                continue;
-            }
-            if (!arcs_valid) {
-#pragma unroll
-                for (int q = 0; q < SLOTS; ++q) {
-                    cq[q] = nb[q] >= 0 ? LD(&cap[k0 + sub + q * LPN]) : 0;
-                    hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
-                }
-            }
-            long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
-#pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                if (cq[q] > 0) {
-                    const long long cand = ((long long)hq[q] << 32) | (unsigned int)(k0 + sub + q * LPN);
-                    if (cand < key) key = cand;
-                }
-            }
-            key = row_min64(key);
-            if (key == 0x7fffffffffffffffll) {          // no way out at all
-                hu = n;
-                if (sub == 0) ST(&height[u], hu);
+        }
+        const int target = flat ? b.P : b.xcds;
+        u64 v = 0;
+        int hm = 0;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        int abort = 0;
+        for (;;) {
+            v = LD(&ts[slot]);
+            hm = LD(&top[10 + slot]);
+            if ((int)(v & 0xffffull) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {      // 3 s: a workgroup of this launch is not resident
+                atomicExch(&b.flags[C_ERROR], ERR_BARRIER_TIMEOUT);
+                abort = 1;
                 break;
             }
-            const int hmin = (int)(key >> 32), kmin = (int)(key & 0xffffffffll);
-            if (hu > hmin) {
-                const int off = kmin - k0, owner = off % LPN, slot = off / LPN;
-                int c_mine = cq[0], v_mine = nb[0], r_mine = rv[0];
-#pragma unroll
-                for (int q = 1; q < SLOTS; ++q)
-                    if (slot == q) { c_mine = cq[q]; v_mine = nb[q]; r_mine = rv[q]; }
-                const int c = __shfl(c_mine, owner, LPN);
-                const int d = e < c ? e : c;
-                if (sub == owner) {
-                    atomicSub(&cap[kmin], d);
-                    atomicAdd(&cap[r_mine], d);
-                    atomicAdd(&excess[v_mine], d);
-                }
-                if (sub == 0) atomicSub(&excess[u], d);
-            } else {
-                hu = hmin + 1;
-                if (hu > n) hu = n;
-                if (sub == 0) ST(&height[u], hu);
-            }
-            // next cycle's inputs, all in flight together
-            e_next = (sub == 0) ? LD(&excess[u]) : 0;
-#pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                cq[q] = nb[q] >= 0 ? LD(&cap[k0 + sub + q * LPN]) : 0;
-                hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
-            }
-            arcs_valid = true;
         }
-        return;
+        b.s_red[3] = (int)((v >> 16) & 0xffffull);
+        b.s_red[4] = (int)(v >> 32);
+        b.s_red[5] = hm;
+        b.s_red[6] = abort;
+        if (blockIdx.x == 0) { ST(&ts[next], 0ull); ST(&top[10 + next], 0); }
     }
-    for (int cyc = 0; cyc < CYCLES; ++cyc) {            // generic path: any degree
-        if (hu >= n) break;
-        // lane 0 reads the excess and broadcasts it: all lanes of the row act on ONE value
-        int e = (sub == 0) ? LD(&excess[u]) : 0;
-        e = __shfl(e, 0, LPN);
-        if (e <= 0) continue;
-        if (sc > 0) {                               // t-link: h(t) = 0, h(u) = 1
-            const int d = e < sc ? e : sc;
-            sc -= d;
-            if (sub == 0) { sink_cap[u] = sc; atomicSub(&excess[u], d); }
-            e -= d;
-            if (e == 0) continue;
+    __syncthreads();
+    any_changed = b.s_red[3];
+    n_active = b.s_red[4];
+    hmax = b.s_red[5];
+    ++b.seq;
+    b.ticks += __builtin_amdgcn_s_memrealtime() - t_in;
+    return b.s_red[6] == 0;
+}
+
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, int* aux, int* height, int* decided,
+        const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
+        SolveParams sp)
+{
+    __shared__ int s_red[8];
+    __shared__ int s_skip;
+    if (threadIdx.x == 0) s_skip = move_is_skipped(flags, t, L) ? 1 : 0;
+    __syncthreads();
+    if (s_skip) return;
+    if (g.n >= H_MASK) { if (threadIdx.x == 0) atomicExch(&flags[C_ERROR], ERR_OVERFLOW); return; }   // heights carry 24 bits
+    int pre[EXPAND_CORE_SHARDS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int s = 0; s < EXPAND_CORE_SHARDS; ++s) pre[s + 1] = pre[s] + flags[C_CORE + s];
+    const int K = pre[EXPAND_CORE_SHARDS];
+    if (K == 0) return;
+    int P = (K + SOLVE_ROWS - 1) / SOLVE_ROWS;
+    if (P > (int)gridDim.x) P = (int)gridDim.x;
+    if ((int)blockIdx.x >= P) return;
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
+    const int total_rows = P * SOLVE_ROWS;
+    const int row = blockIdx.x * SOLVE_ROWS + threadIdx.x / SLPN;
+    const int sub = threadIdx.x % SLPN;
+    const bool single = K <= total_rows;             // one site per row: its state lives in registers
+    const int INF = K + 1;                           // no residual path in the core is longer than K
+    int* spent_mem = aux;                            // per-site state of rows that walk several sites
+    int* hprop_mem = aux + g.n;
+    // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
+    GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull };
+    long long st_outer = 0, st_relax = 0, st_push = 0;
+    unsigned long long tk_relax = 0, tk_push = 0;
+
+    // the row's site (re-loaded at every visit unless `single`)
+    int u = -1, k0 = 0, k1 = 0, dec = 3, hu = 0, sc = 0, spent = 0, hprop = 0;
+    bool fast = false;
+    int nb[SSLOTS], rv[SSLOTS], c0[SSLOTS], so[SSLOTS];
+    unsigned rin = 0;                                // bit q: the arc nb[q] -> u is residual (relabel direction)
+
+    auto load_site = [&](int c) {
+        int s = 0, first = 0;
+#pragma unroll
+        for (int q = 1; q < EXPAND_CORE_SHARDS; ++q) if (c >= pre[q]) { s = q; first = pre[q]; }
+        u = core[(size_t)s * g.n + (c - first)];
+        k0 = g.rowptr[u];
+        k1 = g.rowptr[u + 1];
+        fast = (k1 - k0) <= SLPN * SSLOTS;
+#pragma unroll
+        for (int q = 0; q < SSLOTS; ++q) {
+            const int k = k0 + sub + q * SLPN;
+            const bool in = fast && k < k1;
+            nb[q] = in ? g.col[k] : -1;
+            rv[q] = in ? g.rev[k] : 0;
+            c0[q] = 0; so[q] = 0;
         }
-        long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
-        for (int k = k0 + sub; k < k1; k += LPN) {
-            if (LD(&cap[k]) > 0) {
-                const long long cand = ((long long)LD(&height[g.col[k]]) << 32) | (unsigned int)k;
-                if (cand < key) key = cand;
+        dec = LD(&decided[u]);
+    };
+    // capacities (final once the reduction has reached its fixed point) and the row's own counters; arcs
+    // without capacity in either direction (decided neighbours) drop out
+    auto load_arcs = [&]() {
+        if (!fast) return;
+#pragma unroll
+        for (int q = 0; q < SSLOTS; ++q) {
+            if (nb[q] >= 0) {
+                const int k = k0 + sub + q * SLPN;
+                c0[q] = LD(&cap[k]);
+                so[q] = LD(&sent[k]);
+                if ((c0[q] | LD(&cap[rv[q]])) == 0) nb[q] = -1;
             }
         }
-        key = row_min64(key);
-        if (key == 0x7fffffffffffffffll) {          // no way out at all
-            hu = n;
-            if (sub == 0) ST(&height[u], hu);
-            break;
-        }
-        const int hmin = (int)(key >> 32), kmin = (int)(key & 0xffffffffll);
-        if (hu > hmin) {
+    };
+    auto load_rin = [&]() {                          // arcs residual TOWARDS me, constant between two push phases
+        rin = 0;
+        if (!fast) return;
+#pragma unroll
+        for (int q = 0; q < SSLOTS; ++q)
+            if (nb[q] >= 0 && LD(&cap[rv[q]]) - LD(&sent[rv[q]]) + so[q] > 0) rin |= 1u << q;
+    };
+#define FOR_MY_SITES(c) for (int c = row; c < K; c += total_rows)
+#define VISIT(c) do { if (!single || u < 0) load_site(c); } while (0)
+
+    // my arcs' flow counters start at zero (visible to everybody behind the barriers of phase 0)
+    FOR_MY_SITES(c) {
+        VISIT(c);
+        for (int k = k0 + sub; k < k1; k += SLPN) ST(&sent[k], 0);
+        if (sub == 0) { ST(&spent_mem[u], 0); ST(&height[u], 0x7fffffff); }      // a word of no epoch
+    }
+    if (!grid_sync_first(bar)) return;
+
+    // ---- phase 0: the reduction cascade to its fixed point (k_reduce's body on the core) -------------
+    for (;;) {
+        bool changed = false;
+        FOR_MY_SITES(c) {
+            VISIT(c);
+            if (dec != 0) continue;
+            long long net = (long long)LD(&excess[u]) - LD(&sink_cap[u]);
+            bool dirty = false;
+            int verdict = 0;
+            for (int r = 0; r < sp.reduce_rounds; ++r) {
+                long long add = 0, out = 0, in = 0;
+                for (int k = k0 + sub; k < k1; k += SLPN) {
+                    const int kr = g.rev[k];
+                    const int co = LD(&cap[k]), ci = LD(&cap[kr]);
+                    if ((co | ci) == 0) continue;
+                    const int dv = LD(&decided[g.col[k]]);
+                    if (dv == 1) { add += ci; ST(&cap[k], 0); ST(&cap[kr], 0); }
+                    else if (dv == 2) { add -= co; ST(&cap[k], 0); ST(&cap[kr], 0); }
+                    else { out += co; in += ci; }
+                }
+                add = row_sum64<SLPN>(add); out = row_sum64<SLPN>(out); in = row_sum64<SLPN>(in);
+                if (add != 0) { net += add; dirty = true; changed = true; }
+                if (net > out) verdict = 1;
+                else if (-net > in) verdict = 2;
+                if (verdict || add == 0) break;       // a round that folded nothing would repeat itself
+            }
             if (sub == 0) {
-                const int c = LD(&cap[kmin]);
-                const int d = e < c ? e : c;
-                atomicSub(&cap[kmin], d);
-                atomicAdd(&cap[g.rev[kmin]], d);
-                atomicSub(&excess[u], d);
-                atomicAdd(&excess[g.col[kmin]], d);
+                if (dirty) {
+                    if (net > 0x7fffffffll || -net > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                    ST(&excess[u], net > 0 ? (int)net : 0);
+                    ST(&sink_cap[u], net < 0 ? (int)(-net) : 0);
+                }
+                if (verdict) ST(&decided[u], verdict);
             }
-        } else {
-            hu = hmin + 1;
-            if (hu > n) hu = n;
-            if (sub == 0) ST(&height[u], hu);
+            if (verdict) { dec = verdict; changed = true; }
+        }
+        int any, nact, hm;
+        if (!grid_sync(bar, changed && sub == 0, false, 0, any, nact, hm)) return;
+        if (!any || sp.reduce_rounds <= 0) break;
+    }
+    if (single) {
+        FOR_MY_SITES(c) {
+            if (dec != 0) continue;
+            load_arcs();
+            sc = LD(&sink_cap[u]);
+        }
+    }
+
+    // ---- phase 1: global relabel <-> push until no site with excess can reach the sink ---------------
+    int outer = 0, epoch = 0, hprev = 4;
+    bool exact = false;
+    for (;; ++outer) {
+        if (outer >= sp.max_outer) { if (leader) atomicExch(&flags[C_ERROR], ERR_NO_CONVERGENCE); break; }
+        ++st_outer;
+        const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+        // Global relabel.  Height words carry the relabel's epoch in their top bits, newer epochs SMALLER: a word of
+        // an older epoch reads as "unreachable" and loses against any atomicMin of the running epoch, so a relabel
+        // needs no pass that resets the words, and the sites next to the sink enter with an atomicMin of their own.
+        if (++epoch > H_EPOCHS) {                      // out of epochs (never seen): start over behind two barriers
+            int a0, a1, a2;
+            if (!grid_sync(bar, false, false, 0, a0, a1, a2)) return;
+            FOR_MY_SITES(c) { VISIT(c); if (dec == 0 && sub == 0) ST(&height[u], 0x7fffffff); }
+            if (!grid_sync(bar, false, false, 0, a0, a1, a2)) return;
+            epoch = 1;
+        }
+        const int ebits = (H_EPOCHS - epoch) << H_SHIFT;
+        FOR_MY_SITES(c) {
+            VISIT(c);
+            if (dec != 0) continue;
+            if (!single) sc = LD(&sink_cap[u]);
+            if (sub == 0) {
+                if (sc > 0) atomicMin(&height[u], ebits | 1);
+                if (!single) ST(&hprop_mem[u], INF);
+            }
+            hprop = INF;                              // nothing told to the neighbours yet
+            if (single) load_rin();
+        }
+        int any, nact, hmax;
+        // (the frontier advances one level per round: a few rounds more than the last relabel was deep)
+        int relax_rounds = hprev + 12;
+        if (relax_rounds > sp.relax_rounds) relax_rounds = sp.relax_rounds;
+        // ... then the frontier runs: a site whose word dropped since it last spoke lowers its upstream
+        // neighbours' words to its height + 1.  Words only decrease and every value is realised by a residual
+        // path, so any schedule converges to the BFS distances; an interval without a single announcement is
+        // the fixed point (all atomics of earlier intervals had landed before it began).
+        for (;;) {
+            ++st_relax;
+            bool spoke = false, active = false;
+            int my_h = 0;
+            FOR_MY_SITES(c) {
+                VISIT(c);
+                if (dec != 0) continue;
+                if (!single) { load_arcs(); load_rin(); hprop = LD(&hprop_mem[u]); spent = LD(&spent_mem[u]); }
+                const int rounds = single ? relax_rounds : 1;
+                for (int r = 0; r < rounds; ++r) {
+                    const int w = LD(&height[u]);
+                    hu = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
+                    if (hu < hprop) {
+                        if (fast) {
+#pragma unroll
+                            for (int q = 0; q < SSLOTS; ++q)
+                                if (rin & (1u << q)) atomicMin(&height[nb[q]], ebits | (hu + 1));
+                        } else {
+                            for (int k = k0 + sub; k < k1; k += SLPN) {
+                                const int kr = g.rev[k];
+                                if (LD(&cap[kr]) - LD(&sent[kr]) + LD(&sent[k]) > 0) atomicMin(&height[g.col[k]], ebits | (hu + 1));
+                            }
+                        }
+                        hprop = hu;
+                        spoke = true;
+                    } else if (hu <= 1) break;        // next to the sink and announced: final
+                }
+                if (!single && sub == 0) ST(&hprop_mem[u], hprop);
+                if (hu < INF) {
+                    if (hu > my_h) my_h = hu;
+                    if (sub == 0 && LD(&excess[u]) - spent > 0) active = true;
+                }
+            }
+            if (!grid_sync(bar, spoke, active, my_h, any, nact, hmax)) return;
+            // no announcement in a whole interval: the distances are exact.  Otherwise every finite height is still
+            // realised by a residual path, which is all the pushes need: go on as soon as somebody can push.
+            if (!any || nact) { exact = !any; break; }
+        }
+        hprev = hmax;
+        tk_relax += __builtin_amdgcn_s_memrealtime() - tr0;
+        if (detail && leader && outer < 2048) {
+            int* d = detail + 4 * (size_t)outer;
+            d[0] = nact; d[1] = hmax; d[2] = (int)st_relax; d[3] = (int)(__builtin_amdgcn_s_memrealtime() - tick0);
+        }
+        if (nact == 0) break;                          // (then exact) finished: nobody with excess reaches the sink
+        if (outer == 0 && leader) atomicAdd(&flags[C_FLOW_MOVES], 1);
+
+        // lock-free push-relabel (see the header of this kernel); a wave of pushes needs about as many cycles
+        // as the longest residual path is long
+        const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
+        int cycles = sp.push_mult * (hmax + 3);
+        if (cycles > sp.push_cycles) cycles = sp.push_cycles;
+        for (int phase = 0; phase < sp.push_phases; ++phase) {
+            ++st_push;
+            bool active = false;
+            FOR_MY_SITES(c) {
+                VISIT(c);
+                if (dec != 0) continue;
+                {                                     // my word as the last announcements left it
+                    const int w = LD(&height[u]);
+                    hu = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
+                }
+                if (!single) { sc = LD(&sink_cap[u]); spent = LD(&spent_mem[u]); load_arcs(); }
+                for (int cyc = 0; cyc < cycles; ++cyc) {
+                    if (hu >= INF) break;
+                    const int x = LD(&excess[u]);
+                    if (x > (1 << 30)) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                    int e = x - spent;
+                    if (e > 0 && sc > 0) {                          // t-link: h(t) = 0, h(u) >= 1
+                        const int d = e < sc ? e : sc;
+                        sc -= d; spent += d; e -= d;
+                        if (sub == 0) ST(&sink_cap[u], sc);
+                    }
+                    if (e <= 0) continue;                           // idle: poll again
+                    if (fast) {
+                        int r[SSLOTS], hq[SSLOTS];
+#pragma unroll
+                        for (int q = 0; q < SSLOTS; ++q) {          // one level of independent loads
+                            r[q] = nb[q] >= 0 ? LD(&sent[rv[q]]) : 0;
+                            hq[q] = nb[q] >= 0 ? LD(&height[nb[q]]) : 0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < SSLOTS; ++q)
+                            hq[q] = (hq[q] >> H_SHIFT) == (ebits >> H_SHIFT) ? (hq[q] & H_MASK) : INF;
+                        int D = 0;                                  // what my downhill residual arcs can take
+#pragma unroll
+                        for (int q = 0; q < SSLOTS; ++q) {
+                            r[q] = nb[q] >= 0 ? c0[q] - so[q] + r[q] : 0;
+                            if (r[q] > 0 && hq[q] < hu) D += r[q];
+                        }
+                        int incl = D;
+#pragma unroll
+                        for (int o = 1; o < SLPN; o <<= 1) { const int y = __shfl_up(incl, o, SLPN); if (sub >= o) incl += y; }
+                        const int tot = __shfl(incl, SLPN - 1, SLPN);
+                        if (tot > 0) {
+                            int budget = e - (incl - D);            // the lanes in front of me are served first
+                            if (budget > D) budget = D;
+#pragma unroll
+                            for (int q = 0; q < SSLOTS; ++q) {
+                                if (budget > 0 && r[q] > 0 && hq[q] < hu) {
+                                    const int d = r[q] < budget ? r[q] : budget;
+                                    so[q] += d;
+                                    budget -= d;
+                                    ST(&sent[k0 + sub + q * SLPN], so[q]);
+                                    atomicAdd(&excess[nb[q]], d);
+                                    if (so[q] > (1 << 30)) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                                }
+                            }
+                            spent += e < tot ? e : tot;
+                        } else {                                    // nothing downhill: lift just above the lowest residual neighbour
+                            int hmin = INF;
+#pragma unroll
+                            for (int q = 0; q < SSLOTS; ++q) if (r[q] > 0 && hq[q] < hmin) hmin = hq[q];
+                            hmin = row_min<SLPN>(hmin);
+                            hu = hmin >= INF ? INF : hmin + 1;
+                            if (sub == 0) ST(&height[u], ebits | hu);
+                        }
+                    } else {                                        // any degree: one arc per cycle, arcs walked in memory
+                        long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
+                        for (int k = k0 + sub; k < k1; k += SLPN) {
+                            if (LD(&cap[k]) - LD(&sent[k]) + LD(&sent[g.rev[k]]) > 0) {
+                                const int w = LD(&height[g.col[k]]);
+                                const int hv = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
+                                const long long cand = ((long long)hv << 32) | (unsigned int)k;
+                                if (cand < key) key = cand;
+                            }
+                        }
+                        key = row_min64<SLPN>(key);
+                        if (key == 0x7fffffffffffffffll) {          // no way out at all
+                            hu = INF;
+                            if (sub == 0) ST(&height[u], ebits | hu);
+                            break;
+                        }
+                        const int hmin = (int)(key >> 32), kmin = (int)(key & 0xffffffffll);
+                        if (hu > hmin) {
+                            const int a = LD(&sent[kmin]);
+                            const int rr = LD(&cap[kmin]) - a + LD(&sent[g.rev[kmin]]);
+                            const int d = e < rr ? e : rr;
+                            if (sub == 0) {
+                                ST(&sent[kmin], a + d);
+                                atomicAdd(&excess[g.col[kmin]], d);
+                                if (a + d > (1 << 30)) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                            }
+                            spent += d;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next cycle reads the counter back
+                        } else {
+                            hu = hmin + 1;
+                            if (hu > INF) hu = INF;
+                            if (sub == 0) ST(&height[u], ebits | hu);
+                        }
+                    }
+                }
+                if (!single && sub == 0) ST(&spent_mem[u], spent);
+                if (sub == 0 && hu < INF && LD(&excess[u]) - spent > 0) active = true;
+            }
+            // this barrier also separates the pushes from the next relabel (the counters are final behind it)
+            if (!grid_sync(bar, false, active, 0, any, nact, hmax)) return;
+            if (nact == 0) break;
+        }
+        tk_push += __builtin_amdgcn_s_memrealtime() - tp0;
+    }
+
+    // ---- read-out: whoever cannot reach the sink takes alpha ---------------------------------------
+    FOR_MY_SITES(c) {
+        VISIT(c);
+        if (dec != 0) continue;
+        if (!single) {
+            const int w = LD(&height[u]);
+            hu = (w >> H_SHIFT) == ((H_EPOCHS - epoch) & 0x7f) ? (w & H_MASK) : INF;
+        }
+        if (sub == 0) ST(&decided[u], hu >= INF ? 1 : 2);
+    }
+#undef FOR_MY_SITES
+#undef VISIT
+    if (leader) {
+        atomicAdd(&flags[C_MOVES_SOLVED], 1);
+        atomicMax(&flags[C_CORE_MAX], K);
+        atomicAdd((unsigned long long*)&acc[A_CORE_SUM], (unsigned long long)K);
+        atomicAdd((unsigned long long*)&acc[A_OUTER], (unsigned long long)st_outer);
+        atomicAdd((unsigned long long*)&acc[A_RELAX], (unsigned long long)st_relax);
+        atomicAdd((unsigned long long*)&acc[A_PUSH], (unsigned long long)st_push);
+        atomicAdd((unsigned long long*)&acc[A_BARRIERS], (unsigned long long)bar.seq);
+        atomicAdd((unsigned long long*)&acc[A_TICKS], __builtin_amdgcn_s_memrealtime() - tick0);
+        atomicAdd((unsigned long long*)&acc[A_T_BAR], bar.ticks);
+        atomicAdd((unsigned long long*)&acc[A_T_RELAX], tk_relax);
+        atomicAdd((unsigned long long*)&acc[A_T_PUSH], tk_push);
+        atomicMax(&flags[C_XCD_USED], bar.xcds);
+        if (trace) {
+            int* tr = trace + 8 * (size_t)t;
+            tr[0] = K; tr[1] = P; tr[2] = (int)st_outer; tr[3] = (int)st_relax; tr[4] = (int)st_push; tr[5] = (int)bar.seq;
+            tr[6] = (int)(__builtin_amdgcn_s_memrealtime() - tick0); tr[7] = (int)bar.ticks;
         }
     }
 }
 
-// Energy difference of the candidate labeling (sites with height == n take alpha).
+// Energy difference of the candidate labeling (sites with decided == 1 take alpha) and, by the last
+// workgroup to finish, the verdict of the move: accept iff the energy strictly decreases (:1259).
 __global__ void __launch_bounds__(256)
-k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
+k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int t,
         const int* __restrict__ label, const int* __restrict__ cur_cost,
-        const int* __restrict__ height, long long* __restrict__ acc)
+        const int* __restrict__ decided, unsigned char* __restrict__ took,
+        int* __restrict__ flags, long long* acc)
 {
+    __shared__ long long s[256];
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = move_is_skipped(flags, t, L) ? 1 : 0;
+    __syncthreads();
+    if (s_last) return;
     const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
     long long mine = 0;
     if (i < g.n) {
         const int oi = label[i];
-        const int ni = (oi != alpha && height[i] >= g.n) ? alpha : oi;
-        if (sub == 0 && ni != oi) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
+        const bool ti = decided[i] == 1;
+        const int ni = ti ? alpha : oi;
+        if (sub == 0) {
+            took[i] = ti ? 1 : 0;
+            if (ti) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
+        }
         for (int k = g.rowptr[i] + sub; k < g.rowptr[i + 1]; k += LPN) {
             const int j = g.col[k];
             if (j < i) {
                 const int oj = label[j];
-                const int nj = (oj != alpha && height[j] >= g.n) ? alpha : oj;
+                const int nj = decided[j] == 1 ? alpha : oj;
                 const int dn = (ni != nj) - (oi != oj);
                 mine += (long long)dn * g.w[k] * potts;
             }
         }
     }
-    __shared__ long long s[256];
     s[threadIdx.x] = mine;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
         if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && s[0] != 0)
-        atomicAdd((unsigned long long*)&acc[A_DELTA], (unsigned long long)s[0]);
+    if (threadIdx.x == 0) {
+        if (s[0] != 0) atomicAdd((unsigned long long*)&acc[A_DELTA_S + (blockIdx.x % STRIPES) * STRIPE_LL], (unsigned long long)s[0]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my sum has landed before my ticket
+        // two-level ticket: the last of my sub-ticket's workgroups takes a top ticket, the last of those finishes the move
+        const int st = (int)(blockIdx.x % SUBTICKETS);
+        const int members = ((int)gridDim.x - st + SUBTICKETS - 1) / SUBTICKETS;
+        int last = 0;
+        if (atomicAdd(&flags[C_SUBTICKET + st * C_LINE], 1) == members - 1) {
+            const int used = (int)gridDim.x < SUBTICKETS ? (int)gridDim.x : SUBTICKETS;
+            last = atomicAdd(&flags[C_TICKET], 1) == used - 1;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        long long d = (int)threadIdx.x < STRIPES ? LD(&acc[A_DELTA_S + threadIdx.x * STRIPE_LL]) : 0ll;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m, 64);
+        if (threadIdx.x == 0 && d < 0) {
+            flags[C_TLAST] = t;
+            flags[C_PEND] = alpha;
+            flags[C_ACCEPTED] += 1;
+        }
+        if (threadIdx.x == 0) flags[C_MOVES_RUN] += 1;
+    }
 }
 
+// The labels of a pending accepted move, when no k_move_setup follows (end of a cycle).
 __global__ void __launch_bounds__(256)
-k_apply(int n, const int* __restrict__ cost, int L, int alpha, int* __restrict__ label,
-        int* __restrict__ cur_cost, const int* __restrict__ height,
-        const long long* __restrict__ acc, int* __restrict__ flags)
+k_apply_pending(int n, const int* __restrict__ cost, int L, int* __restrict__ label,
+                int* __restrict__ cur_cost, const unsigned char* __restrict__ took,
+                const int* __restrict__ flags)
 {
-    if (acc[A_DELTA] >= 0) return;                   // strict decrease only (:1259)
+    const int pa = flags[C_PEND];
+    if (pa < 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) flags[F_ACCEPTED] += 1;
-    if (i >= n) return;
-    if (label[i] != alpha && height[i] >= n) {       // applyNewLabeling, :423-441
-        label[i] = alpha;
-        cur_cost[i] = cost[(size_t)i * L + alpha];
+    if (i < n && took[i]) {                                      // applyNewLabeling, :423-441
+        label[i] = pa;
+        cur_cost[i] = cost[(size_t)i * L + pa];
     }
 }
 
 // compute_energy = data + smooth (:953-956; giveSmoothEnergyInternal :267-286)
 __global__ void __launch_bounds__(256)
 k_energy(Graph g, int potts, const int* __restrict__ label, const int* __restrict__ cur_cost,
-         long long* __restrict__ acc)
+         int* __restrict__ flags, long long* __restrict__ acc)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[C_PEND] = -1;     // k_apply_pending ran in front of this launch
     const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
     const int sub = threadIdx.x % LPN;
     long long mine = 0;
@@ -525,7 +952,8 @@ k_energy(Graph g, int potts, const int* __restrict__ label, const int* __restric
         if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd((unsigned long long*)&acc[A_ENERGY], (unsigned long long)s[0]);
+    if (threadIdx.x == 0)
+        atomicAdd((unsigned long long*)&acc[A_ENERGY_S + (blockIdx.x % STRIPES) * STRIPE_LL], (unsigned long long)s[0]);
 }
 
 hipError_t launch_init_labeling(const int* cost, int L, int n, const int* init, int* label,
@@ -546,147 +974,107 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 
 #define RET_IF(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-
 // Control words travel to the host through device-mapped pinned memory: one 1-wave kernel copies
-// them (no hipMemcpy calls, which cost tens of microseconds each for 32 bytes), then the host
+// them (no hipMemcpy calls, which cost tens of microseconds each for a few bytes), then the host
 // waits for the stream.
-__global__ void k_publish(int* __restrict__ flags, long long* __restrict__ acc,
+__global__ void k_publish(const int* __restrict__ flags, long long* __restrict__ acc,
                           int* __restrict__ h_flags, long long* __restrict__ h_acc)
 {
     const int t = threadIdx.x;
-    if (t < F_COUNT) h_flags[t] = flags[t];
-    if (t < A_COUNT) h_acc[t] = acc[t];
-    // the per-check words start the next batch from zero (saves a 4-byte memset launch per word)
-    if (t == F_ACTIVE || t == F_CHANGED || t == F_EXCESS_NODES || t == F_UNDECIDED_EXCESS) flags[t] = 0;
-    if (t == A_EXCESS_SUM) acc[t] = 0;
+    if (t < EXPAND_HOST_WORDS) h_flags[t] = flags[t];
+    long long en = t < STRIPES ? acc[A_ENERGY_S + t * STRIPE_LL] : 0ll;      // k_energy's (or k_argmin_labels') stripes
+    if (t < STRIPES) acc[A_ENERGY_S + t * STRIPE_LL] = 0;                     // the next k_energy accumulates from zero
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) en += __shfl_xor(en, m, 64);
+    if (t < A_COUNT) h_acc[t] = t == A_ENERGY ? en : acc[t];
 }
 
-static hipError_t fetch(ExpandWork& w, hipStream_t s)
+static hipError_t fetch(ExpandWork& w, ExpandStats& st, hipStream_t s)
 {
-    ++w.host_syncs;
+    ++st.host_syncs;
+    ++st.launches;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, w.flags, w.acc, w.h_flags_dev, w.h_acc_dev);
     RET_IF(hipGetLastError());
     return hipStreamSynchronize(s);
-}
-
-static hipError_t total_energy(const Graph& g, int potts, ExpandWork& w, long long* out,
-                               hipStream_t s)
-{
-    const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK), blk(256);
-    RET_IF(hipMemsetAsync(&w.acc[A_ENERGY], 0, sizeof(long long), s));
-    hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.acc);
-    RET_IF(hipGetLastError());
-    RET_IF(fetch(w, s));
-    *out = w.h_acc[A_ENERGY];
-    return hipSuccess;
 }
 
 hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, ExpandWork& w,
                          int max_cycles, ExpandStats* st, hipStream_t s)
 {
     const dim3 grid1((g.n + 255) / 256), blk(256);                          // one thread per site
-    const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site
+    const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site, 256 threads
+    const int sites_big = 1024 / LPN;
+    const dim3 grid_big((g.n + sites_big - 1) / sites_big), blk_big(1024); // LPN lanes per site, 1024 threads
     ExpandStats stats = {};
-    w.host_syncs = 0;
-    RET_IF(hipMemsetAsync(w.flags, 0, sizeof(int) * F_COUNT, s));
-    RET_IF(hipMemsetAsync(w.acc, 0, sizeof(long long) * A_COUNT, s));
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, s, w.flags, w.acc);
+    RET_IF(hipGetLastError());
+    ++stats.launches;
 
     if (g.nnz == 0) {                                  // solveSpecialCases, :470-491
         RET_IF(launch_argmin_labels(cost, L, g.n, w.label, w.acc, s));
-        RET_IF(fetch(w, s));
+        RET_IF(fetch(w, stats, s));
         stats.energy = w.h_acc[A_ENERGY];
         if (st) *st = stats;
         return hipSuccess;
     }
 
     long long energy = 0, old_energy = 0;
-    RET_IF(total_energy(g, potts, w, &energy, s));     // :1036
-    int bfs_need = w.bfs_batch;                        // relax launches before the first check of a relabel
+    hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.flags, w.acc);     // :1036
+    RET_IF(fetch(w, stats, s));
+    stats.launches += 1;
+    energy = w.h_acc[A_ENERGY];
 
+    SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20 };
+    int solve_grid = w.solve_grid > 0 ? w.solve_grid : 128;
+    int t = 0;
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         old_energy = energy;
-        for (int alpha = 0; alpha < L; ++alpha) {
+        for (int alpha = 0; alpha < L; ++alpha, ++t) {
             ++stats.moves;
-            // (ACTIVE, CHANGED, EXCESS_NODES, EXCESS_SUM were zeroed by the last k_publish; DELTA by k_move_setup)
-            hipLaunchKernelGGL(k_move_setup, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
-                               w.cur_cost, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
+            hipLaunchKernelGGL(k_move_setup, grid, blk, 0, s, g, cost, L, potts, alpha, t, w.reduce_rounds > 0 ? 1 : 0,
+                               w.label, w.cur_cost, w.took, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_big, blk_big, 0, s, g, L, t, w.cap, w.excess,
+                               w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_big, blk_big, 0, s, g, L, t, w.cap, w.excess,
+                               w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
+            hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), 0, s, g, L, t, w.cap, w.sent, w.excess,
+                               w.sink_cap, w.aux, w.height, w.decided, w.core, w.flags, w.acc,
+                               (w.trace && t < w.trace_moves) ? w.trace : nullptr,
+                               (w.trace && t == w.detail_move) ? w.trace + 8 * (size_t)w.trace_moves : nullptr, sp);
+            hipLaunchKernelGGL(k_delta, grid, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
+                               w.decided, w.took, w.flags, w.acc);
             RET_IF(hipGetLastError());
-            // The first host check of the move looks at the set-up counters (overflow, number of sites
-            // with excess) and, in the same round trip, at the first batch of the dominance reduction.
-            bool flow_needed = true, first_check = true, skip_move = false;
-            for (;;) {
-                if (w.reduce_rounds > 0) {
-                    // four launches per host check; only the last one's flag decides (a launch that
-                    // changed nothing is the fixed point)
-                    for (int b = 0; b < 4; ++b)
-                        hipLaunchKernelGGL(k_reduce, grid, blk, 0, s, g, w.cap, w.excess, w.sink_cap, w.decided,
-                                           w.flags, &w.flags[b == 3 ? F_CHANGED : F_SCRATCH], w.reduce_rounds);
-                    stats.reduce_launches += 4;
-                    hipLaunchKernelGGL(k_count_undecided, grid1, blk, 0, s, g.n, w.excess, w.decided, w.flags);
-                    RET_IF(hipGetLastError());
-                }
-                RET_IF(fetch(w, s));
-                if (w.h_flags[F_OVERFLOW] || (first_check && w.h_acc[A_EXCESS_SUM] > 0x7fffffffll)) {
-                    if (st) { stats.energy = -1; *st = stats; }
-                    return hipErrorInvalidValue;       // int32 energy terms would overflow
-                }
-                // No excess anywhere: max-flow is 0, after == before, the move is rejected (:1259).
-                if (first_check && w.h_flags[F_EXCESS_NODES] == 0) { skip_move = true; break; }
-                first_check = false;
-                if (w.reduce_rounds <= 0) break;
-                // no undecided site holds excess: nothing can flow any more, the residual graph is final
-                flow_needed = w.h_flags[F_UNDECIDED_EXCESS] != 0;
-                if (!w.h_flags[F_CHANGED]) break;
-            }
-            if (skip_move) continue;
-            if (flow_needed) ++stats.flow_moves;
-
-            for (int round = 0; round < 100000; ++round) {
-                // exact global relabel
-                hipLaunchKernelGGL(k_bfs_init, grid1, blk, 0, s, g.n, w.decided, w.sink_cap,
-                                   w.height);
-                // Batches of relaxation launches; the flag of the LAST launch of a batch decides
-                // (a launch that lowered nothing is a fixed point).  The active count is taken
-                // in the same batch: it is only trusted when that last launch changed nothing.
-                // The first batch is as long as the previous relabel needed (relabels of one move, and of
-                // neighbouring moves, converge in similar numbers of launches): usually one host check.
-                int launched = 0;
-                for (int batch = bfs_need;; batch = w.bfs_batch) {
-                    for (int b = 0; b < batch; ++b) {
-                        hipLaunchKernelGGL(k_bfs_relax, grid, blk, 0, s, g, w.decided, w.cap, w.height,
-                                           &w.flags[b == batch - 1 ? F_CHANGED : F_SCRATCH], w.bfs_rounds);
-                        ++stats.bfs_launches;
-                    }
-                    launched += batch;
-                    hipLaunchKernelGGL(k_count_active, grid1, blk, 0, s, g.n, w.excess, w.height, w.decided, w.flags);
-                    RET_IF(hipGetLastError());
-                    RET_IF(fetch(w, s));
-                    if (!w.h_flags[F_CHANGED]) break;
-                }
-                bfs_need = launched > bfs_need ? launched : bfs_need - 1;
-                if (bfs_need < w.bfs_batch) bfs_need = w.bfs_batch;
-                if (bfs_need > 12) bfs_need = 12;
-                if (w.h_flags[F_ACTIVE] == 0) break;
-                for (int b = 0; b < w.pr_batch; ++b) {
-                    hipLaunchKernelGGL(k_push_relabel, grid, blk, 0, s, g, w.decided,
-                                       w.cap, w.excess, w.sink_cap, w.height, w.pr_cycles);
-                    ++stats.pr_launches;
-                }
-                RET_IF(hipGetLastError());
-            }
-            hipLaunchKernelGGL(k_delta, grid, blk, 0, s, g, cost, L, potts, alpha, w.label,
-                               w.cur_cost, w.height, w.acc);
-            hipLaunchKernelGGL(k_apply, grid1, blk, 0, s, g.n, cost, L, alpha, w.label, w.cur_cost,
-                               w.height, w.acc, w.flags);
-            RET_IF(hipGetLastError());
+            stats.launches += 5;
+            if (w.reduce_rounds > 0) stats.reduce_launches += 2;
         }
-        RET_IF(total_energy(g, potts, w, &energy, s));
+        hipLaunchKernelGGL(k_apply_pending, grid1, blk, 0, s, g.n, cost, L, w.label, w.cur_cost, w.took, w.flags);
+        hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.flags, w.acc);
+        stats.launches += 2;
+        RET_IF(fetch(w, stats, s));
         stats.cycles = cycle;
+        if (w.h_flags[C_ERROR]) {
+            stats.energy = -(long long)w.h_flags[C_ERROR];
+            if (st) *st = stats;
+            return w.h_flags[C_ERROR] == ERR_OVERFLOW ? hipErrorInvalidValue : hipErrorLaunchTimeOut;
+        }
+        energy = w.h_acc[A_ENERGY];
         if (energy == old_energy) break;               // :1045
     }
     stats.energy = energy;
-    stats.host_syncs = w.host_syncs;
-    stats.accepted = w.h_flags[F_ACCEPTED];
+    stats.accepted = w.h_flags[C_ACCEPTED];
+    stats.flow_moves = w.h_flags[C_FLOW_MOVES];
+    stats.moves_solved = w.h_flags[C_MOVES_SOLVED];
+    stats.moves_run = w.h_flags[C_MOVES_RUN];
+    stats.core_sites = w.h_acc[A_CORE_SUM];
+    stats.core_max = w.h_flags[C_CORE_MAX];
+    stats.outer_iterations = w.h_acc[A_OUTER];
+    stats.relax_intervals = w.h_acc[A_RELAX];
+    stats.push_phases = w.h_acc[A_PUSH];
+    stats.barriers = w.h_acc[A_BARRIERS];
+    stats.solve_ms = (double)w.h_acc[A_TICKS] * 1e-5;  // 100 MHz ticks
+    stats.barrier_ms = (double)w.h_acc[A_T_BAR] * 1e-5;
+    stats.relax_ms = (double)w.h_acc[A_T_RELAX] * 1e-5;
+    stats.push_ms = (double)w.h_acc[A_T_PUSH] * 1e-5;
     if (st) *st = stats;
     return hipSuccess;
 }

@@ -107,28 +107,49 @@ struct Graph {              // symmetric weighted CSR in HBM
 struct ExpandWork {         // scratch owned by the engine
     int* label;             // n   current labeling (GCO numbering)
     int* cur_cost;          // n   cost[i][label[i]]
-    int* cap;               // nnz residual capacities
+    int* cap;               // nnz capacities of the move's s-t graph
+    int* sent;              // nnz cumulative flow per arc, written by the arc's tail only (expand.hip, k_solve)
     int* excess;            // n
     int* sink_cap;          // n
     int* height;            // n
+    int* aux;               // 2n  per-site solver state of rows that walk several sites (expand.hip, k_solve)
     int* decided;           // n   0 undecided, 1 source side (takes alpha), 2 sink side (keeps its label), 3 not in the graph
-    int* flags;             // device control words (see expand.hip)
-    long long* acc;         // device 64-bit accumulators
+    unsigned char* took;    // n   1 where the last solved move moves the site to alpha (applied lazily, see expand.hip)
+    int* core;              // 8 x n  compacted list of the sites the dominance reduction left undecided, in 8 shards
+    int* flags;             // device control words (EXPAND_FLAG_WORDS ints, see expand.hip)
+    long long* acc;         // device 64-bit accumulators (EXPAND_ACC_WORDS)
     int* h_flags;           // pinned, device-mapped host mirror of flags (host address)
     long long* h_acc;       // pinned, device-mapped host mirror of acc (host address)
     int* h_flags_dev;       // device addresses of the two mirrors
     long long* h_acc_dev;
-    int bfs_rounds, bfs_batch, pr_cycles, pr_batch;   // schedule knobs (see expand.hip)
+    // schedule knobs of the per-move solver (see expand.hip): relaxation rounds per barrier interval, push cycles per
+    // push phase, push phases per global relabel, workgroups of the solver launch
+    int relax_rounds, push_cycles, push_phases, solve_grid, push_mult;
     int reduce_rounds;      // dominance-reduction rounds per launch; 0 switches the reduction off (A/B)
-    long long host_syncs = 0;   // host synchronisations of the running expansion (stats)
+    int* trace;             // optional: 8 ints per move {core sites, workgroups, relabels, relax intervals, push phases,
+    int trace_moves;        //   barriers, ticks (100 MHz), ticks inside barriers}; moves beyond trace_moves are not traced
+    int detail_move;        // move whose global relabels are logged behind the trace (4 ints each, at most 2048): {active sites,
+                            //   largest finite height, relabel intervals so far, ticks so far}; -1 none
 };
+constexpr int EXPAND_FLAG_WORDS = 896;     // device control block (expand.hip)
+constexpr int EXPAND_HOST_WORDS = 32;      // its head, mirrored to the host
+constexpr int EXPAND_ACC_WORDS = 64 + 3 * 64 * 16;   // 16 scalars (mirrored to the host) + three striped sums
+constexpr int EXPAND_CORE_SHARDS = 8;
 
 struct ExpandStats {
     int cycles;
     long long energy;
-    int moves, accepted;
-    long long pr_launches, bfs_launches, host_syncs;
+    int moves, accepted;                      // moves enqueued; moves that lowered the energy
+    long long push_phases, relax_intervals;   // summed over the moves that were solved
+    long long host_syncs;
     long long reduce_launches, flow_moves;    // reduction launches; moves that still needed push-relabel
+    long long launches;                       // kernel launches of the whole expansion
+    long long moves_run;                      // moves not skipped as provably idempotent
+    long long moves_solved;                   // of those, moves whose core was not empty (k_solve had work)
+    long long core_sites, core_max;           // undecided sites handed to the solver: sum and maximum over moves
+    long long barriers, outer_iterations;     // grid barriers / global relabels inside the solver launches
+    double solve_ms;                          // time inside the solver launches (device clock of workgroup 0)
+    double barrier_ms, relax_ms, push_ms;     // of which: inside grid barriers; global relabels; push phases (the last two include their barriers)
 };
 
 hipError_t run_expansion(const Graph& g, const int* cost /* n x L */, int L, int potts,

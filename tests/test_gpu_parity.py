@@ -198,6 +198,46 @@ def test_dominance_reduction_changes_nothing(engine, synth, oracle, lam):
         engine.set_params(2.6, THR, 0.005, LAM, 20)
 
 
+@pytest.mark.parametrize("case", ["rows_walk_several_sites", "one_workgroup", "degree_above_register_slots", "no_reduction_large_core"])
+def test_expand_solver_paths(engine, synth, oracle, case):
+    """The per-move solver launch (csrc/expand.hip k_solve) has several code paths that the default sizes never
+    take: rows that walk several sites (core larger than the launch holds one site per row), a single workgroup,
+    sites whose degree exceeds the arcs a row keeps in registers (arcs walked in memory), and the whole graph as
+    core (dominance reduction off).  Each must give the oracle's labels, energy and cycle count."""
+    knn = 16
+    n, k, grid, reduce_rounds = 3000, 4, 256, 4
+    if case == "rows_walk_several_sites":
+        grid, reduce_rounds = 3, 0                       # 3 workgroups x 64 rows for ~3000 core sites
+    elif case == "one_workgroup":
+        grid = 1
+    elif case == "degree_above_register_slots":
+        knn, n = 31, 2500                                # symmetric closure of 31-NN: many sites above 48 arcs
+    elif case == "no_reduction_large_core":
+        n, reduce_rounds = 20000, 0                      # ~20 000 core sites > 256 workgroups x 64 rows
+    sc = synth.make_scene(n, k, seed=11, knn=knn, noise=1.0, outlier_frac=0.3)
+    H = _models(sc, np.random.default_rng(5), extra=3)
+    _load(engine, sc)
+    if case == "degree_above_register_slots":
+        rp, _, _ = engine.get_sym_graph()
+        assert np.diff(rp).max() > 48
+    engine.set_models(H)
+    cost = engine.data_cost()
+    lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM))
+    try:
+        engine.set_tuning(5, grid)
+        engine.set_tuning(6, reduce_rounds)
+        labels, energy, cycles = engine.expand()
+        st = engine.expand_stats()
+    finally:
+        engine.set_tuning(5, 256)
+        engine.set_tuning(6, 4)
+    assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), case
+    if case in ("rows_walk_several_sites", "no_reduction_large_core"):
+        assert st["core_max"] > grid * 64, "the case did not reach the several-sites-per-row path"
+    assert st["moves_run"] < st["moves"], "the converged last cycle should have been skipped on the device"
+    assert st["host_syncs"] <= st["cycles"] + 2
+
+
 def test_expand_without_neighbours_is_argmin(engine, synth, oracle):
     sc = synth.make_scene(500, 3, seed=2, with_neighbours=False)
     _load(engine, sc, neighbours=False)
