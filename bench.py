@@ -235,7 +235,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         n_res, ms_res = eng.profile_get(1)       # MH_K_RESIDUAL

@@ -45,6 +45,10 @@ def gather_scores(local: torch.Tensor, world: int, out: torch.Tensor | None = No
     (strong scaling with world not dividing M) pad to the longest shard and strip the padding."""
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal on a box with fewer GPUs than ranks (tests): gloo moves host memory, so stage through it.
+        # On a real node the backend is "nccl" (= RCCL) and the branches below run on the device buffers.
+        return gather_scores(local.cpu(), world, None, sizes).to(local.device)
     if sizes is None or len(set(sizes)) == 1:
         if out is None:
             out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)

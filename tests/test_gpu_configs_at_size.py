@@ -1,0 +1,92 @@
+"""BASELINE.json configs[3] and configs[4] at their stated sizes on the one GPU of the test box.
+
+configs[3]: ONE batch of 100 000 hypotheses x 50 000 correspondences split across ranks, all-gather of the
+int32 scores (`bench.py --scaling strong`).  The ranks share the device and exchange over gloo (RCCL refuses
+two ranks on one GPU); the split, the counters, the gather and the selection are the code the 8-GPU run uses.
+The ranks are started by bench.py itself (`--gpus N` without a launcher).
+
+configs[4]: the full loop — 50 000 correspondences / 10 planes / 100 000 proposals / 20 fixed iterations —
+through class MultiH (tools/loop_bench.py), one process against two processes with the sharded propose stage.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def _bench(gpus, *args):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", *args]
+    env = _clean_env(MH_BENCH_BACKEND="gloo", MH_BENCH_DEVICE="0")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_configs3_strong_split_over_ranks_equals_the_single_rank_batch():
+    one = _bench(1)
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong"
+    assert one["config"]["points"] == 50000 and one["config"]["models_per_step"] == 100000
+    assert one["roofline"]["traffic_source"] is None or "profiles/" in one["roofline"]["traffic_source"]
+    for world in (2, 3):                                   # 3: a ragged split (33 334 / 33 333 / 33 333)
+        got = _bench(world)
+        assert got["n_gpus"] == world and got["scaling"] == "strong"
+        assert "configs[3]" in got["config"]["workload"]
+        assert got["config"]["models_per_step"] == 100000
+        # same counters -> same hypotheses -> the gathered score vector is the single-rank one, bit for bit
+        assert got["scores_sha256"] == one["scores_sha256"]
+        assert (got["best_model"], got["best_score"]) == (one["best_model"], one["best_score"])
+        weak = got["weak_scaling"]
+        assert weak["models_per_step"] == 100000 * world and weak["value"] > 0
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """`bench.py --gpus N` run by hand spawns its ranks and must end non-zero when one of them dies."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--points", "-5"]
+    out = subprocess.run(cmd, env=_clean_env(MH_BENCH_BACKEND="gloo", MH_BENCH_DEVICE="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _loop(world):
+    env = _clean_env(N="50000", K="10", HYP="100000", ITERS="20", LOOP_BACKEND="gloo", LOOP_DEVICE="0")
+    script = os.path.join(ROOT, "tools", "loop_bench.py")
+    if world == 1:
+        cmd = [sys.executable, script]
+    else:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"loop_bench_world{world}.json"), "w") as f:
+        json.dump(rec, f)
+    return rec
+
+
+def test_configs4_full_loop_at_size_is_independent_of_world_size():
+    one = _loop(1)
+    # GetIterationNumber() is the reference's `iteration_number - 1` (M/MultiH.cpp:311): 19 after 20 iterations
+    assert one["points"] == 50000 and one["hypotheses"] == 100000 and one["iterations"] == 19
+    assert one["clusters"] >= 5, "10 planes were generated; merging and the compatibility check keep the supported ones"
+    two = _loop(2)
+    assert two["ranks_identical"] and two["exchanges"] > 0
+    assert two["digest"] == one["digest"] and two["clusters"] == one["clusters"] and two["energy"] == one["energy"]
