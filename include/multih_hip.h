@@ -79,6 +79,10 @@ MH_API int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col,
 /* Exact k-NN hit list built on the GPU in float32 (x1,y1,x2,y2) space — the engine's own
  * replacement for the FLANN radius search (deviation documented). */
 MH_API int mh_build_neighbors_knn(mh_engine* e, int k);
+/* The same k nearest hits, but only those within `radius` of the query (radius <= 0: no cut): the reference's
+ * radius (1/locality_lambda) with the list bounded the way FLANN's default search bounds it in practice
+ * (32 checks: a few dozen approximate nearest neighbours, never the full ball). */
+MH_API int mh_build_neighbors_knn_radius(mh_engine* e, int k, double radius);
 /* The reference's neighbourhood rule itself (M/MultiH.cpp:252-253, radiusMatch with maxDistance =
  * 1/locality_lambda), answered exactly instead of by FLANN's randomised KD-trees: query i hits
  * every j (itself included) whose float32 squared distance in (x1,y1,x2,y2) is <= radius^2.

@@ -22,7 +22,7 @@ K_DLT4, K_RESIDUAL, K_SCORE, K_DATACOST, K_EXPAND, K_REESTIMATE = 0, 1, 2, 3, 4,
 SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
-    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_build_neighbors_radius", "mh_get_sym_graph", "mh_propose_fund8",
+    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_build_neighbors_knn_radius", "mh_build_neighbors_radius", "mh_get_sym_graph", "mh_propose_fund8",
     "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
@@ -136,8 +136,12 @@ class Engine:
         cp = _p(col, C.c_int) if col.size else None
         self._check(self.lib.mh_set_neighbors_csr(self._h, _p(rowptr, C.c_int), cp, rowptr.size - 1))
 
-    def build_neighbors_knn(self, k: int):
-        self._check(self.lib.mh_build_neighbors_knn(self._h, int(k)))
+    def build_neighbors_knn(self, k: int, radius: float = 0.0):
+        """k nearest hits per query; radius > 0 keeps only those within it (the reference's 1/locality)."""
+        if radius > 0.0:
+            self._check(self.lib.mh_build_neighbors_knn_radius(self._h, int(k), C.c_double(radius)))
+        else:
+            self._check(self.lib.mh_build_neighbors_knn(self._h, int(k)))
 
     def build_neighbors_radius(self, radius: float, max_hits: int = 0) -> int:
         hits = C.c_longlong(0)

@@ -525,7 +525,8 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
     HIPCHK(e->x2.reserve(cap)); HIPCHK(e->y2.reserve(cap));
     HIPCHK(e->a11.reserve(cap)); HIPCHK(e->a12.reserve(cap));
     HIPCHK(e->a21.reserve(cap)); HIPCHK(e->a22.reserve(cap));
-    DevBuf<double> s, d, a;
+    struct Staging { DevBuf<double> b; ~Staging() { b.release(); } } st_s, st_d, st_a;   // freed on every return path
+    DevBuf<double>&s = st_s.b, &d = st_d.b, &a = st_a.b;
     HIPCHK(s.reserve((size_t)n * 2));
     HIPCHK(d.reserve((size_t)n * 2));
     HIPCHK(hipMemcpyAsync(s.p, src_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, e->stream));
@@ -539,7 +540,11 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
                        e->a12.p, e->a21.p, e->a22.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
-    s.release(); d.release(); a.release();
+    if (n != e->n) {
+        // everything sized by the previous point set is stale: the residual matrix and its pitch, the sampled batch,
+        // the fundamental-matrix hypotheses
+        e->m = 0; e->ldr = 0; e->have_samples = false; e->fm = 0;
+    }
     e->n = n;
     e->have_aff = affines != nullptr;
     e->have_graph = false;
@@ -574,22 +579,58 @@ int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col, int n)
     });
 }
 
-int mh_build_neighbors_knn(mh_engine* e, int k)
+// k nearest hits per query, optionally only those within `radius` (<= 0: no cut).
+static int build_knn_graph(mh_engine* e, int k, double radius)
 {
-    return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (k < 1 || k > 32 || k >= e->n) return fail(MH_ERR_INVALID, "k must be in [1, 32] and < n");
-    HIPCHK(e->knn_tmp.reserve((size_t)e->n * k));
+    const int n = e->n;
+    HIPCHK(e->knn_tmp.reserve((size_t)n * k));
     HIPCHK(launch_knn(e->pts(), k, e->knn_tmp.p, e->stream));
-    std::vector<int> col((size_t)e->n * k), rowptr(e->n + 1);
+    std::vector<int> col((size_t)n * k), rowptr(n + 1);
     HIPCHK(hipMemcpyAsync(col.data(), e->knn_tmp.p, sizeof(int) * col.size(), hipMemcpyDeviceToHost, e->stream));
+    std::vector<double> xy;
+    if (radius > 0.0) {
+        xy.resize(4 * (size_t)n);
+        const double* srcs[4] = { e->x1.p, e->y1.p, e->x2.p, e->y2.p };
+        for (int c = 0; c < 4; ++c)
+            HIPCHK(hipMemcpyAsync(xy.data() + (size_t)c * n, srcs[c], sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (int i = 0; i <= e->n; ++i) rowptr[i] = i * k;
-    rc = build_sym_graph(e, rowptr.data(), col.data(), e->n);
+    if (radius > 0.0) {
+        // the reference's radius (M/MultiH.cpp:252-253) in the kernels' float32 arithmetic: ((dx^2+dy^2)+dz^2)+dw^2 <= r^2
+        const float r2 = (float)radius * (float)radius;
+        size_t w = 0;
+        for (int i = 0; i < n; ++i) {
+            rowptr[i] = (int)w;
+            for (int j = 0; j < k; ++j) {
+                const int c = col[(size_t)i * k + j];
+                if (c < 0 || c >= n) return fail(MH_ERR_INVALID, "neighbour index out of range (non-finite coordinates?)");
+                const float dx = (float)xy[i] - (float)xy[c], dy = (float)xy[(size_t)n + i] - (float)xy[(size_t)n + c];
+                const float dz = (float)xy[2 * (size_t)n + i] - (float)xy[2 * (size_t)n + c];
+                const float dw = (float)xy[3 * (size_t)n + i] - (float)xy[3 * (size_t)n + c];
+                const float d = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
+                if (d <= r2) col[w++] = c;
+            }
+        }
+        rowptr[n] = (int)w;
+    } else {
+        for (int i = 0; i <= n; ++i) rowptr[i] = i * k;
+    }
+    rc = build_sym_graph(e, rowptr.data(), col.data(), n);
     if (rc) return rc;
     return upload_graph(e);
-    });
+}
+
+int mh_build_neighbors_knn(mh_engine* e, int k)
+{
+    return guarded([&]() -> int { return build_knn_graph(e, k, 0.0); });
+}
+
+int mh_build_neighbors_knn_radius(mh_engine* e, int k, double radius)
+{
+    return guarded([&]() -> int { return build_knn_graph(e, k, radius); });
 }
 
 int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, long long* hits_out)
@@ -876,6 +917,13 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             HIPCHK(hipMemcpyAsync(e->h_ms_list, e->ms_list.p, sizeof(int) * 2 * MS_LIST_PREFIX, hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             if (out[1] || out[3]) break;
+        }
+        if (!out[1] && !out[3]) {
+            // the climb neither converged nor died within the cap: compact and clear its votes (they would leak into the
+            // next climb's membership list) and give up loudly
+            HIPCHK(launch_ms_collect(w, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            return fail(MH_ERR_INVALID, "mean shift: a climb did not converge within 20000 batches of iterations");
         }
         const int len = out[2];
         list.resize(2 * (size_t)len);
@@ -1278,7 +1326,7 @@ int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long
     switch (which) {
     case MH_BUF_COUNTS: *ptr_dev = e->counts.p; *bytes = sizeof(int) * (size_t)e->m; break;
     case MH_BUF_MODELS: *ptr_dev = e->H.p; *bytes = sizeof(double) * 9 * (size_t)e->m; break;
-    case MH_BUF_RESIDUALS: *ptr_dev = e->R.p; *bytes = sizeof(double) * (size_t)e->m * (size_t)e->ldr; break;
+    case MH_BUF_RESIDUALS: *ptr_dev = (e->ldr > 0 && e->m > 0) ? e->R.p : nullptr; *bytes = sizeof(double) * (size_t)e->m * (size_t)e->ldr; break;
     case MH_BUF_LABELS: *ptr_dev = e->ew_label.p; *bytes = sizeof(int) * (size_t)e->n; break;
     case MH_BUF_COST: *ptr_dev = e->cost.p; *bytes = sizeof(int) * (size_t)e->n * e->cost_L; break;
     default: return fail(MH_ERR_INVALID, "unknown buffer id");

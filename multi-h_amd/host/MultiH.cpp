@@ -16,13 +16,17 @@
 
 namespace {
 
-cv::Mat MatFrom9(const double* h)
+// A matrix that OWNS its storage, filled from a raw array: allocate, then copy.  (cv::Mat(rows, cols, type, ptr) would
+// only be a header over the caller's memory.)
+cv::Mat OwnedMat(int rows, int cols, const double* v)
 {
-    cv::Mat m(3, 3, CV_64F);
+    cv::Mat m(rows, cols, CV_64F);
     double* p = reinterpret_cast<double*>(m.data);
-    for (int i = 0; i < 9; ++i) p[i] = h[i];
+    for (int i = 0; i < rows * cols; ++i) p[i] = v[i];
     return m;
 }
+
+cv::Mat MatFrom9(const double* h) { return OwnedMat(3, 3, h); }
 
 bool Check(int rc, const char* what)
 {
@@ -160,7 +164,7 @@ bool MultiH::Process()
                     const double* r = &refined[8 * (size_t)i];
                     s2.push_back(cv::Point2d(r[0], r[1]));
                     d2.push_back(cv::Point2d(r[2], r[3]));
-                    a2.push_back(cv::Mat(2, 2, CV_64F, r + 4));
+                    a2.push_back(OwnedMat(2, 2, r + 4));
                 }
             printf("[Multi-H] %d points kept from the initial %d after filtering.\n", (int)s2.size(), N);   // :840
             if (s2.size() < 8) {
@@ -239,6 +243,43 @@ void MultiH::HomographyCompatibilityCheck()
                                                 minimum_inlier_number, proposal_seed ^ 0xc0117a7ull);
     cluster_homographies.clear();
     for (int i = 0; i < kept; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
+}
+
+// DrawClusters, M/MultiH.cpp:314-350: one filled circle per labelled correspondence in each image, colour by plane.
+// The reference's fixed palette (:322-332) for the first eleven planes; it writes all eleven entries whatever the
+// number of planes (out of bounds below eleven planes), which is not reproduced: the palette is sized first.
+void MultiH::DrawClusters(cv::Mat& img1, cv::Mat& img2, int size)
+{
+    static const double fixed[11][3] = { { 255, 0, 0 }, { 255, 255, 255 }, { 0, 0, 255 }, { 255, 255, 0 }, { 255, 0, 255 },
+                                         { 0, 255, 255 }, { 0, 255, 0 }, { 127, 255, 0 }, { 0, 255, 127 }, { 127, 127, 0 },
+                                         { 63, 255, 127 } };
+    const size_t k = cluster_homographies.size();
+    std::vector<cv::Scalar> colors(std::max<size_t>(k + 1, 12));
+    colors[0] = cv::Scalar(0, 0, 0);
+    uint64_t z = proposal_seed ^ 0xc0105ull;                              // planes beyond the palette: counter RNG, not rand()
+    for (size_t i = 1; i < colors.size(); ++i) {
+        if (i <= 11) { colors[i] = cv::Scalar(fixed[i - 1][0], fixed[i - 1][1], fixed[i - 1][2]); continue; }
+        double c[3];
+        for (double& v : c) {
+            z += 0x9E3779B97F4A7C15ull;
+            uint64_t x = z;
+            x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+            x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+            v = 255.0 * (double)((x ^ (x >> 31)) >> 11) * (1.0 / 9007199254740992.0);
+        }
+        colors[i] = cv::Scalar(c[0], c[1], c[2]);
+    }
+    for (size_t i = 0; i < labeling.size(); ++i) {
+        if (labeling[i] == -1) continue;                                                  // :336
+        const cv::Scalar& col = colors[(size_t)labeling[i] + 1];
+        if (k == 1 && i < src_points_original.size()) {                                   // degenerate path labels the ORIGINAL points, :339-343
+            cv::circle(img1, src_points_original[i], size, col, -1);
+            cv::circle(img2, dst_points_original[i], size, col, -1);
+        } else if (i < src_points.size()) {
+            cv::circle(img1, src_points[i], size, col, -1);
+            cv::circle(img2, dst_points[i], size, col, -1);
+        }
+    }
 }
 
 bool MultiH::UploadModels()
@@ -413,9 +454,8 @@ void MultiH::ClusterMergingAndLabeling()
     auto start = std::chrono::system_clock::now();
     const int N = static_cast<int>(src_points.size());
 
-    // Neighbourhood (M/MultiH.cpp:233-253).  Given hits are used as they are; otherwise the
-    // engine builds exact k-NN hits in the same float32 (x1,y1,x2,y2) space (deviation
-    // from FLANN's approximate radius search).
+    // Neighbourhood (M/MultiH.cpp:233-253).  Given hits are used as they are; otherwise the engine builds them in the
+    // same float32 (x1,y1,x2,y2) space (MultiH.h, SetNeighbourK / SetNeighbourRadius).
     bool ok;
     if (!neighbours.empty()) {
         std::vector<int> rowptr(N + 1, 0), col;
@@ -424,12 +464,21 @@ void MultiH::ClusterMergingAndLabeling()
             rowptr[i + 1] = static_cast<int>(col.size());
         }
         ok = Check(mh_set_neighbors_csr(engine, rowptr.data(), col.data(), N), "mh_set_neighbors_csr");
-    } else if (neighbour_radius > 0.0) {
-        long long hits = 0;
-        ok = Check(mh_build_neighbors_radius(engine, neighbour_radius, neighbour_max_hits, &hits), "mh_build_neighbors_radius");
-        if (ok && log_to_console) printf("[Multi-H] %lld neighbourhood hits within %.1f px\n", hits, neighbour_radius);
+    } else if (neighbour_mode == NEIGHBOURS_KNN) {
+        // the k nearest hits within the reference's radius 1 / locality_lambda (M/MultiH.cpp:252-253); see MultiH.h
+        ok = Check(mh_build_neighbors_knn_radius(engine, std::min(knn, N - 1), 1.0 / locality_lambda), "mh_build_neighbors_knn_radius");
     } else {
-        ok = Check(mh_build_neighbors_knn(engine, std::min(knn, N - 1)), "mh_build_neighbors_knn");
+        // the complete radius list, answered exactly; it grows like N^2, and beyond `neighbour_max_hits` the engine refuses
+        long long hits = 0;
+        const int rc = mh_build_neighbors_radius(engine, neighbour_radius, neighbour_max_hits, &hits);
+        if (rc == MH_ERR_OVERFLOW) {
+            printf("[Multi-H] %lld neighbourhood hits within %.1f px exceed the limit of %lld: using the %d nearest hits instead\n",
+                   hits, neighbour_radius, neighbour_max_hits, std::min(knn, N - 1));
+            ok = Check(mh_build_neighbors_knn_radius(engine, std::min(knn, N - 1), neighbour_radius), "mh_build_neighbors_knn_radius");
+        } else {
+            ok = Check(rc, "mh_build_neighbors_radius");
+            if (ok && log_to_console) printf("[Multi-H] %lld neighbourhood hits within %.1f px\n", hits, neighbour_radius);
+        }
     }
     std::chrono::duration<double> el = std::chrono::system_clock::now() - start;
     printf("[Multi-H] Adjacency-matrix calculation time = %f secs\n", el.count());      // :258
@@ -555,6 +604,19 @@ void MultiH::HandleDegenerateCase()
 {
     const int N = static_cast<int>(src_points_original.size());
     labeling.assign(N, -1);
+    // The engine may still hold the FILTERED, refined correspondences (Process() re-uploads them after
+    // GetFundamentalMatrixAndRefineData); the reference fits and labels the originals here (:725-739).
+    {
+        std::vector<double> s(2 * (size_t)N), d(2 * (size_t)N), a(4 * (size_t)N);
+        for (int i = 0; i < N; ++i) {
+            s[2 * i] = src_points_original[i].x; s[2 * i + 1] = src_points_original[i].y;
+            d[2 * i] = dst_points_original[i].x; d[2 * i + 1] = dst_points_original[i].y;
+            const cv::Mat& A = affinities_original[i];
+            a[4 * i] = A.at<double>(0, 0); a[4 * i + 1] = A.at<double>(0, 1);
+            a[4 * i + 2] = A.at<double>(1, 0); a[4 * i + 3] = A.at<double>(1, 1);
+        }
+        if (!Check(mh_set_correspondences(engine, s.data(), d.data(), a.data(), N), "mh_set_correspondences")) return;
+    }
     const int M = std::max(proposal_hypotheses, 1000);
     if (!Check(mh_propose_dlt4(engine, proposal_seed ^ 0xdeadull, 0, M), "mh_propose_dlt4")) return;
     std::vector<int> counts(M);
@@ -581,6 +643,13 @@ static int g_device = 0;
 extern "C" __attribute__((visibility("default")))
 void mhh_set_device(int device) { g_device = device; }
 
+// Neighbourhood of the next mhh_run_process calls: radius > 0 selects the complete radius list, else k > 0 the k nearest
+// hits within 1 / locality; both 0: the class default (k = 16).
+static int g_knn = 0;
+static double g_radius = 0.0;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_neighbourhood(int knn_k, double radius) { g_knn = knn_k; g_radius = radius; }
+
 // ---- C hook for the GPU-side integration test (ctypes; plain arrays in/out) ----------------
 extern "C" __attribute__((visibility("default")))
 int mhh_run_process(const double* src_xy, const double* dst_xy, const double* aff, int n,
@@ -595,7 +664,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     for (int i = 0; i < n; ++i) {
         s[i] = cv::Point2d(src_xy[2 * i], src_xy[2 * i + 1]);
         d[i] = cv::Point2d(dst_xy[2 * i], dst_xy[2 * i + 1]);
-        a[i] = cv::Mat(2, 2, CV_64F, aff + 4 * (size_t)i);
+        a[i] = OwnedMat(2, 2, aff + 4 * (size_t)i);
     }
     MultiH mh(thr_F, thr_H, locality, lambda, min_inliers);
     if (F && e2) mh.SetEpipolarGeometry(F, e2);
@@ -604,10 +673,12 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetIterativeProposal(iter_hypotheses, iter_max_new < 0 ? 4 : iter_max_new);
     mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
     mh.SetDevice(g_device);
+    if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
+    else if (g_knn > 0) mh.SetNeighbourK(g_knn);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init
     if (init_H && n_init > 0) {
         std::vector<cv::Mat> hs;
-        for (int i = 0; i < n_init; ++i) hs.push_back(cv::Mat(3, 3, CV_64F, init_H + 9 * (size_t)i));
+        for (int i = 0; i < n_init; ++i) hs.push_back(MatFrom9(init_H + 9 * (size_t)i));
         mh.SetInitialHomographies(hs);
     }
     if (!mh.Process(s, d, a)) return -1;

@@ -6,17 +6,15 @@
 // to stderr, M/MultiH.cpp:44-50), so `ApplyMultiH` (M/main.cpp:232-311) can
 // construct it, call Process and read the getters unchanged.
 //
-// Scope: Process() runs the propose-score-label hot loop
-// (ClusterMergingAndLabeling, M/MultiH.cpp:224-312) on the GPU.  The OpenCV-bound
-// front half of the reference's Process() — findFundamentalMat, Hartley-Sturm
-// correction, affine consistency, per-point HAF, stable-set initialisation
-// (M/MultiH.cpp:770-848, 696-717, 604-694) — is §8(f) row 4 ("next") and is NOT
-// re-implemented on the GPU: F and the epipoles are either supplied (SetEpipolarGeometry; the points are
-// then taken as already refined) or estimated (8-point RANSAC, Sampson scoring, LS refit) and followed
-// by the per-correspondence refinement (Hartley-Sturm correction, affine consistency filter, optimal
-// affinity).  Optional neighbour hits and initial models can be
-// supplied; when no initial models are given the engine proposes them itself from random minimal
-// samples with the batched 4-point DLT (north_star).
+// Scope: Process() follows the reference's Process() (M/MultiH.cpp:42-98) stage by stage with every heavy
+// stage on the GPU.  The front half (GetFundamentalMatrixAndRefineData, M/MultiH.cpp:770-848) has two routes: the
+// caller hands over F and the epipole (SetEpipolarGeometry — e.g. the reference's own OpenCV code; the points are
+// then taken as already refined), or the engine estimates them itself (8-point RANSAC with Sampson scoring and a
+// least-squares refit, then the per-correspondence Hartley-Sturm correction, affine-consistency filter and optimal
+// affinity of :807-838).  Initial models: SetInitialHomographies, the reference's stable point sets
+// (INIT_STABLE_SETS: per-point HAF homographies -> mean shift -> 3-point fits, :604-717), or — the default — random
+// minimal samples with the batched 4-point DLT (north_star).  Neighbour hits can be supplied (SetNeighbours) or are
+// built on the GPU.
 #pragma once
 
 #include <cstdint>
@@ -62,6 +60,8 @@ public:
     cv::Mat GetHomography(int idx) { return cluster_homographies[idx - 1]; }   // 1-based, :69
     double GetEnergy() { return final_energy; }
     double GetHomographyThreshold() { return threshold_homography; }
+    // M/MultiH.h:71, M/MultiH.cpp:314-350: a filled circle per labelled correspondence, colour by plane.
+    void DrawClusters(cv::Mat& img1, cv::Mat& img2, int size);
     // Post-filter of the reference (M/MultiH.cpp:100-222), host-side (multih::CompatibilityCheck).
     void HomographyCompatibilityCheck();
 
@@ -69,13 +69,17 @@ public:
     // fundamental_matrix (row-major) and epipole_2 = (x, y, 1) (M/MultiH.cpp:775-799).
     void SetEpipolarGeometry(const double F[9], const double e2[2]);
     // `neighbours` (M/MultiH.cpp:252-253): per query the hit indices (self allowed).
-    // Without it Process() builds exact k-NN hits on the GPU (k = knn, default 16).
     void SetNeighbours(const std::vector<std::vector<int>>& hits);
-    void SetNeighbourK(int k) { knn = k; }
-    // The reference's own rule instead: every correspondence within `radius` pixels in the float32
-    // (x1,y1,x2,y2) space is a hit (M/MultiH.cpp:252-253 passes 1/locality_lambda), found exactly on the
-    // GPU.  The hit list grows like N^2, so it is bounded by `max_hits`; beyond it Process() fails.
-    void SetNeighbourRadius(double radius, long long max_hits = 1ll << 28) { neighbour_radius = radius; neighbour_max_hits = max_hits; }
+    // Without SetNeighbours the hits are built on the GPU in the reference's float32 (x1,y1,x2,y2) space.  The reference
+    // asks FLANN for every correspondence within 1 / locality_lambda pixels (radiusMatch, :252-253), but with FLANN's
+    // default search (4 randomised KD-trees, 32 checks) the answer is a few dozen approximate nearest neighbours
+    // inside that ball, never the ball itself — which at the harness defaults holds hundreds of points, enough for the
+    // Potts term to swamp the data term (on the reference's own barrsmith pair the complete list leaves no plane
+    // standing).  Default here: the k = 16 EXACT nearest hits that lie within the reference's radius.
+    void SetNeighbourK(int k) { neighbour_mode = NEIGHBOURS_KNN; knn = k; }
+    // The complete radius list instead (every hit within `radius`, exact), bounded by `max_hits` because it grows like
+    // N^2: beyond the bound the k nearest hits within the radius are used and a line says so.
+    void SetNeighbourRadius(double radius, long long max_hits = 1ll << 28) { neighbour_mode = NEIGHBOURS_RADIUS; neighbour_radius = radius; neighbour_max_hits = max_hits; }
     // Initial cluster_homographies (what EstablishStablePointSets hands to the loop).
     void SetInitialHomographies(const std::vector<cv::Mat>& Hs);
     // How the initial models are made when SetInitialHomographies was not called:
@@ -137,6 +141,8 @@ protected:
     // engine state
     mh_engine* engine = nullptr;
     int device = 0;
+    enum { NEIGHBOURS_KNN = 0, NEIGHBOURS_RADIUS = 1 };
+    int neighbour_mode = NEIGHBOURS_KNN;
     int knn = 16;
     double neighbour_radius = 0.0;
     long long neighbour_max_hits = 1ll << 28;

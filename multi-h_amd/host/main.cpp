@@ -7,7 +7,7 @@
 //   multih_harness <in_corr.txt> <out_result.txt> [--epipolar <file with F(9) e2x e2y>]
 //                  [--thrF 2.6] [--thrH 2.2] [--locality 0.005] [--lambda 0.5] [--min-inliers 20]
 //                  [--hypotheses 10000] [--max-models 32] [--seed 1234] [--iterations 0]
-//                  [--neighbourhood knn|radius]   (radius = the reference's rule, 1/locality pixels)
+//                  [--neighbourhood knn|radius]   (knn, the default: the 16 nearest hits within 1/locality pixels; radius: every hit within it)
 // Defaults are the harness defaults of the reference (M/main.cpp:55-59).
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +29,9 @@ static bool LoadPointsFromFile(std::vector<cv::Point2d>& srcPoints, std::vector<
         srcPoints.push_back(cv::Point2d(x1, y1));
         dstPoints.push_back(cv::Point2d(x2, y2));
         const double a[4] = { a1, a2, a3, a4 };
-        affines.push_back(cv::Mat(2, 2, CV_64F, a));
+        cv::Mat A(2, 2, CV_64F);                                     // owns its storage (M/main.cpp:394 builds a Mat_<double>)
+        for (int q = 0; q < 4; ++q) A.at<double>(q / 2, q % 2) = a[q];
+        affines.push_back(A);
     }
     // The reference also drops F-RANSAC outliers here (findFundamentalMat, :399-409): OpenCV
     // front end, out of scope (§8(f) row 4).
@@ -97,7 +99,7 @@ int main(int argc, char** argv)
     }
     multiH->SetProposal(seed, hypotheses, max_models);
     multiH->SetFixedIterations(iterations);
-    if (neighbourhood == "radius") multiH->SetNeighbourRadius(1.0 / locality);        // M/MultiH.cpp:252-253
+    if (neighbourhood == "radius") multiH->SetNeighbourRadius(1.0 / locality);        // the complete list of M/MultiH.cpp:252-253 (see MultiH.h)
     if (!multiH->Process(srcPointsOrig, dstPointsOrig, origAffines)) { delete multiH; return 1; }
 
     std::vector<int> labeling;

@@ -304,6 +304,36 @@ def test_knn_builder(engine, synth):
         assert np.array_equal(w[rp[i]:rp[i + 1]], mult[i][js])
 
 
+def test_knn_within_the_reference_radius(engine, synth):
+    """mh_build_neighbors_knn_radius (the host class's default neighbourhood): the k nearest hits, of which only those
+    within the radius survive — checked against a float32 brute force with the kernel's association order."""
+    sc = synth.make_scene(1500, 3, seed=13, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    k, r = 12, 45.0
+    engine.build_neighbors_knn(k, radius=r)
+    rp, col, w = engine.get_sym_graph()
+    pv = np.concatenate([sc.src, sc.dst], axis=1).astype(np.float32)
+    diff = pv[:, None, :] - pv[None, :, :]
+    sq = diff * diff
+    d = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]) + sq[..., 3]
+    np.fill_diagonal(d, np.inf)
+    order = np.lexsort((np.broadcast_to(np.arange(sc.n), d.shape), d), axis=1)[:, :k]
+    hits = np.zeros((sc.n, sc.n), dtype=np.int32)
+    r2 = np.float32(r) * np.float32(r)
+    for i in range(sc.n):
+        js = order[i][d[i, order[i]] <= r2]
+        hits[i, js] += 1
+    assert 0 < hits.sum() < sc.n * k, "the radius must cut some of the k nearest hits for this test to mean anything"
+    mult = hits + hits.T
+    for i in range(0, sc.n, 53):
+        js = col[rp[i]:rp[i + 1]]
+        assert np.array_equal(js, np.flatnonzero(mult[i]))
+        assert np.array_equal(w[rp[i]:rp[i + 1]], mult[i][js])
+    engine.build_neighbors_knn(k)                                  # no cut: every query keeps its k hits
+    rp2, _, w2 = engine.get_sym_graph()
+    assert w2.sum() == 2 * sc.n * k
+
+
 def test_radius_neighbourhood_is_the_exact_reference_rule(mh, engine, synth, oracle):
     """mh_build_neighbors_radius: the hit list radiusMatch(1/locality) asks for (M/MultiH.cpp:252-253),
     exact: float32 squared distance <= r^2, self included; fed through the same setNeighbors
@@ -544,6 +574,33 @@ def test_host_multih_process_loop(mh, engine_lib, synth):
                              C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1), 100, 4, 0, None, 0,
                              labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64, None, None, None, 0, 4)
     assert k == -1
+
+
+def test_degenerate_tail_labels_the_original_points(mh, engine_lib, synth, oracle):
+    """HandleDegenerateCase reached from the END of Process() (at most one cluster left, M/MultiH.cpp:88-94) after the
+    engine's own front half has FILTERED the points: the reference fits and labels the ORIGINAL correspondences
+    (:719-741), so labels.size() is the original count and label i belongs to original point i.  (Round-1 bug: the
+    engine still held the filtered set, the labels were written in filtered order.)  One plane plus gross outliers,
+    no SetEpipolarGeometry; the outliers make the affine-consistency filter drop points."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    sc = synth.make_scene(3000, 1, seed=5, outlier_frac=0.35)
+    n = sc.n
+    dp = C.POINTER(C.c_double)
+    labels = np.full(n, -7, dtype=np.int32)
+    Hout = np.zeros((8, 9))
+    src, dst, aff = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.aff))
+    k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n,
+                             None, None, C.c_double(2.6), C.c_double(2.2), C.c_double(0.005), C.c_double(0.5), 20,
+                             C.c_ulonglong(99), 4000, 8, 0, None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)),
+                             Hout.ctypes.data_as(dp), 8, None, None, None, 0, 4)
+    assert k == 1, "a single plane: the loop ends with one cluster and Process() takes the degenerate tail"
+    assert set(np.unique(labels)) <= {-1, 0}, "every ORIGINAL point carries a label (none left at the -7 fill)"
+    # label 0 <=> forward-transfer inlier of the returned homography, evaluated on the ORIGINAL point of that index
+    with np.errstate(all="ignore"):
+        d2 = oracle.residual_matrix(sc.src, sc.dst, Hout[:1])[0]
+    assert np.array_equal(labels == 0, d2 < THR2)
+    assert (labels == 0).sum() > 0.5 * (sc.gt_label == 0).sum()
 
 
 def test_barrsmith_real_data_end_to_end(mh, engine_lib):

@@ -28,6 +28,7 @@ if world > 1:
     import torch, torch.distributed as dist
 host = C.CDLL(os.path.join(ROOT, "multi-h_amd", "libmultih_host.so"))
 host.mhh_set_device(device)
+if "KNN" in os.environ: host.mhh_set_neighbourhood(int(os.environ["KNN"]), C.c_double(0.0))
 hook = None
 if world > 1:
     backend = os.environ.get("LOOP_BACKEND", "nccl")
