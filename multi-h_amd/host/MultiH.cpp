@@ -206,7 +206,7 @@ bool MultiH::Process()
 
     ClusterMergingAndLabeling();
 
-    if (cluster_homographies.size() > 1) {                                   // :78-86
+    if (cluster_homographies.size() > 1 && run_compatibility_check) {        // :78-86
         const int before = static_cast<int>(cluster_homographies.size());
         auto t0 = std::chrono::system_clock::now();
         HomographyCompatibilityCheck();
@@ -645,8 +645,10 @@ void mhh_set_device(int device) { g_device = device; }
 
 // Neighbourhood of the next mhh_run_process calls: radius > 0 selects the complete radius list, else k > 0 the k nearest
 // hits within 1 / locality; both 0: the class default (k = 16).
-static int g_knn = 0;
+static int g_knn = 0, g_post_filter = 1;
 static double g_radius = 0.0;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_post_filter(int on) { g_post_filter = on; }
 extern "C" __attribute__((visibility("default")))
 void mhh_set_neighbourhood(int knn_k, double radius) { g_knn = knn_k; g_radius = radius; }
 
@@ -673,6 +675,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetIterativeProposal(iter_hypotheses, iter_max_new < 0 ? 4 : iter_max_new);
     mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
     mh.SetDevice(g_device);
+    mh.SetCompatibilityCheck(g_post_filter != 0);
     if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
     else if (g_knn > 0) mh.SetNeighbourK(g_knn);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init

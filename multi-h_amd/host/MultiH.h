@@ -114,6 +114,9 @@ public:
     void SetSharding(int rank, int world, AllGatherFn fn, void* ctx);
     // Number of 8-point hypotheses of the GPU F estimation used when SetEpipolarGeometry was not called.
     void SetFundamentalHypotheses(int n) { fundamental_hypotheses = n; }
+    // The post-filter of Process() (HomographyCompatibilityCheck, M/MultiH.cpp:78-86) can be switched off to look at
+    // what the merge <-> label loop itself produced (parity tests against the oracle of that loop).
+    void SetCompatibilityCheck(bool on) { run_compatibility_check = on; }
     void SetDevice(int d) { device = d; }
     void SetVerbose(bool v) { log_to_console = v; }
     double GetLastLoopSeconds() const { return loop_seconds; }
@@ -153,6 +156,7 @@ protected:
     int iter_hypotheses = 0, iter_max_new = 4;
     int fundamental_hypotheses = 4000;
     int init_mode = INIT_DLT;
+    bool run_compatibility_check = true;
     uint64_t merge_rng_counter = 0;
     double loop_seconds = 0.0;
     std::vector<cv::Mat> initial_homographies;

@@ -1362,4 +1362,409 @@ MHO_API int mho_labeling_step(const double* x1, const double* y1, const double* 
     return energy;
 }
 
+// ---------------------------------------------------------------------------
+// 11. MergingStep and the whole merge <-> label alternation       
+// ---------------------------------------------------------------------------
+// Written from the reference text alone (M/MultiH.cpp:263-311, :352-471, :995-1055,
+// MeanShiftClustering.h:23-157, Homography_Refine3PTCallback.h, Utilities.hpp:750-879) — NOT from the
+// product's host code — so that Process() has an independent checker for labels, model count, iteration
+// number and energy.  OpenCV primitives the reference calls and /root/reference does not contain
+// (cv::eigen, Mat::inv, A.inv(DECOMP_SVD), cv::solve / cv::invert with DECOMP_EIG, cv::norm, gemm) are
+// DEFINED here in the plainest form (sequential sums, closed-form inverse of a similarity, symmetric
+// systems through the Jacobi solver of section 5): "parity unpinned" at those boundaries.  The product's
+// 3-point solver may therefore differ from this one in the last bits of a homography; what must agree is
+// every DECISION taken from them (inlier sets, kept modes, `changed`, labels, energies).
+// Deviations shared with the product: explicit splitmix64 seeds instead of rand();
+// a climb whose window captures no row ends (the reference would loop on a NaN mean).
+
+// Feature vector of a homography: the images of (0,0), (1,0), (0,1).  M/MultiH.cpp:364-390.
+static void homography_feature(const double* h, double* f)
+{
+    const double s1 = h[8];
+    f[0] = h[2] / s1;
+    f[1] = h[5] / s1;
+    const double s2 = h[6] + h[8];
+    f[2] = (h[0] + h[2]) / s2;
+    f[3] = (h[3] + h[5]) / s2;
+    const double s3 = h[7] + h[8];
+    f[4] = (h[1] + h[2]) / s3;
+    f[5] = (h[4] + h[5]) / s3;
+}
+
+// MeanShiftClustering<double>::Cluster, MeanShiftClustering.h:23-157, the reference's own summation order
+// (members added one after the other, :85-96).  Returns the number of modes; modes: up to n x d.
+static int mean_shift_reference_order(const double* data, int n, int d, double band_width, uint64_t seed,
+                                      std::vector<double>& modes, uint64_t* draws_out)
+{
+    const double band_sq = band_width * band_width;                  // :31
+    const double stop = 1e-3 * band_width;                           // :48
+    std::vector<int> init(n), visited(n, 0);
+    for (int i = 0; i < n; ++i) init[i] = i;
+    modes.clear();
+    int k = 0;
+    uint64_t draws = 0;
+    std::vector<double> mean(d), old(d), sum(d);
+    while (!init.empty()) {                                          // :52
+        const uint64_t z = splitmix64(seed + draws++);
+        const double rnd = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+        const int st = init[(int)round(rnd * (double)(init.size() - 1))];      // :54-56
+        for (int j = 0; j < d; ++j) mean[j] = data[(size_t)st * d + j];
+        for (;;) {
+            old = mean;
+            for (int j = 0; j < d; ++j) sum[j] = 0.0;
+            int members = 0;
+            for (int i = 0; i < n; ++i) {
+                double dist = 0.0;                                   // "sqDistToAll": an L1 norm, :78-83 (SURVEY A-8)
+                for (int j = 0; j < d; ++j) {
+                    const double r = old[j] - data[(size_t)i * d + j];
+                    dist = dist + sqrt(r * r);
+                }
+                if (dist < band_sq) {                                // :85
+                    for (int j = 0; j < d; ++j) sum[j] = sum[j] + data[(size_t)i * d + j];
+                    visited[i] = 1;
+                    ++members;
+                }
+            }
+            if (members == 0) { visited[st] = 1; break; }            // deviation: no row captured -> the climb ends
+            for (int j = 0; j < d; ++j) mean[j] = sum[j] / (double)members;    // :96
+            double nrm = 0.0;
+            for (int j = 0; j < d; ++j) { const double r = mean[j] - old[j]; nrm = nrm + r * r; }
+            if (sqrt(nrm) < stop) {                                  // :98
+                int merge_with = -1;
+                for (int c = 0; c < k; ++c) {
+                    double dd = 0.0;
+                    for (int j = 0; j < d; ++j) { const double r = mean[j] - modes[(size_t)c * d + j]; dd = dd + r * r; }
+                    if (sqrt(dd) < band_width / 2) { merge_with = c; break; }  // :101-109
+                }
+                if (merge_with > -1) {
+                    for (int j = 0; j < d; ++j)
+                        modes[(size_t)merge_with * d + j] = 0.5 * (modes[(size_t)merge_with * d + j] + mean[j]);   // :113
+                } else {
+                    modes.insert(modes.end(), mean.begin(), mean.end());
+                    ++k;
+                }
+                break;
+            }
+        }
+        init.clear();                                                // :125-130
+        for (int i = 0; i < n; ++i) if (!visited[i]) init.push_back(i);
+    }
+    if (draws_out) *draws_out = draws;
+    return k;
+}
+
+static void mat3_mul(const double* a, const double* b, double* c)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            c[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+
+// NormalizePoints<double> for an N x 2 CV_64F matrix, Homography_Refine3PTCallback.h:164-199.
+static void normalize_points(const double* pts, int n, std::vector<double>& out, double T[9])
+{
+    double mx = 0.0, my = 0.0;
+    for (int i = 0; i < n; ++i) { mx = mx + pts[2 * i]; my = my + pts[2 * i + 1]; }
+    const double inv_n = 1 / (double)n;
+    mx = inv_n * mx; my = inv_n * my;                                // :171
+    out.resize(2 * (size_t)n);
+    double avg = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double x = pts[2 * i] - mx, y = pts[2 * i + 1] - my;
+        out[2 * i] = x; out[2 * i + 1] = y;
+        avg = avg + sqrt(x * x + y * y);                             // :178
+    }
+    avg = avg / n;
+    const double ratio = sqrt(2.0) / avg;                            // :182
+    for (int i = 0; i < 2 * n; ++i) out[i] = out[i] * ratio;
+    T[0] = ratio; T[1] = 0; T[2] = -mx * ratio;                      // :191-196
+    T[3] = 0; T[4] = ratio; T[5] = -my * ratio;
+    T[6] = 0; T[7] = 0; T[8] = 1;
+}
+
+// inverse of T = [r 0 tx; 0 r ty; 0 0 1] (stands in for cv::Mat::inv, LU)
+static void similarity_inverse(const double* T, double* Ti)
+{
+    const double ir = 1.0 / T[0];
+    Ti[0] = ir; Ti[1] = 0; Ti[2] = -T[2] * ir;
+    Ti[3] = 0; Ti[4] = ir; Ti[5] = -T[5] * ir;
+    Ti[6] = 0; Ti[7] = 0; Ti[8] = 1;
+}
+
+// x = pinv(A) b for a symmetric n x n A through its eigen-decomposition, eigenvalues below the cut count as zero
+// (what cv::solve / cv::invert do with DECOMP_EIG).  Ainv (nullable) receives the pseudo-inverse.
+static void sym_solve_eig(int n, const double* A, const double* b, double* x, double* Ainv)
+{
+    std::vector<double> a(A, A + n * n), v(n * n), w(n);
+    jacobi_sym(n, a.data(), v.data(), w.data());
+    double cut = 0.0;
+    for (int k = 0; k < n; ++k) cut = cut + fabs(w[k]);
+    cut = cut * (2.0 * 2.220446049250313e-16);
+    if (x) for (int i = 0; i < n; ++i) x[i] = 0.0;
+    if (Ainv) for (int i = 0; i < n * n; ++i) Ainv[i] = 0.0;
+    for (int k = 0; k < n; ++k) {
+        if (fabs(w[k]) <= cut) continue;
+        if (x) {
+            double proj = 0.0;
+            for (int i = 0; i < n; ++i) proj = proj + v[i * n + k] * b[i];
+            proj = proj / w[k];
+            for (int i = 0; i < n; ++i) x[i] = x[i] + proj * v[i * n + k];
+        }
+        if (Ainv)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) Ainv[i * n + j] = Ainv[i * n + j] + v[i * n + k] * v[j * n + k] / w[k];
+    }
+}
+
+struct Refine3PT {                      // Homography_Refine3PTCallback<double>, :62-145
+    const double* src; const double* dst; int count;
+    const double* F; double ex, ey;
+    void compute(const double* h, double* err, double* J) const
+    {
+        for (int i = 0; i < count; ++i) {
+            const double x1 = src[2 * i], y1 = src[2 * i + 1], x2 = dst[2 * i], y2 = dst[2 * i + 1];
+            double s = h[0] * x1 + h[1] * y1 + h[2];
+            s = fabs(s) > 2.220446049250313e-16 ? 1. / s : 0;        // :112
+            const double h21 = ey * h[0] - F[0], h22 = ey * h[1] - F[1], h23 = ey * h[2] - F[2];
+            const double h11 = ex * h[0] + F[3], h12 = ex * h[1] + F[4], h13 = ex * h[2] + F[5];
+            const double xi = (h11 * x1 + h12 * y1 + h13) * s;
+            const double yi = (h21 * x1 + h22 * y1 + h23) * s;
+            err[2 * i] = x2 - xi;
+            err[2 * i + 1] = y2 - yi;
+            if (J) {
+                double* j = J + 6 * i;
+                j[0] = ex * s * x1; j[1] = ex * s * y1; j[2] = ex * s;
+                j[3] = ey * s * x1; j[4] = ey * s * y1; j[5] = ey * s;
+            }
+        }
+    }
+};
+
+// cv::LMSolverImpl::run (M/Utilities.hpp:762-869) for 3 parameters, maxIters = 1000, epsx = epsf = FLT_EPSILON.
+static void lm_refine3(const Refine3PT& cb, double x[3])
+{
+    const int m = 2 * cb.count;
+    const double eps = 2.220446049250313e-16, feps = 1.1920928955078125e-07;
+    std::vector<double> r(m), rd(m), J(3 * (size_t)m);
+    double A[9], v[3], D[3], xd[3], d[3], Ap[9];
+    auto normal_eq = [&]() {                                          // mulTransposed(J, A, true); gemm(J, r, ..., GEMM_1_T)
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) {
+                double s = 0.0;
+                for (int i = 0; i < m; ++i) s = s + J[3 * i + a] * J[3 * i + b];
+                A[3 * a + b] = s;
+            }
+            double s = 0.0;
+            for (int i = 0; i < m; ++i) s = s + J[3 * i + a] * r[i];
+            v[a] = s;
+        }
+    };
+    auto sumsq = [&](const std::vector<double>& q) { double s = 0.0; for (int i = 0; i < m; ++i) s = s + q[i] * q[i]; return s; };
+    cb.compute(x, r.data(), J.data());
+    double S = sumsq(r);
+    normal_eq();
+    for (int i = 0; i < 3; ++i) D[i] = A[4 * i];                     // :783, taken once
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        for (int i = 0; i < 9; ++i) Ap[i] = A[i];
+        for (int i = 0; i < 3; ++i) Ap[4 * i] += lambda * D[i];
+        sym_solve_eig(3, Ap, v, d, nullptr);                         // solve(Ap, v, d, DECOMP_EIG)
+        for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
+        cb.compute(xd, rd.data(), nullptr);
+        const double Sd = sumsq(rd);
+        double dS = 0.0, t = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double Ad = (A[3 * i] * d[0] + A[3 * i + 1] * d[1]) + A[3 * i + 2] * d[2];
+            dS = dS + d[i] * (-Ad + 2 * v[i]);                       // gemm(A, d, -1, v, 2, temp_d); d.dot(temp_d)
+            t = t + d[i] * v[i];
+        }
+        const double R = (S - Sd) / (fabs(dS) > eps ? dS : 1);
+        if (R > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (R < Rlo) {
+            double nu = (Sd - S) / (fabs(t) > eps ? t : 1) + 2;
+            nu = std::min(std::max(nu, 2.), 10.);
+            if (lambda == 0) {
+                double Ai[9];
+                sym_solve_eig(3, A, nullptr, nullptr, Ai);           // invert(A, Ap, DECOMP_EIG)
+                double maxval = eps;
+                for (int i = 0; i < 3; ++i) maxval = std::max(maxval, fabs(Ai[4 * i]));
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            for (int i = 0; i < 3; ++i) x[i] = xd[i];
+            cb.compute(x, r.data(), J.data());
+            normal_eq();
+        }
+        ++iter;
+        double dinf = 0.0, rinf = 0.0;
+        for (int i = 0; i < 3; ++i) dinf = std::max(dinf, fabs(d[i]));
+        for (int i = 0; i < m; ++i) rinf = std::max(rinf, fabs(r[i]));
+        if (!(iter < 1000 && dinf >= feps && rinf >= feps)) break;
+    }
+}
+
+// GetHomography3PT (M/MultiH.cpp:995-1055) with RefineHomography3PT (Homography_Refine3PTCallback.h:7-58).
+static bool homography_3pt(const double* p1, const double* p2, int n, const double* Fund, double* H, bool refine)
+{
+    std::vector<double> n1, n2;
+    double T1[9], T2[9], T1i[9], T2i[9];
+    normalize_points(p1, n, n1, T1);
+    normalize_points(p2, n, n2, T2);
+    similarity_inverse(T1, T1i);
+    similarity_inverse(T2, T2i);
+    double T2it[9], tmp[9], Fn[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2it[3 * i + j] = T2i[3 * j + i];
+    mat3_mul(T2it, Fund, tmp);
+    mat3_mul(tmp, T1i, Fn);                                          // :1010
+    double FFt[9], V[9], W[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            FFt[3 * i + j] = (Fn[3 * i] * Fn[3 * j] + Fn[3 * i + 1] * Fn[3 * j + 1]) + Fn[3 * i + 2] * Fn[3 * j + 2];
+    jacobi_sym(3, FFt, V, W);
+    int jm = 0;
+    for (int j = 1; j < 3; ++j) if (W[j] < W[jm]) jm = j;            // last row of cv::eigen's descending order
+    const double ex = V[0 * 3 + jm] / V[2 * 3 + jm], ey = V[1 * 3 + jm] / V[2 * 3 + jm];   // :1018
+    std::vector<double> A(6 * (size_t)n), b(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) {                                    // :1025-1037
+        const double x1 = n1[2 * i], y1 = n1[2 * i + 1], x2 = n2[2 * i], y2 = n2[2 * i + 1];
+        double* a = &A[6 * (size_t)i];
+        a[0] = ex * x1 - x2 * x1; a[1] = ex * y1 - x2 * y1; a[2] = ex - x2;
+        a[3] = ey * x1 - y2 * x1; a[4] = ey * y1 - y2 * y1; a[5] = ey - y2;
+        b[2 * i] = -(x1 * Fn[3] + y1 * Fn[4] + Fn[5]);
+        b[2 * i + 1] = (x1 * Fn[0] + y1 * Fn[1] + Fn[2]);
+    }
+    // res = A.inv(DECOMP_SVD) * b: the least-squares solution, here through the normal equations
+    double AtA[9], Atb[3], h3[3];
+    for (int a = 0; a < 3; ++a) {
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int i = 0; i < 2 * n; ++i) s = s + A[3 * (size_t)i + a] * A[3 * (size_t)i + c];
+            AtA[3 * a + c] = s;
+        }
+        double s = 0.0;
+        for (int i = 0; i < 2 * n; ++i) s = s + A[3 * (size_t)i + a] * b[i];
+        Atb[a] = s;
+    }
+    sym_solve_eig(3, AtA, Atb, h3, nullptr);
+    if (refine) {
+        Refine3PT cb{ n1.data(), n2.data(), n, Fn, ex, ey };
+        lm_refine3(cb, h3);
+    }
+    double Hn[9];
+    Hn[6] = h3[0]; Hn[7] = h3[1]; Hn[8] = h3[2];
+    Hn[3] = ey * h3[0] - Fn[0]; Hn[4] = ey * h3[1] - Fn[1]; Hn[5] = ey * h3[2] - Fn[2];
+    Hn[0] = ex * h3[0] + Fn[3]; Hn[1] = ex * h3[1] + Fn[4]; Hn[2] = ex * h3[2] + Fn[5];
+    mat3_mul(T2i, Hn, tmp);
+    mat3_mul(tmp, T1, H);                                            // :1054
+    for (int i = 0; i < 9; ++i) if (!std::isfinite(H[i])) return false;
+    return true;
+}
+
+MHO_API int mho_homography_3pt(const double* p1, const double* p2, int n, const double* F, double* H, int refine)
+{
+    return homography_3pt(p1, p2, n, F, H, refine != 0) ? 1 : 0;
+}
+
+// MergingStep, M/MultiH.cpp:352-471.  H: Nh*9 in; kept: capacity >= Nh*9 (the modes that survive).  Returns the number
+// of kept candidates; *changed = (that number != Nh).  The caller replaces its model set only when changed (:468-470).
+MHO_API int mho_merging_step(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                             const double* H, int Nh, const double* F, double thr_h, double straightness,
+                             uint64_t seed, double* kept /* up to Nh*9 */, int* changed, uint64_t* draws)
+{
+    std::vector<double> feat(6 * (size_t)Nh), modes;
+    for (int i = 0; i < Nh; ++i) homography_feature(H + 9 * (size_t)i, &feat[6 * (size_t)i]);
+    const int k = mean_shift_reference_order(feat.data(), Nh, 6, thr_h, seed, modes, draws);     // :394-397
+    const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                                // :408
+    int nk = 0;
+    for (int i = 0; i < k; ++i) {
+        double Hc[9];
+        if (!homography_3pt(pts1, &modes[6 * (size_t)i], 3, F, Hc, true)) continue;             // :427
+        double mom[6], mineig = 0.0;
+        mho_inlier_moments(x1, y1, x2, y2, N, Hc, 1, thr_h * thr_h, mom, &mineig);              // :430-461
+        if (mineig < straightness || (int)mom[0] < 3) continue;                                 // :462
+        for (int q = 0; q < 9; ++q) kept[9 * (size_t)nk + q] = Hc[q];
+        ++nk;
+    }
+    *changed = nk != Nh;                                                                        // :468
+    return nk;
+}
+
+typedef int (*mho_expand_hook)(int N, int L, const int* cost, const int* hit_rowptr, const int* hit_col, int potts,
+                               const int* init_labels, int* labels_out);
+
+// ClusterMergingAndLabeling's loop, M/MultiH.cpp:263-311, started from `Nh` initial models (what
+// EstablishStablePointSets hands over).  H: capacity max_models*9 in/out; labeling: N out.  expand (nullable) replaces
+// the oracle's own alpha-expansion, e.g. by the reference's GCoptimization compiled unmodified (oracle/_ref).
+// seed_of_step(c) = seed ^ 0x4d53 ^ (c << 20) for the c-th MergingStep, the product's convention.
+// Returns the number of models; *iterations = final_iteration_number (:311), *energy = final_energy (0 unless the
+// loop converged, :297).
+MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1, const double* x2, const double* y2,
+                                             const double* aff, int N, double* H, int Nh, int max_models,
+                                             const double* F, const double* e2, double lambda, double thr_h,
+                                             double straightness, const int* hit_rowptr, const int* hit_col,
+                                             uint64_t seed, mho_expand_hook expand, int* labeling, int* iterations,
+                                             double* energy_out)
+{
+    const double thr2 = thr_h * thr_h;
+    std::vector<double> models(H, H + 9 * (size_t)Nh), kept;
+    for (int i = 0; i < N; ++i) labeling[i] = -1;                    // :263
+    double last_energy = 2147483647.0, final_energy = 0.0;           // INT_MAX, :264
+    int not_changed = 0, iteration = 0;
+    uint64_t step = 0;
+    while (iteration++ < 500) {                                      // :267
+        int nh = (int)(models.size() / 9);
+        int changed = 0;
+        if (nh > 0) {
+            kept.assign(models.size(), 0.0);
+            const int nk = mho_merging_step(x1, y1, x2, y2, N, models.data(), nh, F, thr_h, straightness,
+                                            seed ^ 0x4d53u ^ (step << 20), kept.data(), &changed, nullptr);
+            ++step;
+            if (changed) models.assign(kept.begin(), kept.begin() + 9 * (size_t)nk);          // :469-470
+        }
+        if (changed) not_changed = 0; else ++not_changed;           // :275-278
+        nh = (int)(models.size() / 9);
+        if (nh == 1) {                                               // :280-285
+            for (int i = 0; i < N; ++i)
+                if (fwd_d2(models.data(), x1[i], y1[i], x2[i], y2[i]) < thr2) labeling[i] = 0;   // :743-768
+            break;
+        } else if (nh == 0)
+            break;
+        // LabelingStep, :513-602
+        const int L = nh + 1;
+        std::vector<int> cost((size_t)N * L), lab(N, 0);
+        mho_data_cost(x1, y1, x2, y2, N, models.data(), nh, lambda, thr2, cost.data());
+        if (!changed) for (int i = 0; i < N; ++i) lab[i] = labeling[i] + 1;                  // :525-529
+        int energy_i;
+        if (expand) {
+            std::vector<int> out(N);
+            energy_i = expand(N, L, cost.data(), hit_rowptr, hit_col, mho_potts(lambda), changed ? nullptr : lab.data(), out.data());
+            lab = out;
+        } else {
+            energy_i = mho_expand(N, L, cost.data(), hit_rowptr, hit_col, mho_potts(lambda), lab.data(), 1000, nullptr, nullptr);
+        }
+        for (int i = 0; i < N; ++i) labeling[i] = lab[i] - 1;                                 // :547-568
+        mho_haf_reestimate(x1, y1, x2, y2, aff, N, labeling, nh, F, e2, models.data(), nullptr);
+        const double energy = (double)energy_i;
+        if ((!changed && fabs(last_energy - energy) < 1e-5) || not_changed > 10) {            // :295
+            final_energy = energy;
+            break;
+        }
+        last_energy = energy;
+    }
+    const int nh = (int)(models.size() / 9);
+    for (int i = 0; i < nh && i < max_models; ++i)
+        for (int q = 0; q < 9; ++q) H[9 * (size_t)i + q] = models[9 * (size_t)i + q];
+    if (iterations) *iterations = iteration - 1;                     // :311
+    if (energy_out) *energy_out = final_energy;
+    return nh;
+}
+
 MHO_API int mho_abi_version(void) { return 1; }

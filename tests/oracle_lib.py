@@ -292,6 +292,50 @@ def labeling_step(src, dst, aff, H, lam, thr2, rowptr, col, warm, F, e2, labelin
     return lab, H, int(e), int(cyc.value)
 
 
+def homography_3pt(p1, p2, F, refine=True):
+    p1, p2, F = f64(p1).reshape(-1, 2), f64(p2).reshape(-1, 2), f64(F).reshape(9)
+    H = np.zeros(9)
+    ok = lib().mho_homography_3pt(_d(p1), _d(p2), p1.shape[0], _d(F), _d(H), int(bool(refine)))
+    return H, bool(ok)
+
+
+def merging_step(src, dst, H, F, thr_h, seed, straightness=0.005):
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    kept = np.zeros_like(H)
+    changed, draws = C.c_int(0), C.c_ulonglong(0)
+    k = lib().mho_merging_step(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], _d(f64(F)), C.c_double(thr_h),
+                               C.c_double(straightness), C.c_ulonglong(seed), _d(kept), C.byref(changed), C.byref(draws))
+    return kept[:k].copy(), bool(changed.value), int(draws.value)
+
+
+_EXPAND_HOOK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                           C.POINTER(C.c_int), C.POINTER(C.c_int))
+
+
+def cluster_merging_and_labeling(src, dst, aff, H0, F, e2, lam, thr_h, rowptr, col, seed, use_reference_gco=True,
+                                 straightness=0.005, max_models=256):
+    """The oracle's ClusterMergingAndLabeling (M/MultiH.cpp:263-311) from initial models H0.  With
+    use_reference_gco and oracle/_ref built, every alpha-expansion inside it is the REFERENCE's own GCoptimization."""
+    x1, y1, x2, y2 = soa(src, dst)
+    aff, F, e2 = f64(aff), f64(F), f64(e2)
+    H0 = f64(H0).reshape(-1, 9)
+    H = np.zeros((max(max_models, H0.shape[0]), 9))
+    H[:H0.shape[0]] = H0
+    rowptr, col = i32(rowptr), i32(col)
+    lab = np.empty(x1.size, dtype=np.int32)
+    it, en = C.c_int(0), C.c_double(0)
+    hook = None
+    if use_reference_gco and ref() is not None:
+        hook = C.cast(ref().ref_gco_expand_table, _EXPAND_HOOK)
+    fn = lib().mho_cluster_merging_and_labeling
+    fn.restype = C.c_int
+    k = fn(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(H), H0.shape[0], H.shape[0], _d(F), _d(e2),
+           C.c_double(lam), C.c_double(thr_h), C.c_double(straightness), _i(rowptr), _i(col), C.c_ulonglong(seed),
+           hook if hook is not None else _EXPAND_HOOK(0), _i(lab), C.byref(it), C.byref(en))
+    return lab, H[:k].copy(), int(it.value), float(en.value), hook is not None
+
+
 # ---- reference GCO (oracle/_ref) -----------------------------------------
 
 def ref_expand_table(cost, rowptr, col, potts_v, init_labels=None):

@@ -256,3 +256,23 @@ def test_compatibility_medians_equal_the_literal_trial_loop(host, synth, sizes):
         m = labels == c
         want, counter = _literal_cluster_median(host, src[m], dst[m], F, seed, counter)
         assert med[c] == want, f"cluster {c} (n={m.sum()}): {med[c]!r} != {want!r}"
+
+
+def test_host_3pt_solver_agrees_with_the_oracles_independent_restatement(host, synth, oracle):
+    """Two restatements of GetHomography3PT + RefineHomography3PT written separately from the reference text (the
+    product's host/merge_step.cpp and oracle/mh_oracle.cpp section 11) agree to 1e-9 on exact and on noisy inputs,
+    with and without the LM refinement.  (Bitwise agreement is not expected: the OpenCV primitives underneath are
+    not under /root/reference and each side defines them for itself.)"""
+    sc = synth.make_scene(300, 3, seed=21, noise=0.0, outlier_frac=0.0, with_neighbours=False)
+    rng = np.random.default_rng(1)
+    canon = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    for k in range(3):
+        for noise in (0.0, 0.3):
+            for pts1 in (canon, sc.src[sc.gt_label == k][:12]):
+                pts2 = synth.apply_h(sc.H_true[k], pts1) + rng.normal(0, noise, size=pts1.shape)
+                for fn, refine in (("lin", False), ("lm", True)):
+                    H_host, _ = _h3pt(host, fn, pts1, pts2, sc.F)
+                    H_or, ok = oracle.homography_3pt(pts1, pts2, sc.F, refine=refine)
+                    assert ok
+                    a, b = H_host / H_host[8], H_or / H_or[8]
+                    assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(b))), (k, noise, fn)
