@@ -174,6 +174,24 @@ MH_API int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_val
  * model set is left untouched.  Used by the sharded propose stage, where the winning hypothesis
  * of a round may live on another rank. */
 MH_API int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int label_value, int* labels /* in/out n */);
+/* Greedy model selection over the resident hypothesis batch, on the device (csrc/select.hip): up to `max_models`
+ * rounds of {score the candidates over the points still in the support mask, take the best — highest count, lowest
+ * hypothesis counter on ties —, stop if it has fewer than `need` inliers, take its inliers out of the mask}.  This is
+ * the sequential-RANSAC scheme of the dead M/MultipleHomographies.h:146-175 behind MultiH::ProposeModels.
+ * point_mask (n bytes, nullable = all ones): in = points that may support a model, out = points no selected model
+ * explains.  H_out: max_models x 9; counters_out / counts_out (nullable): position of each selected hypothesis in the
+ * batch and its inlier count when selected.  Per round the host reads three control words from mapped memory; no
+ * host<->device copy is issued inside the loop (mh_get_copy_stats).
+ * Sharded batch (one process per GPU, rank r of `world` holds its shard of the batch as the resident model set):
+ * `exchange` all-gathers DEVICE buffers in rank order (RCCL on a real node) — per round the int32 score vectors of
+ * `shard_longest` entries per rank (north_star's exchange) and the 72-byte H every rank offers; counters_out then
+ * index the gathered vector (rank * shard_longest + position).  world = 1: exchange = NULL, shard_longest ignored. */
+typedef int (*mh_allgather_dev_fn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank);
+MH_API int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsigned char* point_mask,
+                            double* H_out, long long* counters_out, int* counts_out, int* selected_out,
+                            int rank, int world, int shard_longest, mh_allgather_dev_fn exchange, void* ctx);
+/* Number of explicit host<->device copies mh_select_greedy has issued since the last reset. */
+MH_API int mh_get_copy_stats(mh_engine* e, long long* h2d, long long* d2h, int reset);
 /* Per-model inlier moments {n, Sx, Sy, Sxx, Sxy, Syy} and smallest eigenvalue of the 3x3
  * scatter — the collinearity test of MergingStep (M/MultiH.cpp:446-463). */
 MH_API int mh_inlier_moments(mh_engine* e, double thr2, double* moments /* m x 6 */, double* min_eig /* m */);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
-    "mh_residual_matrix", "mh_get_residual_rows", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_residual_matrix", "mh_get_residual_rows", "mh_select_greedy", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_get_expand_trace", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
@@ -277,6 +277,25 @@ class Engine:
         rows = np.empty((count, self.n), dtype=np.float64)
         self._check(self.lib.mh_get_residual_rows(self._h, int(first), int(count), _p(rows, C.c_double)))
         return rows
+
+    def select_greedy(self, thr2: float, need: int, max_models: int, mask=None):
+        """Greedy selection over the resident batch on the device (mh_select_greedy, one rank).
+        Returns (H [k,9], counters [k], counts [k], mask_out or None)."""
+        H = np.zeros((int(max_models), 9))
+        counters = np.zeros(int(max_models), dtype=np.int64)
+        counts = np.zeros(int(max_models), dtype=np.int32)
+        k = C.c_int(0)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).copy()
+        self._check(self.lib.mh_select_greedy(self._h, C.c_double(thr2), int(need), int(max_models),
+                                              None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                              _p(H, C.c_double), counters.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                              _p(counts, C.c_int), C.byref(k), 0, 1, 0, None, None))
+        return H[:k.value].copy(), counters[:k.value].copy(), counts[:k.value].copy(), m
+
+    def copy_stats(self, reset=False):
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._check(self.lib.mh_get_copy_stats(self._h, C.byref(a), C.byref(b), int(bool(reset))))
+        return int(a.value), int(b.value)
 
     def inliers_of_model(self, idx: int, thr2: float, label_value: int, labels):
         labels = _i32(labels).copy()

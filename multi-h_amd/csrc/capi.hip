@@ -77,6 +77,14 @@ struct mh_engine {
     long long ldr = 0;
     DevBuf<unsigned char> mask;
     DevBuf<double> moments, min_eig;
+    // greedy selection (select.hip): two candidate lists, control words, exchange buffers
+    DevBuf<int> sel_orig[2], sel_counts, sel_rec, sel_scores, sel_gathered;
+    DevBuf<double> sel_cand_H[2], sel_out_H, sel_my_H, sel_all_H;
+    DevBuf<long long> sel_counter;
+    DevBuf<unsigned long long> sel_keys;
+    int* h_sel = nullptr;                      // mapped pinned mirror of the control words
+    int* h_sel_dev = nullptr;
+    long long copies_h2d = 0, copies_d2h = 0;  // explicit host<->device copies issued by mh_select_greedy (mh_get_copy_stats)
 
     // epipolar front half
     int fm = 0;
@@ -472,6 +480,10 @@ void mh_destroy(mh_engine* e)
     if (e->h_ms) (void)hipHostFree(e->h_ms);
     if (e->h_ms_list) (void)hipHostFree(e->h_ms_list);
     if (e->h_acc) (void)hipHostFree(e->h_acc);
+    if (e->h_sel) (void)hipHostFree(e->h_sel);
+    for (int b = 0; b < 2; ++b) { e->sel_orig[b].release(); e->sel_cand_H[b].release(); }
+    e->sel_counts.release(); e->sel_rec.release(); e->sel_scores.release(); e->sel_gathered.release(); e->sel_out_H.release();
+    e->sel_my_H.release(); e->sel_all_H.release(); e->sel_counter.release(); e->sel_keys.release();
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1000,8 +1012,9 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int 
 int mh_set_models(mh_engine* e, const double* H, int m)
 {
     return guarded([&]() -> int {
-    if (!e || !H || m <= 0) return fail(MH_ERR_INVALID, "null argument or m <= 0");
+    if (!e || m < 0 || (m > 0 && !H)) return fail(MH_ERR_INVALID, "null argument or m < 0");
     HIPCHK(hipSetDevice(e->device));
+    if (m == 0) { e->m = 0; e->have_samples = false; e->cost_L = 0; return MH_OK; }     // an empty model set
     HIPCHK(e->H.reserve((size_t)m * 9));
     HIPCHK(e->counts.reserve(m));
     HIPCHK(hipMemcpyAsync(e->H.p, H, sizeof(double) * 9 * m, hipMemcpyHostToDevice, e->stream));
@@ -1117,6 +1130,114 @@ int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
                             sizeof(double) * e->ldr, sizeof(double) * e->n, count,
                             hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+    });
+}
+
+int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsigned char* point_mask,
+                     double* H_out, long long* counters_out, int* counts_out, int* selected_out,
+                     int rank, int world, int shard_longest, mh_allgather_dev_fn exchange, void* ctx)
+{
+    return guarded([&]() -> int {
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!H_out || !selected_out || max_models <= 0 || need < 1) return fail(MH_ERR_INVALID, "bad argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(MH_ERR_INVALID, "bad rank / world");
+    if (world > 1 && (!exchange || shard_longest <= 0 || e->m > shard_longest))
+        return fail(MH_ERR_INVALID, "a sharded selection needs the exchange callback and the longest shard's size");
+    const int n = e->n, M = e->m;                     // M may be 0 on a rank without hypotheses (world > shard count)
+    if (world == 1 && M <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
+    const int longest = world > 1 ? shard_longest : 0;
+    const size_t cap = (size_t)std::max(M, 1);
+    for (int b = 0; b < 2; ++b) { HIPCHK(e->sel_orig[b].reserve(cap)); HIPCHK(e->sel_cand_H[b].reserve(cap * 9)); }
+    HIPCHK(e->sel_counts.reserve(cap));
+    HIPCHK(e->sel_rec.reserve(8));
+    HIPCHK(e->sel_keys.reserve(2));
+    HIPCHK(e->sel_out_H.reserve((size_t)max_models * 9));
+    HIPCHK(e->sel_counter.reserve(max_models));
+    HIPCHK(e->sel_my_H.reserve(16));
+    HIPCHK(e->mask.reserve((size_t)n + 2));
+    if (world > 1) {
+        HIPCHK(e->sel_scores.reserve(longest));
+        HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
+        HIPCHK(e->sel_all_H.reserve((size_t)world * 9));
+    }
+    if (!e->h_sel) {
+        HIPCHK(hipHostMalloc((void**)&e->h_sel, sizeof(int) * 8, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_sel_dev, e->h_sel, 0));
+    }
+    hipStream_t s = e->stream;
+    if (point_mask) { HIPCHK(hipMemcpyAsync(e->mask.p, point_mask, n, hipMemcpyHostToDevice, s)); ++e->copies_h2d; }
+    else HIPCHK(hipMemsetAsync(e->mask.p, 1, n, s));
+    HIPCHK(hipMemsetAsync(e->sel_rec.p, 0, sizeof(int) * 8, s));
+    HIPCHK(hipMemsetAsync(e->sel_keys.p, 0, sizeof(unsigned long long) * 2, s));
+    HIPCHK(hipMemsetAsync(e->sel_my_H.p, 0, sizeof(double) * 16, s));
+    if (world > 1) HIPCHK(hipMemsetAsync(e->sel_scores.p, 0xff, sizeof(int) * longest, s));       // -1: padding / pruned
+    unsigned long long* key_local = e->sel_keys.p;
+    unsigned long long* key_global = world > 1 ? e->sel_keys.p + 1 : e->sel_keys.p;
+
+    int Mc = M, cur = 0, selected = 0;
+    bool first = true;
+    std::vector<int> counts_host;
+    for (int round = 0; round < max_models; ++round) {
+        const double* Hs = first ? e->H.p : e->sel_cand_H[cur].p;
+        const int* orig = first ? nullptr : e->sel_orig[cur].p;
+        if (Mc > 0) {
+            ScopedTimer t(e, MH_K_SCORE);
+            HIPCHK(launch_score(e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p, e->tune_score_variant, s));
+        }
+        HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, key_local, world > 1 ? e->sel_scores.p : nullptr, s));
+        if (world > 1) {
+            // north_star's exchange: the per-model int32 scores of every rank, device buffers on both sides
+            HIPCHK(hipStreamSynchronize(s));
+            if (exchange(ctx, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest) != 0)
+                return fail(MH_ERR_INVALID, "score all-gather failed");
+            HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world * longest, key_global, s));
+        }
+        HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, key_local, key_global,
+                                  world > 1 ? (unsigned int)rank * (unsigned int)longest : 0u, e->sel_orig[cur ^ 1].p,
+                                  e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, e->sel_my_H.p, world > 1 ? e->sel_scores.p : nullptr, s));
+        const double* offers = e->sel_my_H.p;
+        if (world > 1) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (exchange(ctx, e->sel_my_H.p, e->sel_all_H.p, sizeof(double) * 9) != 0)
+                return fail(MH_ERR_INVALID, "model all-gather failed");
+            offers = e->sel_all_H.p;
+        }
+        HIPCHK(launch_sel_claim(e->pts(), offers, longest, key_global, thr2, need, e->mask.p, e->sel_rec.p, e->sel_out_H.p,
+                                e->sel_counter.p, max_models, s));
+        HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, need, e->h_sel_dev, s));
+        HIPCHK(hipStreamSynchronize(s));                 // three control words through mapped memory: no copy
+        const int best = e->h_sel[0];
+        if (best < need) break;
+        if (counts_out) counts_out[selected] = best;
+        ++selected;
+        Mc = e->h_sel[2];
+        cur ^= 1;
+        first = false;
+    }
+    *selected_out = selected;
+    if (selected > 0) {
+        HIPCHK(hipMemcpyAsync(H_out, e->sel_out_H.p, sizeof(double) * 9 * (size_t)selected, hipMemcpyDeviceToHost, s));
+        ++e->copies_d2h;
+        if (counters_out) {
+            HIPCHK(hipMemcpyAsync(counters_out, e->sel_counter.p, sizeof(long long) * (size_t)selected, hipMemcpyDeviceToHost, s));
+            ++e->copies_d2h;
+        }
+    }
+    if (point_mask) { HIPCHK(hipMemcpyAsync(point_mask, e->mask.p, n, hipMemcpyDeviceToHost, s)); ++e->copies_d2h; }
+    HIPCHK(hipStreamSynchronize(s));
+    return MH_OK;
+    });
+}
+
+int mh_get_copy_stats(mh_engine* e, long long* h2d, long long* d2h, int reset)
+{
+    return guarded([&]() -> int {
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (h2d) *h2d = e->copies_h2d;
+    if (d2h) *d2h = e->copies_d2h;
+    if (reset) { e->copies_h2d = 0; e->copies_d2h = 0; }
     return MH_OK;
     });
 }

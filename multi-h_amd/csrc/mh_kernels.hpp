@@ -159,6 +159,17 @@ hipError_t launch_init_labeling(const int* cost, int L, int n, const int* init_o
 hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long long* acc,
                                 hipStream_t s);
 
+// --- select.hip ------------------------------------------------------------
+hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned long long* key, int* scores_full, hipStream_t s);
+hipError_t launch_sel_argmax_gathered(const int* gathered, int total, unsigned long long* key, hipStream_t s);
+hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need,
+                              const unsigned long long* key_local, const unsigned long long* key_global, unsigned int my_pos0,
+                              int* next_orig, double* next_H, int* rec, double* my_best_H, int* scores_full, hipStream_t s);
+hipError_t launch_sel_claim(const Points& p, const double* all_H, int longest, const unsigned long long* key_global, double thr2,
+                            int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
+                            hipStream_t s);
+hipError_t launch_sel_publish(int* rec, unsigned long long* keys, int need, int* h_rec_dev, hipStream_t s);
+
 // --- knn.hip ----------------------------------------------------------------
 hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, hipStream_t s);
 hipError_t launch_radius_count(const Points& p, float r2, int* counts /* n */, hipStream_t s);

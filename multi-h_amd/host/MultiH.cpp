@@ -355,33 +355,31 @@ bool MultiH::ProposeInitialModels()
 }
 
 // `mask`: 1 = point still unexplained (in/out).  Appends the selected models to cluster_homographies.
+// One hypothesis batch -> mh_propose_dlt4 (this rank's shard of it) -> mh_select_greedy: scoring, arg-max, claiming
+// the winner's inliers and pruning the candidates all stay on the device; per round the host reads three control
+// words.  Sharded (SetSharding): rank r owns counters [first + off_r, first + off_r + m_r); the ranks all-gather
+// their int32 score vectors and the H each offers through the caller's transport on DEVICE buffers, and the selection
+// order is the single-GPU one (highest score, lowest counter on ties), so world sizes 1..G give identical model lists.
 bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models, std::vector<unsigned char>& mask)
 {
-    const int N = static_cast<int>(src_points.size());
     const int need = std::max(minimum_inlier_number, 8);
     if (M <= 0 || max_models <= 0) return true;
-    if (shard_world > 1) return ProposeModelsSharded(seed, first, M, max_models, mask);
-    if (!Check(mh_propose_dlt4(engine, seed, first, M), "mh_propose_dlt4")) return false;
-    std::vector<double> H(9 * (size_t)M);
-    if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
-    std::vector<int> counts(M);
-    std::vector<int> lab(N);
-    bool any_masked = false;
-    for (unsigned char m : mask) any_masked = any_masked || (m == 0);
-    for (int round = 0; round < max_models; ++round) {
-        if (!Check(mh_score(engine, sqr_threshold_homography, any_masked ? mask.data() : nullptr, counts.data()),
-                   "mh_score"))
-            return false;
-        const int best = static_cast<int>(std::max_element(counts.begin(), counts.end()) - counts.begin());
-        if (counts[best] < need) break;
-        cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)best]));
-        std::fill(lab.begin(), lab.end(), -1);
-        if (!Check(mh_inliers_of_model(engine, best, sqr_threshold_homography, 0, lab.data()),
-                   "mh_inliers_of_model"))
-            return false;
-        for (int i = 0; i < N; ++i) if (lab[i] == 0) mask[i] = 0;
-        any_masked = true;
+    const int W = std::max(shard_world, 1), base = M / W, rem = M % W;
+    const int longest = base + (rem ? 1 : 0);
+    const int mine = base + (shard_rank < rem ? 1 : 0);
+    const long long off = (long long)shard_rank * base + std::min(shard_rank, rem);
+    if (mine > 0) {
+        if (!Check(mh_propose_dlt4(engine, seed, first + off, mine), "mh_propose_dlt4")) return false;
+    } else if (!Check(mh_set_models(engine, nullptr, 0), "mh_set_models")) {
+        return false;
     }
+    std::vector<double> H(9 * (size_t)max_models);
+    int selected = 0;
+    if (!Check(mh_select_greedy(engine, sqr_threshold_homography, need, max_models, mask.data(), H.data(), nullptr, nullptr,
+                                &selected, shard_rank, W, longest, W > 1 ? shard_allgather : nullptr, shard_ctx),
+               "mh_select_greedy"))
+        return false;
+    for (int i = 0; i < selected; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
     return true;
 }
 
@@ -392,61 +390,6 @@ void MultiH::SetSharding(int rank, int world, AllGatherFn fn, void* ctx)
         return;
     }
     shard_rank = rank; shard_world = world; shard_allgather = fn; shard_ctx = ctx;
-}
-
-// The same greedy selection over a batch whose hypotheses are spread over the ranks: rank r owns
-// counters [first + off_r, first + off_r + m_r).  Selection order is the single-GPU one (highest
-// score, lowest global counter on ties), so world sizes 1..G give identical model lists.
-bool MultiH::ProposeModelsSharded(uint64_t seed, long long first, int M, int max_models,
-                                  std::vector<unsigned char>& mask)
-{
-    const int N = static_cast<int>(src_points.size());
-    const int need = std::max(minimum_inlier_number, 8);
-    const int W = shard_world, base = M / W, rem = M % W;
-    const int longest = base + (rem ? 1 : 0);
-    auto size_of = [&](int r) { return base + (r < rem ? 1 : 0); };
-    const int mine = size_of(shard_rank);
-    const long long off = (long long)shard_rank * base + std::min(shard_rank, rem);
-
-    std::vector<double> H(9 * (size_t)std::max(mine, 1), 0.0);
-    if (mine > 0) {
-        if (!Check(mh_propose_dlt4(engine, seed, first + off, mine), "mh_propose_dlt4")) return false;
-        if (!Check(mh_get_models(engine, H.data()), "mh_get_models")) return false;
-    }
-    std::vector<int> local(longest, -1), all((size_t)W * longest), lab(N);
-    std::vector<double> all_H(9 * (size_t)W);
-    bool any_masked = false;
-    for (unsigned char m : mask) any_masked = any_masked || (m == 0);
-    for (int round = 0; round < max_models; ++round) {
-        if (mine > 0 &&
-            !Check(mh_score(engine, sqr_threshold_homography, any_masked ? mask.data() : nullptr, local.data()),
-                   "mh_score"))
-            return false;
-        if (shard_allgather(shard_ctx, local.data(), all.data(), sizeof(int) * (size_t)longest) != 0) {
-            std::cerr << "Error: score all-gather failed" << std::endl;
-            return false;
-        }
-        int best_rank = -1, best_count = -1;
-        for (int r = 0; r < W; ++r)
-            for (int j = 0; j < size_of(r); ++j)
-                if (all[(size_t)r * longest + j] > best_count) { best_count = all[(size_t)r * longest + j]; best_rank = r; }
-        if (best_rank < 0 || best_count < need) break;
-        // every rank offers the first maximum of its own shard; the owner's is the global one
-        const int my_best = mine > 0 ? static_cast<int>(std::max_element(local.begin(), local.begin() + mine) - local.begin()) : 0;
-        if (shard_allgather(shard_ctx, &H[9 * (size_t)my_best], all_H.data(), sizeof(double) * 9) != 0) {
-            std::cerr << "Error: model all-gather failed" << std::endl;
-            return false;
-        }
-        const double* Hb = &all_H[9 * (size_t)best_rank];
-        cluster_homographies.push_back(MatFrom9(Hb));
-        std::fill(lab.begin(), lab.end(), -1);
-        if (!Check(mh_inliers_of_homography(engine, Hb, sqr_threshold_homography, 0, lab.data()),
-                   "mh_inliers_of_homography"))
-            return false;
-        for (int i = 0; i < N; ++i) if (lab[i] == 0) mask[i] = 0;
-        any_masked = true;
-    }
-    return true;
 }
 
 void MultiH::ClusterMergingAndLabeling()
@@ -634,7 +577,7 @@ static int g_shard_rank = 0, g_shard_world = 1;
 static MultiH::AllGatherFn g_shard_fn = nullptr;
 static void* g_shard_ctx = nullptr;
 extern "C" __attribute__((visibility("default")))
-void mhh_set_sharding(int rank, int world, int (*fn)(void*, const void*, void*, size_t), void* ctx)
+void mhh_set_sharding(int rank, int world, MultiH::AllGatherFn fn, void* ctx)
 {
     g_shard_rank = rank; g_shard_world = world; g_shard_fn = fn; g_shard_ctx = ctx;
 }

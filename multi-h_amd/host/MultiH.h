@@ -101,16 +101,16 @@ public:
     // on the points currently labelled outlier and appends at most `max_new` models that gather
     // >= max(min inliers, 8) of them.  0 hypotheses (default) keeps the reference's behaviour.
     void SetIterativeProposal(int hypotheses, int max_new) { iter_hypotheses = hypotheses; iter_max_new = max_new; }
-    // Multi-GPU propose stage (BASELINE configs[3] and [4]): one process per GPU,
-    // every rank holds all correspondences and owns a contiguous shard of each hypothesis batch
-    // (the hypotheses are a pure function of (seed, counter), so the union over ranks is the
-    // single-GPU batch).  Per greedy round the ranks all-gather their int32 inlier scores, run the
-    // same first-maximum selection, and all-gather 72 bytes per rank to learn the winner's H.
-    // Labeling and re-estimation run replicated and deterministic, so the ranks stay identical
-    // without a broadcast.  `fn` is the transport (RCCL through torch.distributed in
-    // multi-h_amd/sharding.py, or any MPI-like all-gather): send `bytes_per_rank` bytes, receive
-    // world * bytes_per_rank in rank order, return 0 on success.
-    typedef int (*AllGatherFn)(void* ctx, const void* send, void* recv, size_t bytes_per_rank);
+    // Multi-GPU propose stage (BASELINE configs[3] and [4]): one process per GPU, every rank holds all
+    // correspondences and owns a contiguous shard of each hypothesis batch (the hypotheses are a pure function of
+    // (seed, counter), so the union over ranks is the single-GPU batch).  Per greedy round the ranks all-gather their
+    // int32 inlier scores — north_star's exchange — and the 72-byte H each offers, and run the same first-maximum
+    // selection on the device.  Labeling and re-estimation run replicated and deterministic, so the ranks stay
+    // identical without a broadcast.  `fn` is the transport: it receives DEVICE pointers (the engine's resident score
+    // buffer on the send side), so RCCL (`ncclAllGather`, or torch.distributed's all_gather_into_tensor as in
+    // multi-h_amd/sharding.py) works on them in place: send `bytes_per_rank` bytes, receive world * bytes_per_rank in
+    // rank order, return 0 once the result is complete in `recv_dev`.  The engine's stream is idle during the call.
+    typedef int (*AllGatherFn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank);
     void SetSharding(int rank, int world, AllGatherFn fn, void* ctx);
     // Number of 8-point hypotheses of the GPU F estimation used when SetEpipolarGeometry was not called.
     void SetFundamentalHypotheses(int n) { fundamental_hypotheses = n; }
@@ -171,8 +171,6 @@ protected:
     bool EstablishStablePointSets();      // M/MultiH.cpp:604-694 (with ComputeLocalHomographies :696-717)
     bool ProposeModels(uint64_t seed, long long first, int hypotheses, int max_models,
                        std::vector<unsigned char>& mask);
-    bool ProposeModelsSharded(uint64_t seed, long long first, int hypotheses, int max_models,
-                              std::vector<unsigned char>& mask);
     void ClusterMergingAndLabeling();     // M/MultiH.cpp:224-312
     bool MergingStep(bool& changed);      // :352-471
     bool LabelingStep(double& energy, bool changed);   // :513-602

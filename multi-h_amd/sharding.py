@@ -78,29 +78,46 @@ def global_model_index(flat_index: int, sizes: list[int]) -> tuple[int, int]:
     return r, flat_index
 
 
-# Transport hook of the host class (MultiH::SetSharding, multi-h_amd/host/MultiH.h): the C++ side
-# hands over host buffers; the exchange itself is torch.distributed's all-gather — RCCL when the
-# process group is "nccl" (staged through a device tensor, 4*M/G bytes per rank, latency-bound),
-# gloo in the tests.
-ALLGATHER_CFUNC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+# Transport hook of the host class (MultiH::SetSharding, multi-h_amd/host/MultiH.h) and of mh_select_greedy: the engine
+# hands over DEVICE pointers (its resident int32 score buffer on the send side); the exchange is torch.distributed's
+# all-gather on zero-copy views of them — RCCL when the process group is "nccl".  With "gloo" (tests: several ranks
+# share one GPU, which RCCL refuses) the views are staged through host memory.
+ALLGATHER_CFUNC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong)
+
+
+class _DevBytes:
+    """Zero-copy uint8 view of device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2,
+                                         "strides": None}
 
 
 def make_allgather_hook(world: int, device: torch.device | None = None, group=None):
-    """ctypes callback for mhh_set_sharding / MultiH::SetSharding.  `device` = the rank's GPU for an
-    nccl group (None: exchange host tensors directly, gloo).  Keep the returned object alive for as
-    long as the host library may call it."""
+    """ctypes callback for mhh_set_sharding / MultiH::SetSharding / mh_select_greedy.  `device` = the rank's GPU (the
+    pointers the engine passes are device pointers).  device=None treats the pointers as HOST memory: only the CPU
+    tests of the rank-ordered concatenation use that.  Keep the returned object alive for as long as the host library
+    may call it."""
     stats = {"calls": 0, "bytes": 0}
 
     def hook(_ctx, send, recv, nbytes):
         try:
-            src = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(send))
-            dst = np.ctypeslib.as_array((ctypes.c_uint8 * (nbytes * world)).from_address(recv))
             if device is None:
+                src = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(send))
+                dst = np.ctypeslib.as_array((ctypes.c_uint8 * (nbytes * world)).from_address(recv))
                 dist.all_gather_into_tensor(torch.from_numpy(dst), torch.from_numpy(src), group=group)
+                stats["calls"] += 1
+                stats["bytes"] += nbytes * world
+                return 0
+            src = torch.as_tensor(_DevBytes(send, nbytes), device=device)
+            dst = torch.as_tensor(_DevBytes(recv, nbytes * world), device=device)
+            if dist.get_backend(group) == "gloo":
+                out = torch.empty(nbytes * world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, src.cpu(), group=group)
+                dst.copy_(out)
             else:
-                out = torch.empty(nbytes * world, dtype=torch.uint8, device=device)
-                dist.all_gather_into_tensor(out, torch.from_numpy(src).to(device), group=group)
-                dst[:] = out.cpu().numpy()
+                dist.all_gather_into_tensor(dst, src, group=group)        # RCCL on the engine's own buffers
+            torch.cuda.synchronize(device)                                # the engine resumes on its own stream
             stats["calls"] += 1
             stats["bytes"] += nbytes * world
             return 0

@@ -117,3 +117,19 @@ int mh_labeling_step(mh_engine* e, int, int* labeling, double* energy, int* cycl
 }
 }
 extern "C" int mh_build_neighbors_knn_radius(mh_engine*, int, double) { return MH_OK; }
+extern "C" int mh_select_greedy(mh_engine* e, double, int, int max_models, unsigned char* mask, double* H_out, long long* counters,
+                                int* counts, int* selected, int, int, int, mh_allgather_dev_fn, void*)
+{
+    // model `j` is the j-th pick with 30 inliers (every other point); two picks, or one in mode 1
+    int k = e->mode == 1 ? 1 : 2;
+    if (k > max_models) k = max_models;
+    if (k > e->m) k = e->m;
+    for (int j = 0; j < k; ++j) {
+        std::memcpy(H_out + 9 * j, &e->H[9 * (size_t)j], sizeof(double) * 9);
+        if (counters) counters[j] = j;
+        if (counts) counts[j] = 30;
+        if (mask) for (int i = 0; i < e->n; ++i) if ((i % 2) == (j % 2)) mask[i] = 0;
+    }
+    *selected = k;
+    return MH_OK;
+}

@@ -540,6 +540,46 @@ def test_full_size_labeling_equals_the_reference_gco(engine, synth, oracle):
     assert cycles >= 2 and (lab >= 0).sum() > 30000
 
 
+@pytest.mark.parametrize("n,planes,M,max_models", [(3000, 3, 4000, 12), (5000, 3, 10000, 16)])
+def test_greedy_selection_on_the_device(engine, synth, n, planes, M, max_models):
+    """mh_select_greedy (csrc/select.hip) against the selection spelt out on the host with the primitives it replaced —
+    masked re-score of the WHOLE batch, first maximum, the winner's inliers leave the mask: same hypotheses in the same
+    order with the same counts, same homographies, same final mask.  (The device version prunes hypotheses that
+    dropped below `need`; counts only fall, so that can never change a pick.)  And the loop issues no host<->device
+    copy: the count of explicit copies does not depend on the number of rounds."""
+    sc = synth.make_scene(n, planes, seed=31, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    need = 20
+    engine.propose_dlt4(77, 0, M)
+    H_all = engine.get_models()
+    mask = np.ones(n, dtype=np.uint8)
+    picks, counts_ref = [], []
+    for _ in range(max_models):
+        c = engine.score(THR2, mask)
+        best = int(np.argmax(c))
+        if c[best] < need:
+            break
+        picks.append(best)
+        counts_ref.append(int(c[best]))
+        lab = engine.inliers_of_model(best, THR2, 0, np.full(n, -1, np.int32))
+        mask[(lab == 0)] = 0
+    assert len(picks) >= planes
+    engine.copy_stats(reset=True)
+    H, counters, counts, mask_out = engine.select_greedy(THR2, need, max_models, np.ones(n, dtype=np.uint8))
+    copies_full = engine.copy_stats(reset=True)
+    assert counters.tolist() == picks and counts.tolist() == counts_ref
+    assert np.array_equal(H.view(np.uint64), H_all[picks].view(np.uint64))
+    assert np.array_equal(mask_out, mask)
+    # fewer rounds, same number of copies (mask up, H + counters + mask down)
+    engine.select_greedy(THR2, need, 2, np.ones(n, dtype=np.uint8))
+    copies_two = engine.copy_stats(reset=True)
+    assert copies_full == copies_two and sum(copies_full) <= 4
+    # a restricted support mask in: only those points are ever counted or claimed
+    half = (np.arange(n) % 2).astype(np.uint8)
+    H2, counters2, counts2, m2 = engine.select_greedy(THR2, need, max_models, half)
+    assert np.all(m2[half == 0] == 0) and counts2[0] == engine.score(THR2, half)[counters2[0]]
+
+
 # ---- host class MultiH over the C ABI (integration) -----------------------------------------
 def test_host_multih_process_loop(mh, engine_lib, synth):
     import ctypes as C

@@ -32,11 +32,10 @@ if "KNN" in os.environ: host.mhh_set_neighbourhood(int(os.environ["KNN"]), C.c_d
 hook = None
 if world > 1:
     backend = os.environ.get("LOOP_BACKEND", "nccl")
-    if backend == "nccl":
-        torch.cuda.set_device(device)
+    torch.cuda.set_device(device)
     dist.init_process_group(backend, rank=rank, world_size=world)
     sharding = importlib.import_module("multi-h_amd.sharding")
-    hook = sharding.make_allgather_hook(world, torch.device("cuda", device) if backend == "nccl" else None)
+    hook = sharding.make_allgather_hook(world, torch.device("cuda", device))
     host.mhh_set_sharding(rank, world, hook, None)
     dist.barrier()
 sc = mh.synth.make_scene(N, K, seed=1234, with_neighbours=False)
