@@ -86,6 +86,31 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     return HOST_LIB
 
 
+def build_tuning(force: bool = False, verbose: bool = False) -> str:
+    """The measurement library for tools/kernel_sweep.py: the same sources with -DMH_TUNING, which adds the residual /
+    score kernel variants (other tilings, nt stores, compiler division, store-only calibration, fused multiply-adds)
+    that the product library does not carry.  Load it with MH_LIB=multi-h_amd/libmultih_hip_tuning.so."""
+    out_dir = os.path.join(HERE, "_build_tuning")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(HERE, "libmultih_hip_tuning.so")
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
+    headers.append(os.path.join(ROOT, "include", "multih_hip.h"))
+    jobs, objs = [], []
+    for src in KERNEL_SOURCES:
+        s_, o = os.path.join(CSRC, src), os.path.join(out_dir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s_] + headers):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-DMH_TUNING", "-c", s_, "-o", o])
+    if jobs:
+        if verbose:
+            print(f"[build] tuning library: compiling {len(jobs)} translation unit(s) with -DMH_TUNING")
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _newer(lib, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_engine(force, verbose)
     if os.path.exists(os.path.join(HOST, "MultiH.cpp")):
@@ -95,3 +120,5 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv, verbose=True)
     print("ok:", LIB)
+    if "--tuning" in sys.argv:
+        print("ok:", build_tuning(force="--force" in sys.argv, verbose=True))

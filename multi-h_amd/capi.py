@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmultih_hip.so")
+# MH_LIB: another build of the same ABI, e.g. the measurement library of `build.py --tuning` (tools/ only)
+LIB_PATH = os.environ.get("MH_LIB") or os.path.join(HERE, "libmultih_hip.so")
 
 MH_OK = 0
 ERR_NAMES = {-1: "MH_ERR_NO_DEVICE", -2: "MH_ERR_INVALID", -3: "MH_ERR_HIP", -4: "MH_ERR_NOT_SET",

@@ -127,7 +127,8 @@ struct mh_engine {
     int tune_push_mult = 4;                  // push cycles per phase = this x (depth of the last relabel + 3)  // solver: relax rounds per barrier interval, push cycles per phase, push phases per relabel, workgroups
     ExpandStats last_expand{};
 
-    Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n }; }
+    double bbox[4] = { NAN, NAN, NAN, NAN };   // xmin xmax ymin ymax of the source points
+    Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n, bbox[0], bbox[1], bbox[2], bbox[3] }; }
 };
 
 namespace {
@@ -556,6 +557,18 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
         // everything sized by the previous point set is stale: the residual matrix and its pitch, the sampled batch,
         // the fundamental-matrix hypotheses
         e->m = 0; e->ldr = 0; e->have_samples = false; e->fm = 0;
+    }
+    {
+        double xmin = src_xy[0], xmax = src_xy[0], ymin = src_xy[1], ymax = src_xy[1];
+        bool finite = true;
+        for (int i = 0; i < n; ++i) {
+            const double x = src_xy[2 * i], y = src_xy[2 * i + 1];
+            finite = finite && std::isfinite(x) && std::isfinite(y);
+            xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
+            ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
+        }
+        if (!finite) xmin = xmax = ymin = ymax = NAN;
+        e->bbox[0] = xmin; e->bbox[1] = xmax; e->bbox[2] = ymin; e->bbox[3] = ymax;
     }
     e->n = n;
     e->have_aff = affines != nullptr;
@@ -1495,8 +1508,15 @@ int mh_set_tuning(mh_engine* e, int key, int value)
 {
     return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
+#ifdef MH_TUNING
     if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
     if (key == 1) { e->tune_score_variant = value; return MH_OK; }
+#else
+    if (key == 0 || key == 1) {
+        if (value == 0) return MH_OK;
+        return fail(MH_ERR_INVALID, "residual / score kernel variants exist only in a library built with -DMH_TUNING");
+    }
+#endif
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }

@@ -70,6 +70,22 @@ __device__ __forceinline__ bool model_pre(const double* h)
     return ok;
 }
 
+// Per-model bound on s over the bounding box of ALL source points: every operation of s = (h6*x + h7*y) + h8 is
+// monotone in its operands and rounding is monotone, so the s the sweep computes for any point of the box lies in
+// [lo, hi] as computed here with the same operations at the box's corners.  True when that interval keeps clear of
+// (-2^-255, 2^-255): the model's horizon does not come near the data.  NaN / infinite bounds compare false.
+__device__ __forceinline__ bool model_far(const double* h, double xmin, double xmax, double ymin, double ymax)
+{
+    const double a = h[6] * xmin, b = h[6] * xmax, c = h[7] * ymin, d = h[7] * ymax;
+    const double lo = (fmin(a, b) + fmin(c, d)) + h[8];
+    const double hi = (fmax(a, b) + fmax(c, d)) + h[8];
+    const bool finite = (a == a) && (b == b) && (c == c) && (d == d);      // fmin/fmax would hide a NaN product
+    return finite && (lo >= 0x1p-255 || hi <= -0x1p-255);
+}
+
+// SCHK = false: the caller has proved |s| >= 2^-255 for every point this model can meet (model_far below), so the
+// per-pair compare disappears and the fallback is taken on the per-point / per-model precondition alone.
+template <bool SCHK = true>
 __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, double h3,
                                               double h4, double h5, double h6, double h7,
                                               double h8, double x, double y, double x2, double y2,
@@ -93,7 +109,7 @@ __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, d
     const double dy = y2 - v;
     double d2 = dx * dx + dy * dy;
     // bitwise, not short-circuit: two lane masks and-ed on the scalar unit, one branch
-    const int ok = (int)pre_ok & (int)(__builtin_fabs(s) >= 0x1p-255);
+    const int ok = SCHK ? ((int)pre_ok & (int)(__builtin_fabs(s) >= 0x1p-255)) : (int)pre_ok;
     if (__builtin_expect(!ok, 0)) {
         // The empty volatile asm keeps hipcc from if-converting this branch into
         // "compute both and select", which would put the IEEE sequence back on the hot path.

@@ -13,6 +13,9 @@ struct Points {
     const double* x2;
     const double* y2;
     int n;
+    // bounding box of the source points (x1, y1), taken when the correspondences were set; NaN when unknown.  The
+    // residual sweep uses it to prove, per model, that the projective denominator stays away from zero.
+    double xmin, xmax, ymin, ymax;
 };
 
 struct Affines {            // a11 a12 a21 a22, SoA

@@ -23,6 +23,8 @@
 //   Algorithmic bytes per launch: 8*N*M (R) + 32*N + 72*M + 4*M.
 // k_score — same sweep without the stores (FP64-VALU/division bound).
 
+#include <type_traits>
+
 #include "mh_kernels.hpp"
 #include "mh_device.hpp"
 
@@ -38,7 +40,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
            const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
            long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
-           int psplit, int swapxy)
+           int psplit, int swapxy, double bx0, double bx1, double by0, double by1)
 {
     constexpr int CH = PPL / 2;                 // 16-B chunks per lane
     constexpr int WAVE_PTS = 64 * PPL;          // points per wave per tile
@@ -61,11 +63,13 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
         s_h[i] = (g < (size_t)M * 9) ? H[g] : 0.0;
     }
     __shared__ int s_hok[MC];                   // per-model precondition of the shared-reciprocal division
+    __shared__ int s_far[MC];                   // per-model proof that |s| >= 2^-255 on the whole point set (model_far)
     __shared__ int s_aok[SYM ? MC : 1];
     __syncthreads();
     if (threadIdx.x < MC) {
         const double* h = s_h + 9 * threadIdx.x;
         s_hok[threadIdx.x] = model_pre(h);
+        s_far[threadIdx.x] = model_far(h, bx0, bx1, by0, by1);
         if (SYM) {
             // H^-1 up to scale = adjugate; each entry is (mul, mul, sub), rounded once per operation
             double* a = s_a + 9 * threadIdx.x;
@@ -141,58 +145,66 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                 const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5],
                              h6 = h[6], h7 = h[7], h8 = h[8];
                 const bool hok = s_hok[mi] != 0;           // wave-uniform
+                const bool far = FAST && !CONTRACT && s_far[mi] != 0;
                 const bool aok = SYM ? (s_aok[mi] != 0) : false;
                 int c_m = 0;
+                // the chunk loop, once with the per-pair |s| compare and once without (the model's horizon is provably far
+                // from every point): one VALU instruction per pair less on the common path
+                auto sweep = [&](auto schk) {
+                    constexpr bool SCHK = decltype(schk)::value;
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    if (CALIB) {       // store-bandwidth calibration build: no residual arithmetic
-                        const int n = wbase + c * 128 + lane * 2;
-                        if (n + 1 < N)
-                            *reinterpret_cast<double2*>(R + (size_t)m * ldr + n) =
-                                make_double2(px[2 * c] + h0, py[2 * c] + h0);
-                        continue;
-                    }
-                    double d0s, d1s;
-                    const double d0 = CONTRACT ? fwd_d2_contracted(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
-                                                                   py[2 * c], qx[2 * c], qy[2 * c])
-                                      : FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
-                                                         py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c] && hok)
-                                           : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
-                                                    py[2 * c], qx[2 * c], qy[2 * c]);
-                    const double d1 = CONTRACT ? fwd_d2_contracted(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
-                                                                   py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1])
-                                      : FAST ? fwd_d2_fast(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
-                                                         py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1] && hok)
-                                           : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
-                                                    py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
-                    d0s = d0; d1s = d1;
-                    if (SYM) {       // + ||H^-1 p2 - p1||^2 (north_star's symmetric transfer; no reference oracle)
-                        const double* a = s_a + 9 * mi;
-                        const double b0 = fwd_d2_fast(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
-                                                      qx[2 * c], qy[2 * c], px[2 * c], py[2 * c], pokb[2 * c] && aok);
-                        const double b1 = fwd_d2_fast(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
-                                                      qx[2 * c + 1], qy[2 * c + 1], px[2 * c + 1], py[2 * c + 1],
-                                                      pokb[2 * c + 1] && aok);
-                        d0s = d0 + b0;
-                        d1s = d1 + b1;
-                    }
-                    if (WRITE_R) {
-                        const int n = wbase + c * 128 + lane * 2;
-                        double* dstp = R + (size_t)m * ldr + n;
-                        if (n + 1 < N) {
-                            if (NT) {
-                                __builtin_nontemporal_store(d0s, dstp);
-                                __builtin_nontemporal_store(d1s, dstp + 1);
-                            } else {
-                                *reinterpret_cast<double2*>(dstp) = make_double2(d0s, d1s);
-                            }
-                        } else if (n < N) {
-                            dstp[0] = d0s;
+                    for (int c = 0; c < CH; ++c) {
+                        if (CALIB) {       // store-bandwidth calibration build: no residual arithmetic
+                            const int n = wbase + c * 128 + lane * 2;
+                            if (n + 1 < N)
+                                *reinterpret_cast<double2*>(R + (size_t)m * ldr + n) =
+                                    make_double2(px[2 * c] + h0, py[2 * c] + h0);
+                            continue;
                         }
+                        double d0s, d1s;
+                        const double d0 = CONTRACT ? fwd_d2_contracted(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                                                       py[2 * c], qx[2 * c], qy[2 * c])
+                                          : FAST ? fwd_d2_fast<SCHK>(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                                                   py[2 * c], qx[2 * c], qy[2 * c], pok[2 * c] && hok)
+                                               : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c],
+                                                        py[2 * c], qx[2 * c], qy[2 * c]);
+                        const double d1 = CONTRACT ? fwd_d2_contracted(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                                                       py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1])
+                                          : FAST ? fwd_d2_fast<SCHK>(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                                                   py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1], pok[2 * c + 1] && hok)
+                                               : fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1],
+                                                        py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
+                        d0s = d0; d1s = d1;
+                        if (SYM) {       // + ||H^-1 p2 - p1||^2 (north_star's symmetric transfer; no reference oracle)
+                            const double* a = s_a + 9 * mi;
+                            const double b0 = fwd_d2_fast<true>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                                                                qx[2 * c], qy[2 * c], px[2 * c], py[2 * c], pokb[2 * c] && aok);
+                            const double b1 = fwd_d2_fast<true>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                                                                qx[2 * c + 1], qy[2 * c + 1], px[2 * c + 1], py[2 * c + 1],
+                                                                pokb[2 * c + 1] && aok);
+                            d0s = d0 + b0;
+                            d1s = d1 + b1;
+                        }
+                        if (WRITE_R) {
+                            const int n = wbase + c * 128 + lane * 2;
+                            double* dstp = R + (size_t)m * ldr + n;
+                            if (n + 1 < N) {
+                                if (NT) {
+                                    __builtin_nontemporal_store(d0s, dstp);
+                                    __builtin_nontemporal_store(d1s, dstp + 1);
+                                } else {
+                                    *reinterpret_cast<double2*>(dstp) = make_double2(d0s, d1s);
+                                }
+                            } else if (n < N) {
+                                dstp[0] = d0s;
+                            }
+                        }
+                        c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0s < thr2) & okm[2 * c]);
+                        c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1s < thr2) & okm[2 * c + 1]);
                     }
-                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0s < thr2) & okm[2 * c]);
-                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1s < thr2) & okm[2 * c + 1]);
-                }
+                };
+                if (far) sweep(std::false_type{});
+                else sweep(std::true_type{});
                 // lane mi accumulates model mi: read-modify-write of that one lane through the scalar unit
                 const int c_new = __builtin_amdgcn_readlane(cnt, mi) + c_m;
                 asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(c_new), "s"(mi) : "m0");
@@ -242,25 +254,29 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     dim3 grid(gx, psplit);
     if (swapxy) grid = dim3(psplit, gx);
     hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT>), grid, dim3(256), 0, s, p.x1, p.y1,
-                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy);
+                       p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy,
+                       p.xmin, p.xmax, p.ymin, p.ymax);
     return hipGetLastError();
 }
 
+// variant: 0 = the reference's forward transfer error, -1 = north_star's symmetric transfer error (extension).
+// Everything else is a tuning / measurement build of the same kernel (other PPL / MC, nt stores, compiler division,
+// coefficients in SGPRs, store-only calibration, forced slices, fused multiply-adds — the last one NOT bit-exact) and
+// exists only in libraries compiled with -DMH_TUNING (multi-h_amd/build.py --tuning) for tools/kernel_sweep.py.
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s)
 {
-    if (variant == -2)          // symmetric mode at PPL 2 (tuning; PPL 4 measured 3 % faster)
+    if (variant == 0) return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, MC 16, plain 16-B stores
+    if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+#ifdef MH_TUNING
+    if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    if (variant == -1)          // symmetric transfer error (north_star wording; extension)
-        return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
-    if (variant >= 300)         // 300 + s: s interleaved slices with the slice index as the fastest grid dimension (tuning)
+    if (variant >= 300)         // 300 + s: s interleaved slices with the slice index as the fastest grid dimension
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 300, 1);
-    if (variant >= 200)         // 200 + s: s contiguous point slices instead of interleaved tiles (tuning)
+    if (variant >= 200)         // 200 + s: s contiguous point slices instead of interleaved tiles
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, -(variant - 200));
-    if (variant >= 100) {       // 100 + psplit: default kernel with a forced point split (tuning)
+    if (variant >= 100)         // 100 + psplit: default kernel with a forced point split
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 100);
-    }
-    // Tuning variants kept for the A/B evidence in DESIGN.md §7 (bench.py --variant, tools/kernel_sweep.py).
     switch (variant) {
     case 1: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 2
     case 2: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // nt stores
@@ -269,11 +285,13 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 5: return launch_rs<4, 8, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // MC 8
     case 6: return launch_rs<4, 32, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // MC 32
     case 7: return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);    // store-only calibration
-    case 10: return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // fused multiply-adds: NOT bit-exact, measurement only
     case 8: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 8
     case 9: return launch_rs<6, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 6
-    default: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);               // PPL 4, MC 16, plain 16-B stores
+    case 10: return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // fused multiply-adds: NOT bit-exact
+    default: break;
     }
+#endif
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
@@ -284,11 +302,12 @@ hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
         return launch_rs<4, 16, false, false, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
     }
     if (mask) return launch_rs<4, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
-    switch (variant) {
-    case 1: return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);           // PPL 2
-    case 3: return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);    // compiler IEEE division
-    default: return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
-    }
+    if (variant == 0) return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+#ifdef MH_TUNING
+    if (variant == 1) return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);           // PPL 2
+    if (variant == 3) return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);    // compiler IEEE division
+#endif
+    return hipErrorInvalidValue;
 }
 
 // ComputeInliersOfHomography, M/MultiH.cpp:743-768.

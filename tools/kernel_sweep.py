@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the residual / score kernel variants on one GPU (HIP events through the C ABI)."""
+"""Times the residual / score kernel variants on one GPU (HIP events through the C ABI).  The variants exist only in the
+measurement library: python multi-h_amd/build.py --tuning; MH_LIB=multi-h_amd/libmultih_hip_tuning.so python tools/kernel_sweep.py"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mh = importlib.import_module("multi-h_amd")
