@@ -120,6 +120,23 @@ def labeling_extra(mh, eng, a, thr2, lam):
     return out
 
 
+def full_loop_extra(a):
+    """Context (not part of `value`): BASELINE configs[4] on this one GPU — the whole Process() of the host class
+    (100 000 proposals, greedy selection, 20 merge/label/re-estimate iterations) through tools/loop_bench.py in a
+    child process."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(N=str(a.points), K=str(a.planes), HYP=str(a.models), ITERS="20")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loop_bench.py")], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    rec = json.loads(line[-1])
+    return {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 20 propose-expand iterations",
+            "iterations": 20, "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
+            "process_s": rec["total_s"], "ms_per_iteration": rec["loop_s"] / 20 * 1e3, "digest": rec["digest"]}
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of a
     parent that never touches torch or the GPU (no re-exec of a process that has).  Rank 0 inherits
@@ -329,6 +346,10 @@ def main():
                 out["labeling"] = labeling_extra(mh, eng, a, thr2, lam)
             except Exception as ex:                      # context only: never lose the headline line
                 out["labeling"] = {"error": repr(ex)}
+            try:
+                out["full_loop"] = full_loop_extra(a)
+            except Exception as ex:
+                out["full_loop"] = {"error": repr(ex)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -101,7 +101,7 @@ struct mh_engine {
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
-    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_aux, ew_trace;
+    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_aux, ew_trace, d_order;
     int trace_moves = 0;                     // > 0: k_solve logs 8 ints per move (mh_set_tuning key 8)
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
@@ -281,6 +281,24 @@ int upload_graph(mh_engine* e)
         HIPCHK(hipMemcpyAsync(e->d_w.p, e->g_w.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(e->d_rev.p, e->g_rev.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
     }
+    {
+        // the solver's site order: Fisher-Yates with the engine's counter RNG, fixed seed (results never depend on it)
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        unsigned long long z = 0x6d682d6f72646572ull;
+        for (int i = n - 1; i > 0; --i) {
+            z += 0x9E3779B97F4A7C15ull;
+            unsigned long long x = z;
+            x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+            x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+            x ^= x >> 31;
+            const int j = (int)(((x >> 32) * (unsigned long long)(i + 1)) >> 32);
+            std::swap(order[i], order[j]);
+        }
+        HIPCHK(e->d_order.reserve(n));
+        HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));      // `order` dies with this scope
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_graph = true;
     return MH_OK;
@@ -332,7 +350,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     if (e->cost_L != e->m + 1) return fail(MH_ERR_NOT_SET, "data cost is stale; call mh_data_cost first");
     int rc = ensure_expand_work(e);
     if (rc) return rc;
-    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size() };
+    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size(), e->d_order.p };
     // the solver launch must be resident as a whole (it synchronises through a grid barrier): at most half
     // the CUs, so that engines of other processes sharing the GPU can never starve each other's launches
     const int solve_grid = std::max(1, std::min(e->tune_expand[3], e->cu_count));
@@ -475,7 +493,7 @@ void mh_destroy(mh_engine* e)
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
-    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_aux.release(); e->ew_trace.release();
+    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_aux.release(); e->ew_trace.release(); e->d_order.release();
     e->knn_tmp.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     if (e->h_ms) (void)hipHostFree(e->h_ms);

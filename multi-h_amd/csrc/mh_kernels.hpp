@@ -105,6 +105,8 @@ struct Graph {              // symmetric weighted CSR in HBM
     const int* w;           // nnz  multiplicity mult(i,j)
     const int* rev;         // nnz  index of the reverse arc
     int n, nnz;
+    const int* order;       // n    a fixed pseudo-random permutation of the sites: the alpha-expansion's solver takes its
+                            //      core sites in this order so that a workgroup never owns a spatial cluster (expand.hip)
 };
 
 struct ExpandWork {         // scratch owned by the engine
