@@ -899,25 +899,28 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     if (rc) return rc;
     if (!data || n <= 0 || d <= 0 || d > 16 || !assign || !n_modes)
         return fail(MH_ERR_INVALID, "bad argument (1 <= d <= 16)");
+    constexpr int B = MS_BATCH;
     HIPCHK(e->ms_data.reserve((size_t)n * d));
-    HIPCHK(e->ms_mean.reserve(16));
-    HIPCHK(e->ms_votes.reserve(n));
-    HIPCHK(e->ms_out.reserve(4));
-    HIPCHK(e->ms_list.reserve(std::max<size_t>(2 * (size_t)n, 4096)));       // >= the prefix the host always copies
-    HIPCHK(e->ms_partial.reserve(64 * 16));
-    HIPCHK(e->ms_pcnt.reserve(64));
+    HIPCHK(e->ms_mean.reserve((size_t)B * 16));
+    HIPCHK(e->ms_votes.reserve((size_t)B * n));
+    HIPCHK(e->ms_out.reserve((size_t)B * 4));
+    HIPCHK(e->ms_list.reserve((size_t)B * 2 * n));
+    HIPCHK(e->ms_partial.reserve((size_t)B * 64 * 16));
+    HIPCHK(e->ms_pcnt.reserve((size_t)B * 64));
     HIPCHK(hipMemcpyAsync(e->ms_data.p, data, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemsetAsync(e->ms_votes.p, 0, sizeof(int) * n, e->stream));
+    HIPCHK(hipMemsetAsync(e->ms_votes.p, 0, sizeof(int) * (size_t)B * n, e->stream));
     MeanShiftWork w{ e->ms_data.p, n, d, e->ms_mean.p, e->ms_votes.p, e->ms_out.p, e->ms_list.p,
                      e->ms_partial.p, e->ms_pcnt.p };
     const double band_sq = band_width * band_width;                 // MeanShiftClustering.h:31
     const double stop_thresh = 1e-3 * band_width;                   // :48
     constexpr int MS_LIST_PREFIX = 2048;
-    if (!e->h_ms) {
-        HIPCHK(hipHostMalloc((void**)&e->h_ms, sizeof(MeanShiftResultBlock), hipHostMallocMapped));
+    if (!e->h_ms) {                                                 // B result blocks, then the B seed rows
+        HIPCHK(hipHostMalloc((void**)&e->h_ms, sizeof(MeanShiftResultBlock) * B + sizeof(int) * B, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_ms_dev, e->h_ms, 0));
     }
-    if (!e->h_ms_list) HIPCHK(hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * MS_LIST_PREFIX, hipHostMallocDefault));
+    if (!e->h_ms_list) HIPCHK(hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * MS_LIST_PREFIX * B, hipHostMallocDefault));
+    int* const starts = reinterpret_cast<int*>(e->h_ms + B);
+    const int* const starts_dev = reinterpret_cast<const int*>(e->h_ms_dev + B);
 
     // `init` of the reference (:125-130) is the ascending list of unvisited rows, rebuilt after every
     // climb; a Fenwick tree over the unvisited flags answers "the k-th unvisited row" in O(log n).
@@ -937,60 +940,89 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         for (int i = row + 1; i <= n; i += i & -i) fen[i] -= 1;
     };
     int unvisited = n;
-    std::vector<std::vector<double>> cent;
+    std::vector<double> cent;                                       // modes, d values each
+    int n_cent = 0;
     std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: sorted (row, votes)
     unsigned long long counter = 0;
-    auto l2 = [](const double* a, const double* b, int dd) {
-        double s = 0.0;
-        for (int j = 0; j < dd; ++j) { const double x = a[j] - b[j]; s = s + x * x; }
-        return std::sqrt(s);
-    };
     while (unvisited > 0) {
-        unsigned long long z = seed + counter++;                    // splitmix64
-        z += 0x9E3779B97F4A7C15ull;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        const double rnd = (double)(z >> 11) * (1.0 / 9007199254740992.0);
-        const int st = kth_unvisited((int)std::round(rnd * (double)(unvisited - 1)));     // :55-56
-        const int* out = e->h_ms->out;
-        const double* mean = e->h_ms->mean;
-        for (int batch = 0; batch < 20000; ++batch) {               // batches of device-side iterations
-            HIPCHK(launch_ms_climb(w, batch == 0 ? st : -1, band_sq, stop_thresh, e->tune_ms_batch, e->h_ms_dev, e->stream));
-            HIPCHK(hipMemcpyAsync(e->h_ms_list, e->ms_list.p, sizeof(int) * 2 * MS_LIST_PREFIX, hipMemcpyDeviceToHost, e->stream));
+        // the batch: MS_BATCH seeds drawn from the rows unvisited now (:55-56 for each draw); a small tail draws fewer
+        const int climbs = std::min(B, unvisited);
+        for (int b = 0; b < climbs; ++b) {
+            unsigned long long z = seed + counter++;                // splitmix64
+            z += 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+            const double rnd = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+            starts[b] = kth_unvisited((int)std::round(rnd * (double)(unvisited - 1)));
+        }
+        auto all_ended = [&]() {
+            for (int b = 0; b < climbs; ++b) if (!e->h_ms[b].out[1] && !e->h_ms[b].out[3]) return false;
+            return true;
+        };
+        bool ended = false;
+        for (int round = 0; round < 20000 && !ended; ++round) {     // rounds of device-side iterations
+            HIPCHK(launch_ms_climb(w, climbs, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
+                                   e->h_ms_dev, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
-            if (out[1] || out[3]) break;
+            ended = all_ended();
         }
-        if (!out[1] && !out[3]) {
-            // the climb neither converged nor died within the cap: compact and clear its votes (they would leak into the
-            // next climb's membership list) and give up loudly
-            HIPCHK(launch_ms_collect(w, e->stream));
+        if (!ended) {
+            // a climb neither converged nor died within the cap: compact and clear the votes (they would leak into the
+            // next call's membership lists) and give up loudly
+            HIPCHK(launch_ms_collect(w, climbs, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
-            return fail(MH_ERR_INVALID, "mean shift: a climb did not converge within 20000 batches of iterations");
+            return fail(MH_ERR_INVALID, "mean shift: a climb did not converge within 20000 rounds of iterations");
         }
-        const int len = out[2];
-        list.resize(2 * (size_t)len);
-        const int head = std::min(len, MS_LIST_PREFIX);
-        std::copy(e->h_ms_list, e->h_ms_list + 2 * (size_t)head, list.begin());
-        if (len > head) {
-            HIPCHK(hipMemcpyAsync(list.data() + 2 * (size_t)head, e->ms_list.p + 2 * (size_t)head,
-                                  sizeof(int) * 2 * (size_t)(len - head), hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(hipStreamSynchronize(e->stream));
+        for (int b = 0; b < climbs; ++b) {
+            const int head = std::min(e->h_ms[b].out[2], MS_LIST_PREFIX);
+            if (head > 0)
+                HIPCHK(hipMemcpyAsync(e->h_ms_list + (size_t)b * 2 * MS_LIST_PREFIX, e->ms_list.p + (size_t)b * 2 * n,
+                                      sizeof(int) * 2 * (size_t)head, hipMemcpyDeviceToHost, e->stream));
         }
-        std::vector<std::pair<int, int>> mine(len);
-        for (int k = 0; k < len; ++k) {
-            mine[k] = { list[2 * k], list[2 * k + 1] };
-            if (!visited[list[2 * k]]) { mark_visited(list[2 * k]); --unvisited; }
-        }
-        std::sort(mine.begin(), mine.end());
-        if (!out[1]) {
-            if (!visited[st]) { mark_visited(st); --unvisited; }    // climb that captured no row
-        } else {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        // apply the climbs in draw order; one whose seed an earlier climb of the batch has visited never started in
+        // the reference's terms and is dropped
+        for (int b = 0; b < climbs; ++b) {
+            const int st = starts[b];
+            if (visited[st]) continue;
+            const int* out = e->h_ms[b].out;
+            const double* mean = e->h_ms[b].mean;
+            const int len = out[2];
+            list.resize(2 * (size_t)len);
+            const int head = std::min(len, MS_LIST_PREFIX);
+            const int* staged = e->h_ms_list + (size_t)b * 2 * MS_LIST_PREFIX;
+            std::copy(staged, staged + 2 * (size_t)head, list.begin());
+            if (len > head) {
+                HIPCHK(hipMemcpyAsync(list.data() + 2 * (size_t)head, e->ms_list.p + (size_t)b * 2 * n + 2 * (size_t)head,
+                                      sizeof(int) * 2 * (size_t)(len - head), hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(hipStreamSynchronize(e->stream));
+            }
+            std::vector<std::pair<int, int>> mine(len);
+            for (int k = 0; k < len; ++k) {
+                mine[k] = { list[2 * k], list[2 * k + 1] };
+                if (!visited[list[2 * k]]) { mark_visited(list[2 * k]); --unvisited; }
+            }
+            std::sort(mine.begin(), mine.end());
+            if (!out[1]) {
+                if (!visited[st]) { mark_visited(st); --unvisited; }    // climb that captured no row
+                continue;
+            }
             int merge_with = -1;
-            for (size_t cn = 0; cn < cent.size(); ++cn)
-                if (l2(mean, cent[cn].data(), d) < band_width / 2) { merge_with = (int)cn; break; }    // :101-109
+            // :101-109, first centroid with sqrt(sum) < bandWidth/2.  The running sum of squares only grows, so a
+            // centroid is rejected as soon as it exceeds the squared limit by a safe margin; the deciding comparison
+            // is the reference's own.
+            const double half = band_width / 2, reject = half * half * (1.0 + 1e-9);
+            for (int cn = 0; cn < n_cent && merge_with < 0; ++cn) {
+                const double* c = cent.data() + (size_t)cn * d;
+                double sq = 0.0;
+                int j = 0;
+                for (; j < d && sq <= reject; ++j) { const double x = mean[j] - c[j]; sq = sq + x * x; }
+                if (j == d && std::sqrt(sq) < half) merge_with = cn;
+            }
             if (merge_with > -1) {
-                for (int j = 0; j < d; ++j) cent[merge_with][j] = 0.5 * (cent[merge_with][j] + mean[j]);
+                double* c = cent.data() + (size_t)merge_with * d;
+                for (int j = 0; j < d; ++j) c[j] = 0.5 * (c[j] + mean[j]);
                 std::vector<std::pair<int, int>> merged;
                 const auto& a = votes[merge_with];
                 size_t i = 0, k = 0;
@@ -1001,7 +1033,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                 }
                 votes[merge_with].swap(merged);
             } else {
-                cent.emplace_back(mean, mean + d);
+                cent.insert(cent.end(), mean, mean + d);
+                ++n_cent;
                 votes.push_back(mine);
             }
         }
@@ -1011,10 +1044,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     for (size_t r = 0; r < votes.size(); ++r)                       // :133-146, first maximum wins
         for (const auto& pr : votes[r])
             if (best_votes[pr.first] < pr.second) { best_votes[pr.first] = pr.second; assign[pr.first] = (int)r; }
-    *n_modes = (int)cent.size();
-    if (modes)
-        for (int c = 0; c < (int)cent.size() && c < max_modes; ++c)
-            for (int j = 0; j < d; ++j) modes[(size_t)c * d + j] = cent[c][j];
+    *n_modes = n_cent;
+    if (modes) std::copy(cent.begin(), cent.begin() + (size_t)std::min(n_cent, max_modes) * d, modes);
     return MH_OK;
     });
 }

@@ -14,6 +14,11 @@
 // depend on the device — and is mirrored by the oracle (mho_mean_shift), so modes and assignments
 // are bit-identical.  The seed order, vote merging and final assignment stay on the host (they are
 // sequential by definition, :52-56,:100-146).
+// MS_BATCH climbs run side by side (blockIdx.y = climb): their seeds are drawn together from the rows that are
+// unvisited when the batch starts, and the host applies the finished climbs in draw order, dropping a climb whose
+// seed an earlier climb of the same batch has visited meanwhile (the reference never starts from a visited row).
+// A climb depends only on the data and its seed, so the batch costs the host round trips of its longest climb
+// instead of the sum.  The batch size is part of the definition (the oracle draws the same way).
 #include "mh_kernels.hpp"
 
 namespace mh {
@@ -21,9 +26,23 @@ namespace mh {
 constexpr int MS_MAXD = 16;
 constexpr int MS_GROUPS = 64;            // workgroups per sweep; part of the numerical definition
 
-__global__ void __launch_bounds__(256)
-k_ms_partial(MeanShiftWork w, double band_sq)
+// the slice of climb b
+__device__ __forceinline__ MeanShiftWork ms_climb(const MeanShiftWork& a, int b)
 {
+    MeanShiftWork w = a;
+    w.mean = a.mean + (size_t)b * MS_MAXD;
+    w.votes = a.votes + (size_t)b * a.n;
+    w.out = a.out + (size_t)b * 4;
+    w.list = a.list + (size_t)b * 2 * a.n;
+    w.partial = a.partial + (size_t)b * MS_GROUPS * MS_MAXD;
+    w.partial_cnt = a.partial_cnt + (size_t)b * MS_GROUPS;
+    return w;
+}
+
+__global__ void __launch_bounds__(256)
+k_ms_partial(MeanShiftWork all, double band_sq)
+{
+    const MeanShiftWork w = ms_climb(all, blockIdx.y);
     if (w.out[1] || w.out[3]) return;                       // converged or dead end: rest of the batch idles
     const int t = threadIdx.x;
     const int D = w.d;
@@ -59,8 +78,9 @@ k_ms_partial(MeanShiftWork w, double band_sq)
 }
 
 __global__ void __launch_bounds__(64)
-k_ms_update(MeanShiftWork w, double stop_thresh)
+k_ms_update(MeanShiftWork all, double stop_thresh)
 {
+    const MeanShiftWork w = ms_climb(all, blockIdx.x);
     if (w.out[1] || w.out[3]) return;
     const int j = threadIdx.x;
     const int D = w.d;
@@ -88,8 +108,9 @@ k_ms_update(MeanShiftWork w, double stop_thresh)
 
 // (index, votes) of every row touched by the climb (the host sorts the short list); clears the votes.
 __global__ void __launch_bounds__(256)
-k_ms_collect(MeanShiftWork w)
+k_ms_collect(MeanShiftWork all)
 {
+    const MeanShiftWork w = ms_climb(all, blockIdx.y);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w.n) return;
     const int v = w.votes[i];
@@ -101,9 +122,12 @@ k_ms_collect(MeanShiftWork w)
     }
 }
 
+// starts: the batch's seed rows (mapped pinned memory written by the host)
 __global__ void __launch_bounds__(64)
-k_ms_seed(MeanShiftWork w, int start)
+k_ms_seed(MeanShiftWork all, const int* __restrict__ starts)
 {
+    const MeanShiftWork w = ms_climb(all, blockIdx.x);
+    const int start = starts[blockIdx.x];
     const int j = threadIdx.x;
     if (j < w.d) w.mean[j] = w.data[(size_t)start * w.d + j];        // :58  myMean = data.row(stInd)
     if (j < 4) w.out[j] = 0;
@@ -111,8 +135,9 @@ k_ms_seed(MeanShiftWork w, int start)
 
 // k_ms_collect, run only once the climb has ended (converged or dead end)
 __global__ void __launch_bounds__(256)
-k_ms_collect_if_done(MeanShiftWork w)
+k_ms_collect_if_done(MeanShiftWork all)
 {
+    const MeanShiftWork w = ms_climb(all, blockIdx.y);
     if (!(w.out[1] || w.out[3])) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w.n) return;
@@ -126,41 +151,32 @@ k_ms_collect_if_done(MeanShiftWork w)
 }
 
 __global__ void __launch_bounds__(64)
-k_ms_publish(MeanShiftWork w, MeanShiftResultBlock* r)
+k_ms_publish(MeanShiftWork all, MeanShiftResultBlock* results)
 {
+    const MeanShiftWork w = ms_climb(all, blockIdx.x);
+    MeanShiftResultBlock* r = results + blockIdx.x;
     const int j = threadIdx.x;
     if (j < 4) r->out[j] = w.out[j];
     if (j < MS_MAXD) r->mean[j] = j < w.d ? w.mean[j] : 0.0;
 }
 
-hipError_t launch_ms_climb(const MeanShiftWork& w, int start, double band_sq, double stop_thresh, int iterations,
-                           MeanShiftResultBlock* result_dev, hipStream_t s)
+hipError_t launch_ms_climb(const MeanShiftWork& w, int climbs, const int* starts_dev, double band_sq, double stop_thresh,
+                           int iterations, MeanShiftResultBlock* result_dev, hipStream_t s)
 {
-    if (w.d > MS_MAXD) return hipErrorInvalidValue;
-    if (start >= 0) hipLaunchKernelGGL(k_ms_seed, dim3(1), dim3(64), 0, s, w, start);
+    if (w.d > MS_MAXD || climbs < 1) return hipErrorInvalidValue;
+    if (starts_dev) hipLaunchKernelGGL(k_ms_seed, dim3(climbs), dim3(64), 0, s, w, starts_dev);
     for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(k_ms_partial, dim3(MS_GROUPS), dim3(256), 0, s, w, band_sq);
-        hipLaunchKernelGGL(k_ms_update, dim3(1), dim3(64), 0, s, w, stop_thresh);
+        hipLaunchKernelGGL(k_ms_partial, dim3(MS_GROUPS, climbs), dim3(256), 0, s, w, band_sq);
+        hipLaunchKernelGGL(k_ms_update, dim3(climbs), dim3(64), 0, s, w, stop_thresh);
     }
-    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256), dim3(256), 0, s, w);
-    hipLaunchKernelGGL(k_ms_publish, dim3(1), dim3(64), 0, s, w, result_dev);
+    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, climbs), dim3(256), 0, s, w);
+    hipLaunchKernelGGL(k_ms_publish, dim3(climbs), dim3(64), 0, s, w, result_dev);
     return hipGetLastError();
 }
 
-hipError_t launch_ms_iterations(const MeanShiftWork& w, double band_sq, double stop_thresh, int iterations,
-                                hipStream_t s)
+hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s)
 {
-    if (w.d > MS_MAXD) return hipErrorInvalidValue;
-    for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(k_ms_partial, dim3(MS_GROUPS), dim3(256), 0, s, w, band_sq);
-        hipLaunchKernelGGL(k_ms_update, dim3(1), dim3(64), 0, s, w, stop_thresh);
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_ms_collect(const MeanShiftWork& w, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_ms_collect, dim3((w.n + 255) / 256), dim3(256), 0, s, w);
+    hipLaunchKernelGGL(k_ms_collect, dim3((w.n + 255) / 256, climbs), dim3(256), 0, s, w);
     return hipGetLastError();
 }
 

@@ -76,27 +76,26 @@ hipError_t launch_refine_points(const Points& p, const Affines& a, const double 
                                 double* out /* n x 8 */, hipStream_t s);
 
 // --- meanshift.hip ----------------------------------------------------------
-struct MeanShiftWork {
+constexpr int MS_BATCH = 64;   // climbs per batch: part of the definition of the seed order (meanshift.hip; the oracle draws alike)
+struct MeanShiftWork {      // every per-climb array holds MS_BATCH slices
     const double* data;      // n x d row-major
     int n, d;
-    double* mean;            // d   current mean (in/out)
-    int* votes;              // n   votes of the running climb (members get +1 per iteration)
-    int* out;                // [0] iterations, [1] converged, [2] list length, [3] dead end (no member)
-    int* list;               // 2*n (index, votes) pairs compacted by launch_ms_collect
-    double* partial;         // MS_GROUPS x 16 member sums of the running iteration
-    int* partial_cnt;        // MS_GROUPS
+    double* mean;            // [climb] 16      current mean (in/out)
+    int* votes;              // [climb] n       votes of the running climb (members get +1 per iteration)
+    int* out;                // [climb] 4       [0] iterations, [1] converged, [2] list length, [3] dead end (no member)
+    int* list;               // [climb] 2*n     (index, votes) pairs compacted when the climb has ended
+    double* partial;         // [climb] MS_GROUPS x 16 member sums of the running iteration
+    int* partial_cnt;        // [climb] MS_GROUPS
 };
-// `iterations` climb iterations (two launches each, no host round trip); iterations after
-// convergence are no-ops.  launch_ms_collect compacts and clears the votes.
-hipError_t launch_ms_iterations(const MeanShiftWork& w, double band_sq, double stop_thresh, int iterations,
-                                hipStream_t s);
-hipError_t launch_ms_collect(const MeanShiftWork& w, hipStream_t s);
-// One climb without host round trips in between: seed the mean with row `start`, `iterations` climb
-// iterations, then — only if the climb has ended — compact the votes; finally the control words and
-// the mean are written to `result` (device address of a mapped pinned block: int out[4], double mean[16]).
 struct MeanShiftResultBlock { int out[4]; double mean[16]; };
-hipError_t launch_ms_climb(const MeanShiftWork& w, int start /* -1: continue the running climb */, double band_sq,
-                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, hipStream_t s);
+// `climbs` climbs side by side without host round trips in between: seed the means with the rows starts_dev[0..climbs)
+// (null: continue the running climbs), `iterations` climb iterations (no-ops for a climb that has ended), compact the
+// votes of the climbs that have ended, then publish every climb's control words and mean to result_dev[climb]
+// (device address of a mapped pinned array).
+hipError_t launch_ms_climb(const MeanShiftWork& w, int climbs, const int* starts_dev, double band_sq, double stop_thresh,
+                           int iterations, MeanShiftResultBlock* result_dev, hipStream_t s);
+// compacts and clears the votes of all `climbs` climbs, ended or not
+hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s);
 
 // --- expand.hip -------------------------------------------------------------
 struct Graph {              // symmetric weighted CSR in HBM

@@ -919,6 +919,7 @@ MHO_API void mho_haf_point(const double* x1, const double* y1, const double* x2,
 // MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157) with the engine's counter RNG
 // and the engine's summation order for the member sums (strided tree), so that the GPU climbs can be
 // compared bit for bit.  Returns the number of modes; modes (k x d), assign (n).
+static const int MHO_MS_BATCH = 64;   // climbs whose seeds are drawn together (the engine's MS_BATCH)
 MHO_API int mho_mean_shift(const double* data, int n, int d, double bw, unsigned long long seed,
                            double* modes, int max_modes, int* assign)
 {
@@ -934,50 +935,61 @@ MHO_API int mho_mean_shift(const double* data, int n, int d, double bw, unsigned
         return sqrt(s);
     };
     while (!init.empty()) {
-        const double rnd = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
-        const int st = init[(int)round(rnd * (double)(init.size() - 1))];
-        std::vector<double> mean(data + (size_t)st * d, data + (size_t)(st + 1) * d);
-        std::vector<int> my(n, 0);
-        bool converged = false;
-        for (int it = 0; it < 100000; ++it) {
-            const std::vector<double> old = mean;
-            // engine order: 64 groups x 256 strided lanes (row i -> lane i % 16384), binary tree
-            // inside each group, groups added in sequence
-            const int G = 64;
-            std::vector<TreeAcc> acc(G, TreeAcc(d));
-            int in = 0;
-            for (int i = 0; i < n; ++i) {
-                double dist = 0.0;
-                for (int j = 0; j < d; ++j) { const double r = old[j] - data[(size_t)i * d + j]; dist += sqrt(r * r); }
-                if (dist < band_sq) {
-                    const int lane = i % (G * MHO_W);
-                    acc[lane / MHO_W].add(lane % MHO_W, data + (size_t)i * d);
-                    ++in; ++my[i]; visited[i] = 1;
-                }
-            }
-            if (in == 0) break;
-            std::vector<double> sum(d, 0.0), part(d);
-            for (int b = 0; b < G; ++b) {
-                acc[b].finish(part.data());
-                for (int j = 0; j < d; ++j) sum[j] = sum[j] + part[j];
-            }
-            const double inv = 1.0 / (double)in;
-            double move = 0.0;
-            for (int j = 0; j < d; ++j) { mean[j] = sum[j] * inv; const double dd = mean[j] - old[j]; move = move + dd * dd; }
-            if (sqrt(move) < stop) { converged = true; break; }
+        // the engine's seed rule: MHO_MS_BATCH seeds are drawn together from the rows unvisited now (:55-56 for each draw)
+        // and climbed in draw order; a seed that an earlier climb of the batch has visited is dropped, as the reference
+        // never starts from a visited row.  (Section 11's mean_shift_reference_order redraws after every climb.)
+        const int climbs = (int)std::min<size_t>(MHO_MS_BATCH, init.size());
+        std::vector<int> starts(climbs);
+        for (int b = 0; b < climbs; ++b) {
+            const double rnd = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
+            starts[b] = init[(int)round(rnd * (double)(init.size() - 1))];
         }
-        if (!converged) {
-            visited[st] = 1;
-        } else {
-            int mw = -1;
-            for (size_t cn = 0; cn < cent.size(); ++cn)
-                if (l2(mean.data(), cent[cn].data(), d) < bw / 2) { mw = (int)cn; break; }
-            if (mw > -1) {
-                for (int j = 0; j < d; ++j) cent[mw][j] = 0.5 * (cent[mw][j] + mean[j]);
-                for (int i = 0; i < n; ++i) votes[mw][i] += my[i];
+        for (int b = 0; b < climbs; ++b) {
+            const int st = starts[b];
+            if (visited[st]) continue;
+            std::vector<double> mean(data + (size_t)st * d, data + (size_t)(st + 1) * d);
+            std::vector<int> my(n, 0);
+            bool converged = false;
+            for (int it = 0; it < 100000; ++it) {
+                const std::vector<double> old = mean;
+                // engine order: 64 groups x 256 strided lanes (row i -> lane i % 16384), binary tree
+                // inside each group, groups added in sequence
+                const int G = 64;
+                std::vector<TreeAcc> acc(G, TreeAcc(d));
+                int in = 0;
+                for (int i = 0; i < n; ++i) {
+                    double dist = 0.0;
+                    for (int j = 0; j < d; ++j) { const double r = old[j] - data[(size_t)i * d + j]; dist += sqrt(r * r); }
+                    if (dist < band_sq) {
+                        const int lane = i % (G * MHO_W);
+                        acc[lane / MHO_W].add(lane % MHO_W, data + (size_t)i * d);
+                        ++in; ++my[i]; visited[i] = 1;
+                    }
+                }
+                if (in == 0) break;
+                std::vector<double> sum(d, 0.0), part(d);
+                for (int g = 0; g < G; ++g) {
+                    acc[g].finish(part.data());
+                    for (int j = 0; j < d; ++j) sum[j] = sum[j] + part[j];
+                }
+                const double inv = 1.0 / (double)in;
+                double move = 0.0;
+                for (int j = 0; j < d; ++j) { mean[j] = sum[j] * inv; const double dd = mean[j] - old[j]; move = move + dd * dd; }
+                if (sqrt(move) < stop) { converged = true; break; }
+            }
+            if (!converged) {
+                visited[st] = 1;
             } else {
-                cent.push_back(mean);
-                votes.push_back(my);
+                int mw = -1;
+                for (size_t cn = 0; cn < cent.size(); ++cn)
+                    if (l2(mean.data(), cent[cn].data(), d) < bw / 2) { mw = (int)cn; break; }
+                if (mw > -1) {
+                    for (int j = 0; j < d; ++j) cent[mw][j] = 0.5 * (cent[mw][j] + mean[j]);
+                    for (int i = 0; i < n; ++i) votes[mw][i] += my[i];
+                } else {
+                    cent.push_back(mean);
+                    votes.push_back(my);
+                }
             }
         }
         init.clear();

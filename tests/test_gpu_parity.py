@@ -238,6 +238,29 @@ def test_expand_solver_paths(engine, synth, oracle, case):
     assert st["host_syncs"] <= st["cycles"] + 2
 
 
+def test_expand_trace_agrees_with_the_counters(engine, synth):
+    """mh_get_expand_trace (diagnostic): one row per move, zero for skipped moves and empty cores; its sums are the
+    expansion's counters."""
+    sc = synth.make_scene(4000, 4, seed=3)
+    _load(engine, sc)
+    engine.set_models(_models(sc, np.random.default_rng(3), extra=2))
+    engine.data_cost(fetch=False)
+    try:
+        engine.set_tuning(8, 128)
+        engine.expand()
+        st = engine.expand_stats()
+        tr = engine.expand_trace(128)
+    finally:
+        engine.set_tuning(8, 0)
+    moves = st["moves"]
+    assert moves <= 128 and not tr[moves:].any()
+    solved = tr[:moves][tr[:moves, 0] > 0]
+    assert len(solved) == st["moves_solved"]
+    assert solved[:, 0].sum() == st["core_sites"] and solved[:, 0].max() == st["core_max"]
+    assert solved[:, 2].sum() == st["relabels"] and solved[:, 5].sum() == st["barriers"]
+    assert (solved[:, 7] <= solved[:, 6]).all()                # time inside barriers <= time inside the launch
+
+
 def test_expand_without_neighbours_is_argmin(engine, synth, oracle):
     sc = synth.make_scene(500, 3, seed=2, with_neighbours=False)
     _load(engine, sc, neighbours=False)
