@@ -101,7 +101,7 @@ struct mh_engine {
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
-    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_aux, ew_trace, d_order;
+    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_trace, ew_saved, d_order;
     int trace_moves = 0;                     // > 0: k_solve logs 8 ints per move (mh_set_tuning key 8)
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
@@ -123,6 +123,7 @@ struct mh_engine {
     int residual_mode = MH_RESIDUAL_FORWARD;
     int tune_ms_batch = 6;                   // mean-shift climb iterations per host round trip
     int tune_reduce = 4;                     // dominance-reduction rounds per launch (0 = off)
+    int tune_recycle = 1;                    // from the second cycle on a label's max-flow starts from the flow its last expansion left (0 = off, A/B)
     int tune_expand[4] = { 128, 256, 1, 256 };
     int tune_push_mult = 4;                  // push cycles per phase = this x (depth of the last relabel + 3)  // solver: relax rounds per barrier interval, push cycles per phase, push phases per relabel, workgroups
     ExpandStats last_expand{};
@@ -314,7 +315,6 @@ int ensure_expand_work(mh_engine* e)
     HIPCHK(e->ew_excess.reserve(n));
     HIPCHK(e->ew_sink.reserve(n));
     HIPCHK(e->ew_height.reserve(n));
-    HIPCHK(e->ew_aux.reserve(2 * (size_t)n));
     HIPCHK(e->ew_decided.reserve(n));
     HIPCHK(e->ew_flags.reserve(EXPAND_FLAG_WORDS));
     HIPCHK(e->ew_acc.reserve(EXPAND_ACC_WORDS));
@@ -355,10 +355,20 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     // the CUs, so that engines of other processes sharing the GPU can never starve each other's launches
     const int solve_grid = std::max(1, std::min(e->tune_expand[3], e->cu_count));
     ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_sent.p, e->ew_excess.p, e->ew_sink.p,
-                  e->ew_height.p, e->ew_aux.p, e->ew_decided.p, e->ew_took.p, e->ew_core.p, e->ew_flags.p, e->ew_acc.p,
+                  e->ew_height.p, e->ew_decided.p, e->ew_took.p, e->ew_core.p, e->ew_flags.p, e->ew_acc.p,
                   e->h_flags, e->h_acc, e->h_flags_dev, e->h_acc_dev,
                   e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], solve_grid, e->tune_push_mult, e->tune_reduce,
-                  nullptr, 0, -1 };
+                  nullptr, 0, -1, nullptr, nullptr };
+    // flow recycling (expand.hip, k_solve): L x (nnz + n) ints, cleared per expansion; left out (every move starts from
+    // the zero flow) beyond 8 GiB.  Flows are not kept from one call to the next: measured in the alternation, the
+    // re-estimated models move the problems far enough for a kept flow to cost more rounds than the zero flow.
+    const size_t recycle_words = (size_t)e->cost_L * ((size_t)g.nnz + (size_t)g.n);
+    if (e->tune_recycle && recycle_words <= ((size_t)2 << 30)) {
+        HIPCHK(e->ew_saved.reserve(recycle_words));
+        HIPCHK(hipMemsetAsync(e->ew_saved.p, 0, sizeof(int) * recycle_words, e->stream));
+        w.saved_flow = e->ew_saved.p;
+        w.saved_sink = e->ew_saved.p + (size_t)e->cost_L * g.nnz;
+    }
     if (e->trace_moves > 0) {
         HIPCHK(e->ew_trace.reserve(8 * (size_t)e->trace_moves + 4 * 2048));
         HIPCHK(hipMemsetAsync(e->ew_trace.p, 0, sizeof(int) * (8 * (size_t)e->trace_moves + 4 * 2048), e->stream));
@@ -372,6 +382,8 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         ScopedTimer t(e, MH_K_EXPAND);
         HIPCHK(launch_init_labeling(e->cost.p, e->cost_L, e->n, init_dev, w.label, w.cur_cost, e->stream));
         hipError_t he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
+        if (he == hipErrorOutOfMemory)
+            return fail(MH_ERR_INVALID, "alpha-expansion: more sites than the solver's per-row state holds (about 1.3 million at 256 workgroups)");
         if (he == hipErrorInvalidValue && st.energy == -1)
             return fail(MH_ERR_OVERFLOW, "int32 energy term overflow in alpha-expansion");
         if (he == hipErrorLaunchTimeOut && st.energy == -2)
@@ -493,7 +505,7 @@ void mh_destroy(mh_engine* e)
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
-    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_aux.release(); e->ew_trace.release(); e->d_order.release();
+    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release();
     e->knn_tmp.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     if (e->h_ms) (void)hipHostFree(e->h_ms);
@@ -1572,6 +1584,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 8 && value >= 0 && value <= (1 << 20)) { e->trace_moves = value; return MH_OK; }
     if (key == 9 && value >= -1) { e->detail_move = value; return MH_OK; }
     if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }
+    if (key == 11 && (value == 0 || value == 1)) { e->tune_recycle = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

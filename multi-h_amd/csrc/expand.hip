@@ -57,6 +57,8 @@
 
 #include "mh_kernels.hpp"
 
+#include <algorithm>
+
 namespace mh {
 
 // control words (int); the first EXPAND_HOST_WORDS are mirrored to the host
@@ -480,48 +482,57 @@ __device__ __forceinline__ bool grid_sync(GridBarrier& b, bool c_changed, bool c
     return b.s_red[6] == 0;
 }
 
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, int* aux, int* height, int* decided,
-        const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
-        SolveParams sp)
+// per-site state of the rows' sites, in LDS: [field][slot][row of the workgroup]
+enum { F_SITE = 0, F_HPROP, F_SPENT, F_SC, F_HU, F_SINK0, F_FIELDS };
+
+// The solver proper.  MULTI = false: the core fits the launch one site per row — the site stays in registers for the
+// whole move and nothing below touches LDS.  MULTI = true: rows own several sites (see `cur` below).
+template <bool MULTI>
+__device__ __forceinline__ void
+solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_cap, int* height, int* decided,
+           const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
+           int* __restrict__ saved_flow, int* __restrict__ saved_sink, int warm, int mslots, const SolveParams& sp,
+           int* s_priv, int* s_red, const int (&pre)[EXPAND_CORE_SHARDS + 1], int K, int P)
 {
-    __shared__ int s_red[8];
-    __shared__ int s_skip;
-    if (threadIdx.x == 0) s_skip = move_is_skipped(flags, t, L) ? 1 : 0;
-    __syncthreads();
-    if (s_skip) return;
-    if (g.n >= H_MASK) { if (threadIdx.x == 0) atomicExch(&flags[C_ERROR], ERR_OVERFLOW); return; }   // heights carry 24 bits
-    int pre[EXPAND_CORE_SHARDS + 1];
-    pre[0] = 0;
-#pragma unroll
-    for (int s = 0; s < EXPAND_CORE_SHARDS; ++s) pre[s + 1] = pre[s] + flags[C_CORE + s];
-    const int K = pre[EXPAND_CORE_SHARDS];
-    if (K == 0) return;
-    int P = (K + SOLVE_ROWS - 1) / SOLVE_ROWS;
-    if (P > (int)gridDim.x) P = (int)gridDim.x;
-    if ((int)blockIdx.x >= P) return;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
     const int total_rows = P * SOLVE_ROWS;
-    const int row = blockIdx.x * SOLVE_ROWS + threadIdx.x / SLPN;
+    const int lr = threadIdx.x / SLPN;               // my row inside the workgroup
+    const int row = blockIdx.x * SOLVE_ROWS + lr;
     const int sub = threadIdx.x % SLPN;
-    const bool single = K <= total_rows;             // one site per row: its state lives in registers
+    // A row owns the core sites row, row + total_rows, ...: S of them ("slots"; one when the core fits the launch).
+    const int S = row < K ? (MULTI ? (K - row + total_rows - 1) / total_rows : 1) : 0;
+    if ((K + total_rows - 1) / total_rows > mslots) {            // (the host sizes mslots for a core of all n sites)
+        if (threadIdx.x == 0) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+        return;
+    }
     const int INF = K + 1;                           // no residual path in the core is longer than K
-    int* spent_mem = aux;                            // per-site state of rows that walk several sites
-    int* hprop_mem = aux + g.n;
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
     GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull };
     long long st_outer = 0, st_relax = 0, st_push = 0;
     unsigned long long tk_relax = 0, tk_push = 0;
+#define PRIV(field, slot) s_priv[((field) * mslots + (slot)) * SOLVE_ROWS + lr]
+#define CUR(slot) (!MULTI || (slot) == cur)
 
-    // the row's site (re-loaded at every visit unless `single`)
-    int u = -1, k0 = 0, k1 = 0, dec = 3, hu = 0, sc = 0, spent = 0, hprop = 0;
-    bool fast = false;
+    // ONE site at a time lives in registers (`cur` = its slot): head, then on demand neighbours, arc state and the
+    // relabel mask, plus the site's scalars.  The scalars of the other slots wait in LDS; all lanes of a row hold
+    // identical copies and write identical values.  Sites are polled through ONE word (height or excess) and
+    // entered only when that word says there is something to do, so a row with several sites costs one load per
+    // site and round like a row with one.  (The first version of the several-sites case reloaded every site at
+    // every visit and gave every BFS level a grid barrier of its own: 203 ms for one 18 313-site move.)
+    int cur = -1, u = -1, k0 = 0, k1 = 0, dec = 3;
+    int hu = 0, sc = 0, spent = 0, hprop = 0, sink0 = 0;
+    bool fast = false, nb_ok = false, arcs_ok = false, rin_ok = false, priv_live = false;
     int nb[SSLOTS], rv[SSLOTS], c0[SSLOTS], so[SSLOTS];
     unsigned rin = 0;                                // bit q: the arc nb[q] -> u is residual (relabel direction)
 
-    auto load_site = [&](int c) {
+    auto enter = [&](int slot) {
+        if (cur == slot) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the counters I stored for the site I leave are read back when I return
+        if (cur >= 0 && priv_live) { PRIV(F_HPROP, cur) = hprop; PRIV(F_SPENT, cur) = spent; PRIV(F_SC, cur) = sc; PRIV(F_HU, cur) = hu; }
+        cur = slot;
+        const int c = row + slot * total_rows;
         int s = 0, first = 0;
 #pragma unroll
         for (int q = 1; q < EXPAND_CORE_SHARDS; ++q) if (c >= pre[q]) { s = q; first = pre[q]; }
@@ -529,6 +540,12 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
         k0 = g.rowptr[u];
         k1 = g.rowptr[u + 1];
         fast = (k1 - k0) <= SLPN * SSLOTS;
+        dec = LD(&decided[u]);
+        nb_ok = arcs_ok = rin_ok = false;
+        if (priv_live) { hprop = PRIV(F_HPROP, slot); spent = PRIV(F_SPENT, slot); sc = PRIV(F_SC, slot); hu = PRIV(F_HU, slot); sink0 = PRIV(F_SINK0, slot); }
+    };
+    auto need_nbrs = [&]() {
+        if (nb_ok) return;
 #pragma unroll
         for (int q = 0; q < SSLOTS; ++q) {
             const int k = k0 + sub + q * SLPN;
@@ -537,45 +554,55 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
             rv[q] = in ? g.rev[k] : 0;
             c0[q] = 0; so[q] = 0;
         }
-        dec = LD(&decided[u]);
+        nb_ok = true;
     };
     // capacities (final once the reduction has reached its fixed point) and the row's own counters; arcs
     // without capacity in either direction (decided neighbours) drop out
-    auto load_arcs = [&]() {
-        if (!fast) return;
+    auto need_arcs = [&]() {
+        need_nbrs();
+        if (arcs_ok) return;
+        if (fast) {
 #pragma unroll
-        for (int q = 0; q < SSLOTS; ++q) {
-            if (nb[q] >= 0) {
-                const int k = k0 + sub + q * SLPN;
-                c0[q] = LD(&cap[k]);
-                so[q] = LD(&sent[k]);
-                if ((c0[q] | LD(&cap[rv[q]])) == 0) nb[q] = -1;
+            for (int q = 0; q < SSLOTS; ++q) {
+                if (nb[q] >= 0) {
+                    const int k = k0 + sub + q * SLPN;
+                    c0[q] = LD(&cap[k]);
+                    so[q] = LD(&sent[k]);
+                    if ((c0[q] | LD(&cap[rv[q]])) == 0) nb[q] = -1;
+                }
             }
         }
+        arcs_ok = true;
     };
-    auto load_rin = [&]() {                          // arcs residual TOWARDS me, constant between two push phases
+    auto need_rin = [&]() {                          // arcs residual TOWARDS me, constant between two push phases
+        need_arcs();
+        if (rin_ok) return;
         rin = 0;
-        if (!fast) return;
+        if (fast) {
 #pragma unroll
-        for (int q = 0; q < SSLOTS; ++q)
-            if (nb[q] >= 0 && LD(&cap[rv[q]]) - LD(&sent[rv[q]]) + so[q] > 0) rin |= 1u << q;
+            for (int q = 0; q < SSLOTS; ++q)
+                if (nb[q] >= 0 && LD(&cap[rv[q]]) - LD(&sent[rv[q]]) + so[q] > 0) rin |= 1u << q;
+        }
+        rin_ok = true;
     };
-#define FOR_MY_SITES(c) for (int c = row; c < K; c += total_rows)
-#define VISIT(c) do { if (!single || u < 0) load_site(c); } while (0)
+#define FOR_MY_SLOTS(slot) for (int slot = 0; slot < S; ++slot)
+    int site0 = -1;                                  // PRIV(F_SITE, 0): the undecided site of slot 0, or -1
+#define SITE_OF(slot) ((!MULTI || (slot) == 0) ? site0 : PRIV(F_SITE, slot))
 
     // my arcs' flow counters start at zero (visible to everybody behind the barriers of phase 0)
-    FOR_MY_SITES(c) {
-        VISIT(c);
-        for (int k = k0 + sub; k < k1; k += SLPN) ST(&sent[k], 0);
-        if (sub == 0) { ST(&spent_mem[u], 0); ST(&height[u], 0x7fffffff); }      // a word of no epoch
+    FOR_MY_SLOTS(slot) {
+        enter(slot);
+        if (!warm) for (int k = k0 + sub; k < k1; k += SLPN) ST(&sent[k], 0);
+        if (sub == 0) ST(&height[u], 0x7fffffff);     // a word of no epoch
     }
     if (!grid_sync_first(bar)) return;
 
     // ---- phase 0: the reduction cascade to its fixed point (k_reduce's body on the core) -------------
     for (;;) {
         bool changed = false;
-        FOR_MY_SITES(c) {
-            VISIT(c);
+        FOR_MY_SLOTS(slot) {
+            enter(slot);
+            if (MULTI) dec = LD(&decided[u]);          // (a row with one site keeps its verdict in the register)
             if (dec != 0) continue;
             long long net = (long long)LD(&excess[u]) - LD(&sink_cap[u]);
             bool dirty = false;
@@ -611,13 +638,72 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
         if (!grid_sync(bar, changed && sub == 0, false, 0, any, nact, hm)) return;
         if (!any || sp.reduce_rounds <= 0) break;
     }
-    if (single) {
-        FOR_MY_SITES(c) {
+
+    // ---- flow recycling: start from what the previous expansion on this label left in the arcs ----------
+    // saved_flow[k] = net flow the arc carried when that move ended, saved_sink[u] = what u drained into the sink.
+    // Clipped to this move's capacities they are a feasible pseudo-flow: every arc counter lies in [0, cap], so
+    // cap - sent + sent[rev] stays within the pair's total.  A site left owing flow (it sends on more than it owns)
+    // gets the missing amount as source supply AND as sink capacity — the same constant on both t-links changes the
+    // value of every cut alike (Kohli & Torr's reparametrisation) — so excess is never negative.  A maximum flow
+    // from any feasible start has the same residual reachability, so the read-out (hence every label) is unchanged;
+    // only the number of relabel/push rounds is, as later cycles re-solve almost the same problem.
+    if (warm) {
+        FOR_MY_SLOTS(slot) {
+            enter(slot);
+            if (MULTI) dec = LD(&decided[u]);
             if (dec != 0) continue;
-            load_arcs();
-            sc = LD(&sink_cap[u]);
+            for (int k = k0 + sub; k < k1; k += SLPN) {
+                const int f = saved_flow[k], ck = LD(&cap[k]);
+                ST(&sent[k], f < ck ? f : ck);
+            }
+        }
+        int a0, a1, a2;
+        if (!grid_sync(bar, false, false, 0, a0, a1, a2)) return;
+    }
+    FOR_MY_SLOTS(slot) {
+        enter(slot);
+        if (MULTI) { dec = LD(&decided[u]); PRIV(F_SITE, slot) = dec == 0 ? u : -1; }
+        else site0 = dec == 0 ? u : -1;
+        if (dec != 0) continue;
+        int sc_s = LD(&sink_cap[u]), spent_s = 0, sink0_s = sc_s;
+        if (warm) {
+            long long net = 0;                            // what my arcs carry away, net
+            for (int k = k0 + sub; k < k1; k += SLPN) {
+                const int kr = g.rev[k];
+                if ((LD(&cap[k]) | LD(&cap[kr])) == 0) continue;      // decided neighbour: folded, and its counter is not maintained
+                net += (long long)LD(&sent[k]) - LD(&sent[kr]);
+            }
+            net = row_sum64<SLPN>(net);
+            const int sv = saved_sink[u];
+            const int sf = sv < sc_s ? sv : sc_s;
+            sc_s -= sf;
+            long long own = (long long)sf + net;
+            const long long e = (long long)LD(&excess[u]) - own;
+            if (e < 0) {
+                own += e;
+                const long long s2 = (long long)sc_s - e;
+                if (s2 > (1 << 30)) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                sc_s = (int)s2;
+            }
+            spent_s = (int)own;
+            sink0_s = sc_s + sf;
+            if (sub == 0) ST(&sink_cap[u], sc_s);
+        }
+        if (MULTI) {
+            PRIV(F_SC, slot) = sc_s; PRIV(F_SPENT, slot) = spent_s; PRIV(F_SINK0, slot) = sink0_s;
+            PRIV(F_HPROP, slot) = INF; PRIV(F_HU, slot) = INF;
+        } else {
+            sc = sc_s; spent = spent_s; sink0 = sink0_s; hprop = INF; hu = INF;
         }
     }
+    // from here on the scalars of the site in registers are live (written back when the row turns to another site)
+    if (MULTI) {
+        site0 = S > 0 ? PRIV(F_SITE, 0) : -1;
+        if (cur >= 0) { hprop = PRIV(F_HPROP, cur); spent = PRIV(F_SPENT, cur); sc = PRIV(F_SC, cur); hu = PRIV(F_HU, cur); sink0 = PRIV(F_SINK0, cur); }
+        priv_live = true;
+    }
+    arcs_ok = rin_ok = false;
+    if (!MULTI && site0 >= 0) need_arcs();
 
     // ---- phase 1: global relabel <-> push until no site with excess can reach the sink ---------------
     int outer = 0, epoch = 0, hprev = 4;
@@ -632,22 +718,22 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
         if (++epoch > H_EPOCHS) {                      // out of epochs (never seen): start over behind two barriers
             int a0, a1, a2;
             if (!grid_sync(bar, false, false, 0, a0, a1, a2)) return;
-            FOR_MY_SITES(c) { VISIT(c); if (dec == 0 && sub == 0) ST(&height[u], 0x7fffffff); }
+            FOR_MY_SLOTS(slot) { const int us = SITE_OF(slot); if (us >= 0 && sub == 0) ST(&height[us], 0x7fffffff); }
             if (!grid_sync(bar, false, false, 0, a0, a1, a2)) return;
             epoch = 1;
         }
         const int ebits = (H_EPOCHS - epoch) << H_SHIFT;
-        FOR_MY_SITES(c) {
-            VISIT(c);
-            if (dec != 0) continue;
-            if (!single) sc = LD(&sink_cap[u]);
-            if (sub == 0) {
-                if (sc > 0) atomicMin(&height[u], ebits | 1);
-                if (!single) ST(&hprop_mem[u], INF);
-            }
-            hprop = INF;                              // nothing told to the neighbours yet
-            if (single) load_rin();
+        rin_ok = false;                                // the pushes since the last relabel moved the residual capacities
+        FOR_MY_SLOTS(slot) {
+            const int us = SITE_OF(slot);
+            if (us < 0) continue;
+            const int sc_s = CUR(slot) ? sc : PRIV(F_SC, slot);
+            if (sc_s > 0 && sub == 0) atomicMin(&height[us], ebits | 1);
+            if (CUR(slot)) hprop = INF; else PRIV(F_HPROP, slot) = INF;      // nothing told to the neighbours yet
         }
+        // the site in registers has its relabel mask ready before the frontier arrives (a mask computed on arrival
+        // puts a dozen dependent loads between hearing and telling: every BFS level took twice as long)
+        if (MULTI ? (cur >= 0 && SITE_OF(cur) >= 0) : (site0 >= 0)) need_rin();
         int any, nact, hmax;
         // (the frontier advances one level per round: a few rounds more than the last relabel was deep)
         int relax_rounds = hprev + 12;
@@ -660,33 +746,41 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
             ++st_relax;
             bool spoke = false, active = false;
             int my_h = 0;
-            FOR_MY_SITES(c) {
-                VISIT(c);
-                if (dec != 0) continue;
-                if (!single) { load_arcs(); load_rin(); hprop = LD(&hprop_mem[u]); spent = LD(&spent_mem[u]); }
-                const int rounds = single ? relax_rounds : 1;
-                for (int r = 0; r < rounds; ++r) {
-                    const int w = LD(&height[u]);
-                    hu = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
-                    if (hu < hprop) {
+            for (int r = 0; r < relax_rounds; ++r) {
+                bool settled = true;                  // every site of mine next to the sink and announced: final
+                FOR_MY_SLOTS(slot) {
+                    const int us = SITE_OF(slot);
+                    if (us < 0) continue;
+                    const int w = LD(&height[us]);
+                    const int h = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
+                    const int hp = CUR(slot) ? hprop : PRIV(F_HPROP, slot);
+                    if (h < hp) {
+                        if (MULTI) { enter(slot); need_rin(); }
                         if (fast) {
 #pragma unroll
                             for (int q = 0; q < SSLOTS; ++q)
-                                if (rin & (1u << q)) atomicMin(&height[nb[q]], ebits | (hu + 1));
+                                if (rin & (1u << q)) atomicMin(&height[nb[q]], ebits | (h + 1));
                         } else {
                             for (int k = k0 + sub; k < k1; k += SLPN) {
                                 const int kr = g.rev[k];
-                                if (LD(&cap[kr]) - LD(&sent[kr]) + LD(&sent[k]) > 0) atomicMin(&height[g.col[k]], ebits | (hu + 1));
+                                if (LD(&cap[kr]) - LD(&sent[kr]) + LD(&sent[k]) > 0) atomicMin(&height[g.col[k]], ebits | (h + 1));
                             }
                         }
-                        hprop = hu;
+                        hprop = h;
                         spoke = true;
-                    } else if (hu <= 1) break;        // next to the sink and announced: final
+                        settled = false;
+                    } else if (h > 1) settled = false;
+                    if (CUR(slot)) hu = h; else PRIV(F_HU, slot) = h;
                 }
-                if (!single && sub == 0) ST(&hprop_mem[u], hprop);
-                if (hu < INF) {
-                    if (hu > my_h) my_h = hu;
-                    if (sub == 0 && LD(&excess[u]) - spent > 0) active = true;
+                if (settled) break;
+            }
+            FOR_MY_SLOTS(slot) {
+                const int us = SITE_OF(slot);
+                if (us < 0) continue;
+                const int h = CUR(slot) ? hu : PRIV(F_HU, slot);
+                if (h < INF) {
+                    if (h > my_h) my_h = h;
+                    if (sub == 0 && LD(&excess[us]) - (CUR(slot) ? spent : PRIV(F_SPENT, slot)) > 0) active = true;
                 }
             }
             if (!grid_sync(bar, spoke, active, my_h, any, nact, hmax)) return;
@@ -711,25 +805,31 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
         for (int phase = 0; phase < sp.push_phases; ++phase) {
             ++st_push;
             bool active = false;
-            FOR_MY_SITES(c) {
-                VISIT(c);
-                if (dec != 0) continue;
-                {                                     // my word as the last announcements left it
-                    const int w = LD(&height[u]);
-                    hu = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
-                }
-                if (!single) { sc = LD(&sink_cap[u]); spent = LD(&spent_mem[u]); load_arcs(); }
-                for (int cyc = 0; cyc < cycles; ++cyc) {
-                    if (hu >= INF) break;
-                    const int x = LD(&excess[u]);
+            FOR_MY_SLOTS(slot) {                      // my words as the last announcements left them
+                const int us = SITE_OF(slot);
+                if (us < 0) continue;
+                const int w = LD(&height[us]);
+                const int h = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
+                if (CUR(slot)) hu = h; else PRIV(F_HU, slot) = h;
+            }
+            for (int cyc = 0; cyc < cycles; ++cyc) {
+                bool alive = false;                   // somebody of mine can still reach the sink
+                FOR_MY_SLOTS(slot) {
+                    const int us = SITE_OF(slot);
+                    if (us < 0) continue;
+                    if ((CUR(slot) ? hu : PRIV(F_HU, slot)) >= INF) continue;
+                    alive = true;
+                    const int x = LD(&excess[us]);
                     if (x > (1 << 30)) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                    if (x - (CUR(slot) ? spent : PRIV(F_SPENT, slot)) <= 0) continue;      // idle: poll again
+                    if (MULTI) { enter(slot); need_arcs(); }
                     int e = x - spent;
-                    if (e > 0 && sc > 0) {                          // t-link: h(t) = 0, h(u) >= 1
+                    if (sc > 0) {                                   // t-link: h(t) = 0, h(u) >= 1
                         const int d = e < sc ? e : sc;
                         sc -= d; spent += d; e -= d;
                         if (sub == 0) ST(&sink_cap[u], sc);
                     }
-                    if (e <= 0) continue;                           // idle: poll again
+                    if (e <= 0) continue;
                     if (fast) {
                         int r[SSLOTS], hq[SSLOTS];
 #pragma unroll
@@ -787,7 +887,7 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
                         if (key == 0x7fffffffffffffffll) {          // no way out at all
                             hu = INF;
                             if (sub == 0) ST(&height[u], ebits | hu);
-                            break;
+                            continue;
                         }
                         const int hmin = (int)(key >> 32), kmin = (int)(key & 0xffffffffll);
                         if (hu > hmin) {
@@ -808,8 +908,13 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
                         }
                     }
                 }
-                if (!single && sub == 0) ST(&spent_mem[u], spent);
-                if (sub == 0 && hu < INF && LD(&excess[u]) - spent > 0) active = true;
+                if (!alive) break;
+            }
+            FOR_MY_SLOTS(slot) {
+                const int us = SITE_OF(slot);
+                if (us < 0) continue;
+                if (sub == 0 && (CUR(slot) ? hu : PRIV(F_HU, slot)) < INF &&
+                    LD(&excess[us]) - (CUR(slot) ? spent : PRIV(F_SPENT, slot)) > 0) active = true;
             }
             // this barrier also separates the pushes from the next relabel (the counters are final behind it)
             if (!grid_sync(bar, false, active, 0, any, nact, hmax)) return;
@@ -819,17 +924,26 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
     }
 
     // ---- read-out: whoever cannot reach the sink takes alpha ---------------------------------------
-    FOR_MY_SITES(c) {
-        VISIT(c);
-        if (dec != 0) continue;
-        if (!single) {
-            const int w = LD(&height[u]);
-            hu = (w >> H_SHIFT) == ((H_EPOCHS - epoch) & 0x7f) ? (w & H_MASK) : INF;
+    FOR_MY_SLOTS(slot) {
+        const int us = SITE_OF(slot);
+        if (us < 0) continue;
+        const int h = CUR(slot) ? hu : PRIV(F_HU, slot);
+        if (sub == 0) ST(&decided[us], h >= INF ? 1 : 2);
+        if (saved_flow) {                                 // for the next expansion on this label (the counters are final)
+            enter(slot);
+            for (int k = k0 + sub; k < k1; k += SLPN) {
+                const int kr = g.rev[k];
+                int f = 0;
+                if ((LD(&cap[k]) | LD(&cap[kr])) != 0) f = LD(&sent[k]) - LD(&sent[kr]);
+                saved_flow[k] = f > 0 ? f : 0;
+            }
+            if (sub == 0) saved_sink[u] = sink0 - sc;
         }
-        if (sub == 0) ST(&decided[u], hu >= INF ? 1 : 2);
     }
-#undef FOR_MY_SITES
-#undef VISIT
+#undef FOR_MY_SLOTS
+#undef SITE_OF
+#undef CUR
+#undef PRIV
     if (leader) {
         atomicAdd(&flags[C_MOVES_SOLVED], 1);
         atomicMax(&flags[C_CORE_MAX], K);
@@ -849,6 +963,33 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
             tr[6] = (int)(__builtin_amdgcn_s_memrealtime() - tick0); tr[7] = (int)bar.ticks;
         }
     }
+}
+
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, int* height, int* decided,
+        const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
+        int* __restrict__ saved_flow, int* __restrict__ saved_sink, int warm, int mslots, SolveParams sp)
+{
+    extern __shared__ int s_priv[];                  // F_FIELDS x mslots x SOLVE_ROWS
+    __shared__ int s_red[8];
+    __shared__ int s_skip;
+    if (threadIdx.x == 0) s_skip = move_is_skipped(flags, t, L) ? 1 : 0;
+    __syncthreads();
+    if (s_skip) return;
+    if (g.n >= H_MASK) { if (threadIdx.x == 0) atomicExch(&flags[C_ERROR], ERR_OVERFLOW); return; }   // heights carry 24 bits
+    int pre[EXPAND_CORE_SHARDS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int s = 0; s < EXPAND_CORE_SHARDS; ++s) pre[s + 1] = pre[s] + flags[C_CORE + s];
+    const int K = pre[EXPAND_CORE_SHARDS];
+    if (K == 0) return;
+    int P = (K + SOLVE_ROWS - 1) / SOLVE_ROWS;
+    if (P > (int)gridDim.x) P = (int)gridDim.x;
+    if ((int)blockIdx.x >= P) return;
+    if (K <= P * SOLVE_ROWS) solve_body<false>(g, t, cap, sent, excess, sink_cap, height, decided, core, flags, acc, trace, detail,
+                                                saved_flow, saved_sink, warm, mslots, sp, s_priv, s_red, pre, K, P);
+    else solve_body<true>(g, t, cap, sent, excess, sink_cap, height, decided, core, flags, acc, trace, detail,
+                          saved_flow, saved_sink, warm, mslots, sp, s_priv, s_red, pre, K, P);
 }
 
 // Energy difference of the candidate labeling (sites with decided == 1 take alpha) and, by the last
@@ -1031,6 +1172,12 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 
     SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20 };
     int solve_grid = w.solve_grid > 0 ? w.solve_grid : 128;
+    // slots per solver row for a core of all n sites, and the LDS that holds their scalars
+    const int mslots = std::max(1, (g.n + solve_grid * SOLVE_ROWS - 1) / (solve_grid * SOLVE_ROWS));
+    const size_t solve_lds = sizeof(int) * F_FIELDS * (size_t)mslots * SOLVE_ROWS;
+    if (solve_lds > 128 * 1024) return hipErrorOutOfMemory;     // > 1.3 M sites at 256 workgroups
+    if (solve_lds > 48 * 1024)
+        RET_IF(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
     int t = 0;
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         old_energy = energy;
@@ -1042,10 +1189,13 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                                w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_big, blk_big, 0, s, g, L, t, w.cap, w.excess,
                                w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
-            hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), 0, s, g, L, t, w.cap, w.sent, w.excess,
-                               w.sink_cap, w.aux, w.height, w.decided, w.core, w.flags, w.acc,
+            hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), solve_lds, s, g, L, t, w.cap, w.sent, w.excess,
+                               w.sink_cap, w.height, w.decided, w.core, w.flags, w.acc,
                                (w.trace && t < w.trace_moves) ? w.trace : nullptr,
-                               (w.trace && t == w.detail_move) ? w.trace + 8 * (size_t)w.trace_moves : nullptr, sp);
+                               (w.trace && t == w.detail_move) ? w.trace + 8 * (size_t)w.trace_moves : nullptr,
+                               w.saved_flow ? w.saved_flow + (size_t)alpha * g.nnz : nullptr,
+                               w.saved_flow ? w.saved_sink + (size_t)alpha * g.n : nullptr,
+                               (w.saved_flow && cycle > 1) ? 1 : 0, mslots, sp);
             hipLaunchKernelGGL(k_delta, grid, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
                                w.decided, w.took, w.flags, w.acc);
             RET_IF(hipGetLastError());

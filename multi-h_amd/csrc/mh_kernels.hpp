@@ -116,7 +116,6 @@ struct ExpandWork {         // scratch owned by the engine
     int* excess;            // n
     int* sink_cap;          // n
     int* height;            // n
-    int* aux;               // 2n  per-site solver state of rows that walk several sites (expand.hip, k_solve)
     int* decided;           // n   0 undecided, 1 source side (takes alpha), 2 sink side (keeps its label), 3 not in the graph
     unsigned char* took;    // n   1 where the last solved move moves the site to alpha (applied lazily, see expand.hip)
     int* core;              // 8 x n  compacted list of the sites the dominance reduction left undecided, in 8 shards
@@ -134,6 +133,10 @@ struct ExpandWork {         // scratch owned by the engine
     int trace_moves;        //   barriers, ticks (100 MHz), ticks inside barriers}; moves beyond trace_moves are not traced
     int detail_move;        // move whose global relabels are logged behind the trace (4 ints each, at most 2048): {active sites,
                             //   largest finite height, relabel intervals so far, ticks so far}; -1 none
+    // flow recycling (expand.hip, k_solve): per label the net arc flows (L x nnz) and sink flows (L x n) its last
+    // expansion ended with; null = every move starts from the zero flow
+    int* saved_flow;
+    int* saved_sink;
 };
 constexpr int EXPAND_FLAG_WORDS = 896;     // device control block (expand.hip)
 constexpr int EXPAND_HOST_WORDS = 32;      // its head, mirrored to the host

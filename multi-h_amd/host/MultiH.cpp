@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 
 #include "merge_step.h"
@@ -94,7 +95,11 @@ bool MultiH::Process(std::vector<cv::Point2d> _srcPoints, std::vector<cv::Point2
 
 bool MultiH::EnsureEngine()
 {
-    if (!engine && !Check(mh_create(&engine, device), "mh_create")) return false;
+    if (!engine) {
+        if (!Check(mh_create(&engine, device), "mh_create")) return false;
+        for (const auto& kv : engine_tuning)
+            if (!Check(mh_set_tuning(engine, kv.first, kv.second), "mh_set_tuning")) return false;
+    }
     return Check(mh_set_params(engine, threshold_fundamental_matrix, threshold_homography,
                                locality_lambda, energy_lambda, minimum_inlier_number),
                  "mh_set_params");
@@ -433,9 +438,17 @@ void MultiH::ClusterMergingAndLabeling()
     double lastEnergy = INT_MAX;
     int not_changed_number = 0;
 
+    const bool timing = std::getenv("MULTIH_TIMING") != nullptr;                        // diagnostic: where the loop's time goes
+    double merge_s = 0.0, label_s = 0.0;
+    auto seconds_since = [](std::chrono::time_point<std::chrono::system_clock> t0) {
+        return std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
+    };
     while (iteration_number++ < MAX_ITERATION_NUMBER) {                                 // :267
         bool changed = false;
-        if (!MergingStep(changed)) break;
+        const auto t_merge = std::chrono::system_clock::now();
+        const bool merged = MergingStep(changed);
+        merge_s += seconds_since(t_merge);
+        if (!merged) break;
         if (iter_hypotheses > 0 && iteration_number > 1) {
             // PEARL re-proposal on the points the current labeling leaves unexplained
             std::vector<unsigned char> mask(N);
@@ -457,7 +470,25 @@ void MultiH::ClusterMergingAndLabeling()
             break;
 
         double energy;
-        if (!LabelingStep(energy, changed)) break;
+        const auto t_label = std::chrono::system_clock::now();
+        const bool labelled = LabelingStep(energy, changed);
+        label_s += seconds_since(t_label);
+        if (timing) {
+            long long st[20] = {};
+            (void)mh_get_expand_stats(engine, st);
+            printf("[Multi-H] iteration %d: %d clusters, changed %d, merging %.1f ms so far, labeling %.1f ms so far (this step %.1f ms: "
+                   "%lld cycles, %lld moves solved, core %lld / max %lld, %lld relabels, %lld barriers, solver %.1f ms)\n",
+                   iteration_number, (int)cluster_homographies.size(), changed ? 1 : 0, merge_s * 1e3, label_s * 1e3,
+                   seconds_since(t_label) * 1e3, st[0], st[10], st[11], st[12], st[14], st[13], (double)st[15] * 1e-3);
+            std::vector<int> tr(8 * 64, 0);              // per-move log, when the caller switched it on (mh_set_tuning key 8)
+            if (mh_get_expand_trace(engine, tr.data(), 64) == MH_OK)
+                for (int mv = 0; mv < 64; ++mv)
+                    if (tr[8 * mv + 6] > 200000)          // moves of more than 2 ms
+                        printf("[Multi-H]    move %d: core %d, %d workgroups, %d relabels, %d intervals, %d push phases, %d barriers, %.1f ms\n",
+                               mv, tr[8 * mv], tr[8 * mv + 1], tr[8 * mv + 2], tr[8 * mv + 3], tr[8 * mv + 4], tr[8 * mv + 5],
+                               tr[8 * mv + 6] * 1e-5);
+        }
+        if (!labelled) break;
         if (log_to_console)
             printf("Iteration %d.   Number of clusters = %d   Energy = %f\n", iteration_number,
                    (int)cluster_homographies.size(), energy);
@@ -594,6 +625,10 @@ extern "C" __attribute__((visibility("default")))
 void mhh_set_post_filter(int on) { g_post_filter = on; }
 extern "C" __attribute__((visibility("default")))
 void mhh_set_neighbourhood(int knn_k, double radius) { g_knn = knn_k; g_radius = radius; }
+// schedule knobs (mh_set_tuning) for the engines of the next mhh_run_process calls; key < 0 clears the list
+static std::vector<std::pair<int, int>> g_tuning;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_engine_tuning(int key, int value) { if (key < 0) g_tuning.clear(); else g_tuning.emplace_back(key, value); }
 
 // ---- C hook for the GPU-side integration test (ctypes; plain arrays in/out) ----------------
 extern "C" __attribute__((visibility("default")))
@@ -619,6 +654,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
     mh.SetDevice(g_device);
     mh.SetCompatibilityCheck(g_post_filter != 0);
+    for (const auto& kv : g_tuning) mh.SetEngineTuning(kv.first, kv.second);
     if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
     else if (g_knn > 0) mh.SetNeighbourK(g_knn);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init

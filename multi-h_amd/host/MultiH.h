@@ -18,6 +18,7 @@
 #pragma once
 
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "cv_shim.h"
@@ -118,6 +119,8 @@ public:
     // what the merge <-> label loop itself produced (parity tests against the oracle of that loop).
     void SetCompatibilityCheck(bool on) { run_compatibility_check = on; }
     void SetDevice(int d) { device = d; }
+    // schedule knob of the engine (mh_set_tuning; results never depend on it), applied when the engine is created
+    void SetEngineTuning(int key, int value) { engine_tuning.emplace_back(key, value); }
     void SetVerbose(bool v) { log_to_console = v; }
     double GetLastLoopSeconds() const { return loop_seconds; }
 
@@ -144,6 +147,7 @@ protected:
     // engine state
     mh_engine* engine = nullptr;
     int device = 0;
+    std::vector<std::pair<int, int>> engine_tuning;
     enum { NEIGHBOURS_KNN = 0, NEIGHBOURS_RADIUS = 1 };
     int neighbour_mode = NEIGHBOURS_KNN;
     int knn = 16;

@@ -13,6 +13,7 @@ e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2); e.se
 H = sc.H_true * (1.0 + np.random.default_rng(0).normal(0, 1e-4, size=sc.H_true.shape))
 ref = None
 TRACE = int(os.environ.get("TRACE", "0"))
+if "RECYCLE" in os.environ: e.set_tuning(11, int(os.environ["RECYCLE"]))
 if TRACE: e.set_tuning(8, 64); e.set_tuning(9, int(os.environ.get("DETAIL", "20")))
 CFGS = [(128, 256, 2, 256, 2), (128, 256, 1, 256, 2), (128, 256, 1, 256, 3), (128, 256, 1, 256, 4), (128, 256, 2, 256, 1), (128, 256, 2, 256, 3),
         (128, 256, 3, 256, 2), (128, 256, 2, 256, 4), (128, 256, 1, 256, 6), (128, 256, 2, 256, 2)]

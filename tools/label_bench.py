@@ -15,8 +15,9 @@ t0 = time.time(); e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col); print(f"graph 
 H = sc.H_true * (1.0 + np.random.default_rng(0).normal(0, 1e-4, size=sc.H_true.shape))
 lab = np.full(N, -1, np.int32)
 e.set_models(H)
+if "RECYCLE" in os.environ: e.set_tuning(11, int(os.environ["RECYCLE"]))    # flow recycling off (A/B)
 if "REDUCE" in os.environ: e.set_tuning(6, int(os.environ["REDUCE"]))     # 0 = no dominance reduction (A/B)
-for it in range(3):
+for it in range(int(os.environ.get('STEPS', 3))):
     t0 = time.time(); lab_g, en, cyc = e.labeling_step(it > 0, lab); tg = time.time() - t0
     print(f"GPU labeling step {it}: {tg*1e3:.1f} ms, energy {int(en)}, cycles {cyc}, stats {e.expand_stats()}")
     if it == 0: lab0, en0 = lab_g.copy(), en

@@ -28,6 +28,8 @@ if world > 1:
     import torch, torch.distributed as dist
 host = C.CDLL(os.path.join(ROOT, "multi-h_amd", "libmultih_host.so"))
 host.mhh_set_device(device)
+if "RECYCLE" in os.environ: host.mhh_set_engine_tuning(11, int(os.environ["RECYCLE"]))      # alpha-expansion flow recycling A/B
+if "TRACE" in os.environ: host.mhh_set_engine_tuning(8, 64)                                     # per-move solver log (with MULTIH_TIMING=1)
 if "KNN" in os.environ: host.mhh_set_neighbourhood(int(os.environ["KNN"]), C.c_double(0.0))
 hook = None
 if world > 1:
