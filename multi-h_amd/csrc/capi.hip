@@ -12,6 +12,9 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <vector>
 
 using namespace mh;
@@ -65,7 +68,11 @@ struct mh_engine {
     Epipolar epi{};
 
     // symmetric weighted graph
-    std::vector<int> g_rowptr, g_col, g_w, g_rev;
+    std::vector<int> g_rowptr, g_col, g_w, g_rev;   // host copy of the symmetric graph (built here by the fallback path, else fetched on demand)
+    bool g_host_valid = false;
+    int g_nnz = 0;
+    DevBuf<int> gb_deg, gb_start, gb_cursor, gb_raw, gb_mult, gb_uniq, gb_info, gb_hits_rp, gb_hits_col;   // graph.hip scratch
+    int order_n = -1;                        // d_order holds the solver's site order for this many sites
     DevBuf<int> d_rowptr, d_col, d_w, d_rev;
 
     // model set
@@ -211,64 +218,133 @@ int require_models(mh_engine* e)
     return MH_OK;
 }
 
+// Runs fn(begin, end) over [0, n) on up to 16 host threads (one below 20 000 items); fn must only write what its range owns.
+template <typename Fn>
+static void host_parallel_for(int n, Fn fn)
+{
+    unsigned t = std::thread::hardware_concurrency();
+    if (t == 0) t = 1;
+    if (t > 16) t = 16;
+    if (n < 20000) t = 1;
+    if (t == 1) { fn(0, n); return; }
+    std::vector<std::thread> pool;
+    const int chunk = (n + (int)t - 1) / (int)t;
+    for (unsigned k = 0; k < t; ++k) {
+        const int b = (int)k * chunk, en = std::min(n, b + chunk);
+        if (b < en) pool.emplace_back(fn, b, en);
+    }
+    for (auto& th : pool) th.join();
+}
+
 // Symmetric weighted CSR with reverse-arc index from a directed hit list.
 // setNeighbors semantics (GCoptimization.cpp:1656-1681, M/MultiH.cpp:532-540):
 // every directed hit i->j (j != i) appends j to i's list and i to j's list, so the
 // pair weight is mult(i,j) = #[i->j] + #[j->i]   (SURVEY A-2).
+// Rows are built by several host threads (entries land in a row in any order and are sorted there, so the
+// result does not depend on the number of threads).  Fallback of the device construction (graph.hip) for rows too
+// long for its per-row LDS sort; 50k points / 0.8 M hits: 38 ms on one thread, 17.6 ms on 16.
 int build_sym_graph(mh_engine* e, const int* rowptr, const int* col, int n)
 {
-    std::vector<int> deg(n, 0);
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (rowptr[i + 1] < rowptr[i]) return fail(MH_ERR_INVALID, "rowptr must be non-decreasing");
-        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-            const int j = col[k];
-            if (j < 0 || j >= n) return fail(MH_ERR_INVALID, "neighbour index out of range");
-            if (j == i) continue;
-            ++deg[i];
-            ++deg[j];
-        }
-    }
+    std::unique_ptr<std::atomic<int>[]> cnt(new std::atomic<int>[(size_t)n + 1]);
+    for (int i = 0; i <= n; ++i) cnt[i].store(0, std::memory_order_relaxed);
+    std::atomic<int> bad(0);
+    host_parallel_for(n, [&](int b, int en) {
+        for (int i = b; i < en; ++i)
+            for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                const int j = col[k];
+                if (j < 0 || j >= n) { bad.store(1, std::memory_order_relaxed); continue; }
+                if (j == i) continue;
+                cnt[i].fetch_add(1, std::memory_order_relaxed);
+                cnt[j].fetch_add(1, std::memory_order_relaxed);
+            }
+    });
+    if (bad.load()) return fail(MH_ERR_INVALID, "neighbour index out of range");
     std::vector<long long> start(n + 1, 0);
-    for (int i = 0; i < n; ++i) start[i + 1] = start[i] + deg[i];
+    for (int i = 0; i < n; ++i) start[i + 1] = start[i] + cnt[i].load(std::memory_order_relaxed);
     if (start[n] > 0x7fffffffll) return fail(MH_ERR_OVERFLOW, "too many neighbour entries");
     std::vector<int> raw((size_t)start[n]);
-    std::vector<long long> fill(start.begin(), start.end() - 1);
-    for (int i = 0; i < n; ++i)
-        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-            const int j = col[k];
-            if (j == i) continue;
-            raw[(size_t)fill[i]++] = j;
-            raw[(size_t)fill[j]++] = i;
-        }
+    for (int i = 0; i < n; ++i) cnt[i].store(0, std::memory_order_relaxed);       // now: entries placed in row i
+    host_parallel_for(n, [&](int b, int en) {
+        for (int i = b; i < en; ++i)
+            for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                const int j = col[k];
+                if (j == i) continue;
+                raw[(size_t)(start[i] + cnt[i].fetch_add(1, std::memory_order_relaxed))] = j;
+                raw[(size_t)(start[j] + cnt[j].fetch_add(1, std::memory_order_relaxed))] = i;
+            }
+    });
+    // sort each row and fold duplicates in place: (column, multiplicity) pairs at the head of the row
+    std::vector<int> mult((size_t)start[n]);
     e->g_rowptr.assign(n + 1, 0);
-    e->g_col.clear();
-    e->g_w.clear();
-    for (int i = 0; i < n; ++i) {
-        int* b = raw.data() + start[i];
-        int* en = raw.data() + start[i + 1];
-        std::sort(b, en);
-        for (int* p = b; p < en;) {
-            int* q = p;
-            while (q < en && *q == *p) ++q;
-            e->g_col.push_back(*p);
-            e->g_w.push_back((int)(q - p));
-            p = q;
+    host_parallel_for(n, [&](int b, int en) {
+        for (int i = b; i < en; ++i) {
+            int* rb = raw.data() + start[i];
+            int* re = raw.data() + start[i + 1];
+            int* mb = mult.data() + start[i];
+            std::sort(rb, re);
+            int u = 0;
+            for (int* p = rb; p < re;) {
+                int* q = p;
+                while (q < re && *q == *p) ++q;
+                rb[u] = *p;
+                mb[u] = (int)(q - p);
+                ++u;
+                p = q;
+            }
+            e->g_rowptr[i + 1] = u;
         }
-        e->g_rowptr[i + 1] = (int)e->g_col.size();
-    }
-    const int nnz = (int)e->g_col.size();
+    });
+    for (int i = 0; i < n; ++i) e->g_rowptr[i + 1] += e->g_rowptr[i];
+    const int nnz = e->g_rowptr[n];
+    e->g_col.resize(nnz);
+    e->g_w.resize(nnz);
     e->g_rev.assign(nnz, -1);
-    for (int i = 0; i < n; ++i)
-        for (int k = e->g_rowptr[i]; k < e->g_rowptr[i + 1]; ++k) {
-            const int j = e->g_col[k];
-            const int* b = e->g_col.data() + e->g_rowptr[j];
-            const int* en = e->g_col.data() + e->g_rowptr[j + 1];
-            const int* it = std::lower_bound(b, en, i);
-            e->g_rev[k] = (int)(it - e->g_col.data());
+    host_parallel_for(n, [&](int b, int en) {
+        for (int i = b; i < en; ++i) {
+            const int len = e->g_rowptr[i + 1] - e->g_rowptr[i];
+            std::copy(raw.data() + start[i], raw.data() + start[i] + len, e->g_col.data() + e->g_rowptr[i]);
+            std::copy(mult.data() + start[i], mult.data() + start[i] + len, e->g_w.data() + e->g_rowptr[i]);
         }
+    });
+    host_parallel_for(n, [&](int b, int en) {
+        for (int i = b; i < en; ++i)
+            for (int k = e->g_rowptr[i]; k < e->g_rowptr[i + 1]; ++k) {
+                const int j = e->g_col[k];
+                const int* rb = e->g_col.data() + e->g_rowptr[j];
+                const int* re = e->g_col.data() + e->g_rowptr[j + 1];
+                e->g_rev[k] = (int)(std::lower_bound(rb, re, i) - e->g_col.data());
+            }
+    });
     return MH_OK;
 }
 
+// the solver's site order (expand.hip, k_reduce<true>): Fisher-Yates with the engine's counter RNG, fixed seed (results never depend on it)
+static int upload_order(mh_engine* e)
+{
+    const int n = e->n;
+    if (e->order_n == n) return MH_OK;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    unsigned long long z = 0x6d682d6f72646572ull;
+    for (int i = n - 1; i > 0; --i) {
+        z += 0x9E3779B97F4A7C15ull;
+        unsigned long long x = z;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        const int j = (int)(((x >> 32) * (unsigned long long)(i + 1)) >> 32);
+        std::swap(order[i], order[j]);
+    }
+    HIPCHK(e->d_order.reserve(n));
+    HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));          // `order` dies with this scope
+    e->order_n = n;
+    return MH_OK;
+}
+
+// host copy (fallback path) -> device
 int upload_graph(mh_engine* e)
 {
     const int n = e->n, nnz = (int)e->g_col.size();
@@ -282,32 +358,77 @@ int upload_graph(mh_engine* e)
         HIPCHK(hipMemcpyAsync(e->d_w.p, e->g_w.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(e->d_rev.p, e->g_rev.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, e->stream));
     }
-    {
-        // the solver's site order: Fisher-Yates with the engine's counter RNG, fixed seed (results never depend on it)
-        std::vector<int> order(n);
-        for (int i = 0; i < n; ++i) order[i] = i;
-        unsigned long long z = 0x6d682d6f72646572ull;
-        for (int i = n - 1; i > 0; --i) {
-            z += 0x9E3779B97F4A7C15ull;
-            unsigned long long x = z;
-            x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-            x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-            x ^= x >> 31;
-            const int j = (int)(((x >> 32) * (unsigned long long)(i + 1)) >> 32);
-            std::swap(order[i], order[j]);
-        }
-        HIPCHK(e->d_order.reserve(n));
-        HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));      // `order` dies with this scope
-    }
     HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = upload_order(e);
+    if (rc) return rc;
+    e->g_nnz = nnz;
+    e->g_host_valid = true;
+    e->have_graph = true;
+    return MH_OK;
+}
+
+// The symmetric graph from directed hits that are on the device (graph.hip): a CSR (rowptr_dev) or a dense
+// n x stride table with -1 for "no hit".  Rows of more than SYM_MAX_ROW raw entries take the host path.
+// e->gb_info (8 ints) must have been cleared by the caller (its word 2 collects index errors of earlier passes too).
+static int device_sym_graph(mh_engine* e, const int* rowptr_dev, int stride, const int* col_dev)
+{
+    const int n = e->n;
+    HIPCHK(e->gb_deg.reserve(n));
+    HIPCHK(e->gb_start.reserve((size_t)n + 1));
+    HIPCHK(launch_sym_count(n, rowptr_dev, stride, col_dev, e->gb_deg.p, e->gb_start.p, e->gb_info.p, e->stream));
+    int info[8] = {}, total = 0;
+    HIPCHK(hipMemcpyAsync(info, e->gb_info.p, sizeof(int) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&total, e->gb_start.p + n, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (info[2] == 2) return fail(MH_ERR_INVALID, "rowptr must be non-decreasing");
+    if (info[2]) return fail(MH_ERR_INVALID, "neighbour index out of range (non-finite coordinates?)");
+    if (info[0]) return fail(MH_ERR_OVERFLOW, "too many neighbour entries");
+    if (info[1] > SYM_MAX_ROW) {
+        // a very dense neighbourhood: build on the host (any row length)
+        std::vector<int> rp(n + 1), col;
+        if (rowptr_dev) {
+            HIPCHK(hipMemcpy(rp.data(), rowptr_dev, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+            col.resize((size_t)rp[n]);
+            if (rp[n] > 0) HIPCHK(hipMemcpy(col.data(), col_dev, sizeof(int) * col.size(), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<int> dense((size_t)n * stride);
+            HIPCHK(hipMemcpy(dense.data(), col_dev, sizeof(int) * dense.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i) {
+                rp[i] = (int)col.size();
+                for (int j = 0; j < stride; ++j) if (dense[(size_t)i * stride + j] >= 0) col.push_back(dense[(size_t)i * stride + j]);
+            }
+            rp[n] = (int)col.size();
+        }
+        int rc = build_sym_graph(e, rp.data(), col.data(), n);
+        if (rc) return rc;
+        return upload_graph(e);
+    }
+    HIPCHK(e->gb_cursor.reserve(n));
+    HIPCHK(e->gb_uniq.reserve(n));
+    HIPCHK(e->gb_raw.reserve((size_t)std::max(total, 1)));
+    HIPCHK(e->gb_mult.reserve((size_t)std::max(total, 1)));
+    HIPCHK(e->d_rowptr.reserve((size_t)n + 1));
+    HIPCHK(launch_sym_build(n, rowptr_dev, stride, col_dev, e->gb_start.p, e->gb_cursor.p, e->gb_raw.p, e->gb_mult.p,
+                            e->gb_uniq.p, e->d_rowptr.p, e->gb_info.p, e->stream));
+    int nnz = 0;
+    HIPCHK(hipMemcpyAsync(&nnz, e->d_rowptr.p + n, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(e->d_col.reserve((size_t)std::max(nnz, 1)));
+    HIPCHK(e->d_w.reserve((size_t)std::max(nnz, 1)));
+    HIPCHK(e->d_rev.reserve((size_t)std::max(nnz, 1)));
+    HIPCHK(launch_sym_finish(n, e->gb_start.p, e->gb_raw.p, e->gb_mult.p, e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->stream));
+    int rc = upload_order(e);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->g_nnz = nnz;
+    e->g_host_valid = false;
     e->have_graph = true;
     return MH_OK;
 }
 
 int ensure_expand_work(mh_engine* e)
 {
-    const int n = e->n, nnz = (int)e->g_col.size();
+    const int n = e->n, nnz = e->g_nnz;
     HIPCHK(e->ew_label.reserve(n));
     HIPCHK(e->ew_cur.reserve(n));
     HIPCHK(e->ew_cap.reserve(nnz));
@@ -350,7 +471,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     if (e->cost_L != e->m + 1) return fail(MH_ERR_NOT_SET, "data cost is stale; call mh_data_cost first");
     int rc = ensure_expand_work(e);
     if (rc) return rc;
-    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, (int)e->g_col.size(), e->d_order.p };
+    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, e->g_nnz, e->d_order.p };
     // the solver launch must be resident as a whole (it synchronises through a grid barrier): at most half
     // the CUs, so that engines of other processes sharing the GPU can never starve each other's launches
     const int solve_grid = std::max(1, std::min(e->tune_expand[3], e->cu_count));
@@ -507,6 +628,8 @@ void mh_destroy(mh_engine* e)
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
     e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release();
     e->knn_tmp.release();
+    e->gb_deg.release(); e->gb_start.release(); e->gb_cursor.release(); e->gb_raw.release(); e->gb_mult.release();
+    e->gb_uniq.release(); e->gb_info.release(); e->gb_hits_rp.release(); e->gb_hits_col.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     if (e->h_ms) (void)hipHostFree(e->h_ms);
     if (e->h_ms_list) (void)hipHostFree(e->h_ms_list);
@@ -604,6 +727,7 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
     e->have_aff = affines != nullptr;
     e->have_graph = false;
     e->g_rowptr.clear(); e->g_col.clear(); e->g_w.clear(); e->g_rev.clear();
+    e->g_host_valid = false; e->g_nnz = 0;
     e->cost_L = 0;
     return MH_OK;
     });
@@ -628,9 +752,18 @@ int mh_set_neighbors_csr(mh_engine* e, const int* rowptr, const int* col, int n)
     if (rc) return rc;
     if (!rowptr || n != e->n) return fail(MH_ERR_INVALID, "rowptr null or n != number of correspondences");
     if (rowptr[n] > 0 && !col) return fail(MH_ERR_INVALID, "col is null");
-    rc = build_sym_graph(e, rowptr, col, n);
-    if (rc) return rc;
-    return upload_graph(e);
+    if (rowptr[0] < 0) return fail(MH_ERR_INVALID, "rowptr must be non-decreasing");
+    for (int i = 0; i < n; ++i)
+        if (rowptr[i + 1] < rowptr[i]) return fail(MH_ERR_INVALID, "rowptr must be non-decreasing");
+    HIPCHK(e->gb_info.reserve(8));
+    HIPCHK(hipMemsetAsync(e->gb_info.p, 0, sizeof(int) * 8, e->stream));
+    HIPCHK(e->gb_hits_rp.reserve((size_t)n + 1));
+    HIPCHK(e->gb_hits_col.reserve((size_t)std::max(rowptr[n], 1)));
+    HIPCHK(hipMemcpyAsync(e->gb_hits_rp.p, rowptr, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, e->stream));
+    if (rowptr[n] > 0)
+        HIPCHK(hipMemcpyAsync(e->gb_hits_col.p, col, sizeof(int) * (size_t)rowptr[n], hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));          // the caller's arrays are free again
+    return device_sym_graph(e, e->gb_hits_rp.p, 0, e->gb_hits_col.p);
     });
 }
 
@@ -642,40 +775,14 @@ static int build_knn_graph(mh_engine* e, int k, double radius)
     if (k < 1 || k > 32 || k >= e->n) return fail(MH_ERR_INVALID, "k must be in [1, 32] and < n");
     const int n = e->n;
     HIPCHK(e->knn_tmp.reserve((size_t)n * k));
+    HIPCHK(e->gb_info.reserve(8));
+    HIPCHK(hipMemsetAsync(e->gb_info.p, 0, sizeof(int) * 8, e->stream));
     HIPCHK(launch_knn(e->pts(), k, e->knn_tmp.p, e->stream));
-    std::vector<int> col((size_t)n * k), rowptr(n + 1);
-    HIPCHK(hipMemcpyAsync(col.data(), e->knn_tmp.p, sizeof(int) * col.size(), hipMemcpyDeviceToHost, e->stream));
-    std::vector<double> xy;
-    if (radius > 0.0) {
-        xy.resize(4 * (size_t)n);
-        const double* srcs[4] = { e->x1.p, e->y1.p, e->x2.p, e->y2.p };
-        for (int c = 0; c < 4; ++c)
-            HIPCHK(hipMemcpyAsync(xy.data() + (size_t)c * n, srcs[c], sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
-    }
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (radius > 0.0) {
-        // the reference's radius (M/MultiH.cpp:252-253) in the kernels' float32 arithmetic: ((dx^2+dy^2)+dz^2)+dw^2 <= r^2
-        const float r2 = (float)radius * (float)radius;
-        size_t w = 0;
-        for (int i = 0; i < n; ++i) {
-            rowptr[i] = (int)w;
-            for (int j = 0; j < k; ++j) {
-                const int c = col[(size_t)i * k + j];
-                if (c < 0 || c >= n) return fail(MH_ERR_INVALID, "neighbour index out of range (non-finite coordinates?)");
-                const float dx = (float)xy[i] - (float)xy[c], dy = (float)xy[(size_t)n + i] - (float)xy[(size_t)n + c];
-                const float dz = (float)xy[2 * (size_t)n + i] - (float)xy[2 * (size_t)n + c];
-                const float dw = (float)xy[3 * (size_t)n + i] - (float)xy[3 * (size_t)n + c];
-                const float d = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
-                if (d <= r2) col[w++] = c;
-            }
-        }
-        rowptr[n] = (int)w;
-    } else {
-        for (int i = 0; i <= n; ++i) rowptr[i] = i * k;
-    }
-    rc = build_sym_graph(e, rowptr.data(), col.data(), n);
-    if (rc) return rc;
-    return upload_graph(e);
+    // the reference's radius (M/MultiH.cpp:252-253) in the kernels' float32 arithmetic; without a radius the pass only
+    // validates the indices (non-finite coordinates leave garbage in the k-NN table)
+    const float r2 = radius > 0.0 ? (float)radius * (float)radius : INFINITY;
+    HIPCHK(launch_hits_filter(e->pts(), k, r2, e->knn_tmp.p, e->gb_info.p + 2, e->stream));
+    return device_sym_graph(e, nullptr, k, e->knn_tmp.p);
 }
 
 int mh_build_neighbors_knn(mh_engine* e, int k)
@@ -717,13 +824,9 @@ int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, l
     HIPCHK(d_col.reserve((size_t)std::max<long long>(total, 1)));
     HIPCHK(hipMemcpyAsync(d_rp.p, rowptr.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, e->stream));
     HIPCHK(launch_radius_fill(e->pts(), r2, d_rp.p, d_col.p, e->stream));
-    std::vector<int> col((size_t)total);
-    if (total > 0)
-        HIPCHK(hipMemcpyAsync(col.data(), d_col.p, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    rc = build_sym_graph(e, rowptr.data(), col.data(), n);
-    if (rc) return rc;
-    return upload_graph(e);
+    HIPCHK(e->gb_info.reserve(8));
+    HIPCHK(hipMemsetAsync(e->gb_info.p, 0, sizeof(int) * 8, e->stream));
+    return device_sym_graph(e, d_rp.p, 0, d_col.p);      // (synchronises before the scratch lists are released)
     });
 }
 
@@ -732,7 +835,18 @@ int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
     return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (!e->have_graph) return fail(MH_ERR_NOT_SET, "neighbour graph is not set");
-    if (nnz) *nnz = (int)e->g_col.size();
+    if (!e->g_host_valid) {                            // built on the device: fetch once
+        HIPCHK(hipSetDevice(e->device));
+        e->g_rowptr.resize((size_t)e->n + 1); e->g_col.resize(e->g_nnz); e->g_w.resize(e->g_nnz); e->g_rev.resize(e->g_nnz);
+        HIPCHK(hipMemcpy(e->g_rowptr.data(), e->d_rowptr.p, sizeof(int) * ((size_t)e->n + 1), hipMemcpyDeviceToHost));
+        if (e->g_nnz) {
+            HIPCHK(hipMemcpy(e->g_col.data(), e->d_col.p, sizeof(int) * (size_t)e->g_nnz, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(e->g_w.data(), e->d_w.p, sizeof(int) * (size_t)e->g_nnz, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(e->g_rev.data(), e->d_rev.p, sizeof(int) * (size_t)e->g_nnz, hipMemcpyDeviceToHost));
+        }
+        e->g_host_valid = true;
+    }
+    if (nnz) *nnz = e->g_nnz;
     if (rowptr) std::copy(e->g_rowptr.begin(), e->g_rowptr.end(), rowptr);
     if (col) std::copy(e->g_col.begin(), e->g_col.end(), col);
     if (w) std::copy(e->g_w.begin(), e->g_w.end(), w);

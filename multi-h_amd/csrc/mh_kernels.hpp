@@ -182,4 +182,16 @@ hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, hipStrea
 hipError_t launch_radius_count(const Points& p, float r2, int* counts /* n */, hipStream_t s);
 hipError_t launch_radius_fill(const Points& p, float r2, const int* rowptr /* n+1 */, int* col /* nnz */, hipStream_t s);
 
+// --- graph.hip ------------------------------------------------------------------
+// Symmetric weighted CSR with reverse-arc index from directed hits on the device (a CSR, or rowptr == null: a dense
+// n x stride table; column -1 = no hit).  info: 8 device ints the caller cleared —
+//   [0] raw total exceeds int32, [1] longest raw row, [2] index error (1 out of range, 2 rowptr decreasing), [4..5] the same two for the folded rows.
+constexpr int SYM_MAX_ROW = 1024;         // longest raw row (hits made + received) k_sym_fold sorts in LDS
+hipError_t launch_hits_filter(const Points& p, int stride, float r2, int* col, int* err, hipStream_t s);
+hipError_t launch_sym_count(int n, const int* rowptr, int stride, const int* col, int* deg, int* start /* n+1 */, int* info, hipStream_t s);
+hipError_t launch_sym_build(int n, const int* rowptr, int stride, const int* col, const int* start, int* cursor, int* raw,
+                            int* mult, int* uniq, int* out_rowptr /* n+1 */, int* info, hipStream_t s);
+hipError_t launch_sym_finish(int n, const int* start, const int* raw, const int* mult, const int* rowptr, int* col, int* w,
+                             int* rev, hipStream_t s);
+
 } // namespace mh

@@ -281,6 +281,45 @@ def test_sym_graph_matches_oracle(engine, synth, oracle):
     assert set(np.unique(w)) == {1, 2}       # one-way and mutual kNN hits (SURVEY A-2)
 
 
+def test_sym_graph_on_the_device_handles_ragged_hit_lists(mh, engine, synth, oracle):
+    """The symmetric graph is built on the device (csrc/graph.hip).  Caller-supplied lists with repeated hits, self
+    hits, empty rows and a few very long rows (beyond what the per-row LDS sort holds: the host path takes over)
+    give exactly the oracle's CSR, multiplicities and — through the expansion — reverse arcs; bad input fails cleanly."""
+    rng = np.random.default_rng(11)
+    sc = synth.make_scene(2500, 3, seed=12, with_neighbours=False)
+    _load(engine, sc, neighbours=False)
+    n = sc.n
+    for dense_rows in (0, 3):
+        rows = []
+        for i in range(n):
+            d = int(rng.integers(0, 9))
+            if i < dense_rows: d = 1500                               # raw row far beyond SYM_MAX_ROW = 1024
+            if i % 97 == 5: d = 0
+            r = rng.integers(0, n, size=d)
+            if d > 2: r[1] = r[0]; r[2] = i                           # a repeated hit and a self hit
+            rows.append(r)
+        rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        col = np.concatenate(rows).astype(np.int32)
+        engine.set_neighbors_csr(rowptr, col)
+        rp, cl, w = engine.get_sym_graph()
+        rp_o, cl_o, w_o = oracle.build_sym_graph(n, rowptr, col)
+        assert np.array_equal(rp, rp_o) and np.array_equal(cl, cl_o) and np.array_equal(w, w_o), dense_rows
+        assert w.max() >= 2
+        engine.set_models(_models(sc, np.random.default_rng(3), extra=1))
+        cost = engine.data_cost()
+        labels, energy, cycles = engine.expand()
+        lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, rowptr, col, oracle.potts(LAM))
+        assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), dense_rows
+    bad = col.copy(); bad[7] = n
+    with pytest.raises(mh.MultiHError) as ei:
+        engine.set_neighbors_csr(rowptr, bad)
+    assert ei.value.code == -2
+    rp_bad = rowptr.copy(); rp_bad[10] = rp_bad[11] + 1
+    with pytest.raises(mh.MultiHError) as ei:
+        engine.set_neighbors_csr(rp_bad, col)
+    assert ei.value.code == -2
+
+
 @pytest.mark.parametrize("n,k,seed", [(1000, 3, 2), (5000, 3, 1234)])
 def test_labeling_step_and_loop(engine, synth, oracle, n, k, seed):
     """LabelingStep (cost -> expand -> shift -> re-estimate), iterated like the reference's
