@@ -121,7 +121,8 @@ struct mh_engine {
     long long* h_acc = nullptr;
     int* h_flags_dev = nullptr;
     long long* h_acc_dev = nullptr;
-    DevBuf<int> knn_tmp;
+    DevBuf<int> knn_tmp, knn_part_i;
+    DevBuf<float> knn_part_d;
 
     bool profiling = false;
     KernelTimer timers[MH_K_COUNT_];
@@ -627,7 +628,7 @@ void mh_destroy(mh_engine* e)
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
     e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release();
-    e->knn_tmp.release();
+    e->knn_tmp.release(); e->knn_part_i.release(); e->knn_part_d.release();
     e->gb_deg.release(); e->gb_start.release(); e->gb_cursor.release(); e->gb_raw.release(); e->gb_mult.release();
     e->gb_uniq.release(); e->gb_info.release(); e->gb_hits_rp.release(); e->gb_hits_col.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
@@ -777,7 +778,16 @@ static int build_knn_graph(mh_engine* e, int k, double radius)
     HIPCHK(e->knn_tmp.reserve((size_t)n * k));
     HIPCHK(e->gb_info.reserve(8));
     HIPCHK(hipMemsetAsync(e->gb_info.p, 0, sizeof(int) * 8, e->stream));
-    HIPCHK(launch_knn(e->pts(), k, e->knn_tmp.p, e->stream));
+    // enough slices of the candidate range to give every SIMD a few waves (one thread per query and slice)
+    const int blocks = (n + 255) / 256;
+    int splits = (4 * e->cu_count + blocks - 1) / blocks;
+    splits = std::max(1, std::min(splits, std::min(KNN_MAX_SPLITS, (n + 1023) / 1024)));
+    const int kk = k <= 8 ? 8 : k <= 16 ? 16 : 32;
+    if (splits > 1) {
+        HIPCHK(e->knn_part_d.reserve((size_t)splits * n * kk));
+        HIPCHK(e->knn_part_i.reserve((size_t)splits * n * kk));
+    }
+    HIPCHK(launch_knn(e->pts(), k, e->knn_tmp.p, splits, e->knn_part_d.p, e->knn_part_i.p, e->stream));
     // the reference's radius (M/MultiH.cpp:252-253) in the kernels' float32 arithmetic; without a radius the pass only
     // validates the indices (non-finite coordinates leave garbage in the k-NN table)
     const float r2 = radius > 0.0 ? (float)radius * (float)radius : INFINITY;

@@ -11,7 +11,12 @@
 // ties are broken by the smaller index, so the result is a pure function of
 // the input.  One thread per query; candidates stream through LDS in tiles of
 // 256 (16 B each, conflict-free broadcast reads); the running top-K is a
-// sorted register array with a fully unrolled insertion.
+// sorted register array with a fully unrolled insertion.  One thread per query
+// alone leaves the chip empty (50k queries = 196 workgroups on 256 CUs, one
+// wave per SIMD), so the candidate range is cut into `splits` slices
+// (blockIdx.y), each slice keeps its own top-K per query, and k_knn_merge takes
+// the K smallest (distance, index) pairs of the slices' lists: the same set in
+// the same order as one pass over all candidates.
 
 #include "mh_kernels.hpp"
 
@@ -20,8 +25,8 @@ namespace mh {
 template <int K>
 __global__ void __launch_bounds__(256)
 k_knn(const double* __restrict__ x1, const double* __restrict__ y1,
-      const double* __restrict__ x2, const double* __restrict__ y2, int N, int k,
-      int* __restrict__ out)
+      const double* __restrict__ x2, const double* __restrict__ y2, int N, int k, int slice,
+      int* __restrict__ out, float* __restrict__ part_d, int* __restrict__ part_i)
 {
     __shared__ float4 tile[256];
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -32,12 +37,14 @@ k_knn(const double* __restrict__ x1, const double* __restrict__ y1,
 #pragma unroll
     for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = 0x7fffffff; }
 
-    for (int base = 0; base < N; base += 256) {
+    const int first = blockIdx.y * slice;                       // my slice of the candidates (a multiple of 256 long)
+    const int last = (first + slice) < N ? (first + slice) : N;
+    for (int base = first; base < last; base += 256) {
         const int c = base + threadIdx.x;
         __syncthreads();
         if (c < N) tile[threadIdx.x] = make_float4((float)x1[c], (float)y1[c], (float)x2[c], (float)y2[c]);
         __syncthreads();
-        const int lim = (N - base) < 256 ? (N - base) : 256;
+        const int lim = (last - base) < 256 ? (last - base) : 256;
         for (int t = 0; t < lim; ++t) {
             const int j = base + t;
             const float4 o = tile[t];
@@ -62,10 +69,40 @@ k_knn(const double* __restrict__ x1, const double* __restrict__ y1,
             }
         }
     }
-    if (q < N) {
+    if (q >= N) return;
+    if (gridDim.y == 1) {
 #pragma unroll
         for (int i = 0; i < K; ++i)
             if (i < k) out[(size_t)q * k + i] = bi[i];
+    } else {
+        const size_t o = ((size_t)blockIdx.y * N + q) * K;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { part_d[o + i] = bd[i]; part_i[o + i] = bi[i]; }
+    }
+}
+
+// The K smallest (distance, index) pairs of `splits` sorted lists per query: a K-step merge by list heads.
+template <int K>
+__global__ void __launch_bounds__(256)
+k_knn_merge(int N, int k, int splits, const float* __restrict__ part_d, const int* __restrict__ part_i,
+            int* __restrict__ out)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= N) return;
+    int head[KNN_MAX_SPLITS];
+    for (int s = 0; s < splits; ++s) head[s] = 0;
+    for (int i = 0; i < k; ++i) {
+        float bd = __builtin_inff();
+        int bi = 0x7fffffff, bs = 0;
+        for (int s = 0; s < splits; ++s) {
+            if (head[s] >= K) continue;
+            const size_t o = ((size_t)s * N + q) * K + head[s];
+            const float d = part_d[o];
+            const int j = part_i[o];
+            if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; bs = s; }
+        }
+        out[(size_t)q * k + i] = bi;
+        ++head[bs];
     }
 }
 
@@ -122,15 +159,28 @@ hipError_t launch_radius_fill(const Points& p, float r2, const int* rowptr, int*
     return hipGetLastError();
 }
 
-hipError_t launch_knn(const Points& p, int k, int* nbr_out, hipStream_t s)
+template <int K>
+static hipError_t launch_knn_k(const Points& p, int k, int* nbr_out, int splits, float* part_d, int* part_i, hipStream_t s)
+{
+    const int blocks = (p.n + 255) / 256;
+    int slice = ((p.n + splits - 1) / splits + 255) / 256 * 256;
+    if (slice < 256) slice = 256;
+    hipLaunchKernelGGL((k_knn<K>), dim3(blocks, splits), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, k, slice, nbr_out,
+                       part_d, part_i);
+    if (splits > 1)
+        hipLaunchKernelGGL((k_knn_merge<K>), dim3(blocks), dim3(256), 0, s, p.n, k, splits, part_d, part_i, nbr_out);
+    return hipGetLastError();
+}
+
+// splits > 1 needs scratch for the slices' lists: splits x n x K floats and ints (K = 8, 16 or 32, the smallest >= k)
+hipError_t launch_knn(const Points& p, int k, int* nbr_out, int splits, float* part_d, int* part_i, hipStream_t s)
 {
     if (p.n <= 0) return hipSuccess;
-    const dim3 grid((p.n + 255) / 256), blk(256);
-    if (k <= 8) hipLaunchKernelGGL((k_knn<8>), grid, blk, 0, s, p.x1, p.y1, p.x2, p.y2, p.n, k, nbr_out);
-    else if (k <= 16) hipLaunchKernelGGL((k_knn<16>), grid, blk, 0, s, p.x1, p.y1, p.x2, p.y2, p.n, k, nbr_out);
-    else if (k <= 32) hipLaunchKernelGGL((k_knn<32>), grid, blk, 0, s, p.x1, p.y1, p.x2, p.y2, p.n, k, nbr_out);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
+    if (splits < 1 || splits > KNN_MAX_SPLITS || (splits > 1 && (!part_d || !part_i))) return hipErrorInvalidValue;
+    if (k <= 8) return launch_knn_k<8>(p, k, nbr_out, splits, part_d, part_i, s);
+    if (k <= 16) return launch_knn_k<16>(p, k, nbr_out, splits, part_d, part_i, s);
+    if (k <= 32) return launch_knn_k<32>(p, k, nbr_out, splits, part_d, part_i, s);
+    return hipErrorInvalidValue;
 }
 
 } // namespace mh

@@ -178,7 +178,8 @@ hipError_t launch_sel_claim(const Points& p, const double* all_H, int longest, c
 hipError_t launch_sel_publish(int* rec, unsigned long long* keys, int need, int* h_rec_dev, hipStream_t s);
 
 // --- knn.hip ----------------------------------------------------------------
-hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, hipStream_t s);
+constexpr int KNN_MAX_SPLITS = 16;      // slices of the candidate range (knn.hip)
+hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, int splits, float* part_d, int* part_i, hipStream_t s);
 hipError_t launch_radius_count(const Points& p, float r2, int* counts /* n */, hipStream_t s);
 hipError_t launch_radius_fill(const Points& p, float r2, const int* rowptr /* n+1 */, int* col /* nnz */, hipStream_t s);
 
