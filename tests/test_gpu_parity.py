@@ -238,6 +238,33 @@ def test_expand_solver_paths(engine, synth, oracle, case):
     assert st["host_syncs"] <= st["cycles"] + 2
 
 
+def test_flow_recycling_changes_rounds_not_labels(engine, synth, oracle):
+    """From the second cycle on the max-flow of a move starts from the flow the previous expansion on the same label
+    ended with (csrc/expand.hip, k_solve).  The read-out of a maximum flow does not depend on where the flow started:
+    labels, energy and cycle count are the oracle's with recycling on and off (also with several sites per solver
+    row); what recycling changes is the number of relabel rounds."""
+    sc = synth.make_scene(8000, 6, seed=21)
+    H = sc.H_true * (1.0 + np.random.default_rng(8).normal(0, 1e-4, size=sc.H_true.shape))     # every plane slightly off
+    _load(engine, sc)
+    engine.set_models(H)
+    cost = engine.data_cost()
+    lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM))
+    assert cyc_ref >= 3, "the scene should need more than one cycle"
+    relabels = {}
+    try:
+        for grid in (256, 4):
+            for recycle in (0, 1):
+                engine.set_tuning(5, grid)
+                engine.set_tuning(11, recycle)
+                labels, energy, cycles = engine.expand()
+                assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), (grid, recycle)
+                relabels[(grid, recycle)] = engine.expand_stats()["relabels"]
+    finally:
+        engine.set_tuning(5, 256)
+        engine.set_tuning(11, 1)
+    assert relabels[(256, 1)] < relabels[(256, 0)], relabels
+
+
 def test_expand_trace_agrees_with_the_counters(engine, synth):
     """mh_get_expand_trace (diagnostic): one row per move, zero for skipped moves and empty cores; its sums are the
     expansion's counters."""
