@@ -212,7 +212,8 @@ MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int*
  * push-relabel after the reduction, 8 kernel launches, 9 moves actually run (the others were skipped on the
  * device as provably idempotent), 10 moves whose undecided core was not empty, 11 sum and 12 maximum of the
  * core sizes, 13 grid barriers, 14 global relabels, 15 microseconds spent inside the solver launches, of which
- * 16 inside grid barriers, 17 in global relabels and 18 in push phases (both including their barriers), 19 reserved}. */
+ * 16 inside grid barriers, 17 in global relabels and 18 in push phases (both including their barriers), 19 in relabel/push rounds that began with fewer than 64 solver
+ * rows still holding excess (the tail of a move)}. */
 MH_API int mh_get_expand_stats(mh_engine* e, long long stats[20]);
 /* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid

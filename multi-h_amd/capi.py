@@ -339,7 +339,7 @@ class Engine:
         self._check(self.lib.mh_get_expand_stats(self._h, st))
         return dict(zip(("cycles", "moves", "accepted", "push_phases", "relax_intervals", "host_syncs",
                          "reduce_launches", "flow_moves", "launches", "moves_run", "moves_solved",
-                         "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us"),
+                         "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us", "tail_us"),
                         list(st)))
 
     def expand_trace(self, moves: int):

@@ -368,6 +368,13 @@ int upload_graph(mh_engine* e)
     return MH_OK;
 }
 
+// device -> pageable host memory on the engine's stream, complete on return
+static hipError_t fetch_ints(mh_engine* e, int* dst, const int* src_dev, size_t count)
+{
+    hipError_t he = hipMemcpyAsync(dst, src_dev, sizeof(int) * count, hipMemcpyDeviceToHost, e->stream);
+    return he != hipSuccess ? he : hipStreamSynchronize(e->stream);
+}
+
 // The symmetric graph from directed hits that are on the device (graph.hip): a CSR (rowptr_dev) or a dense
 // n x stride table with -1 for "no hit".  Rows of more than SYM_MAX_ROW raw entries take the host path.
 // e->gb_info (8 ints) must have been cleared by the caller (its word 2 collects index errors of earlier passes too).
@@ -388,12 +395,12 @@ static int device_sym_graph(mh_engine* e, const int* rowptr_dev, int stride, con
         // a very dense neighbourhood: build on the host (any row length)
         std::vector<int> rp(n + 1), col;
         if (rowptr_dev) {
-            HIPCHK(hipMemcpy(rp.data(), rowptr_dev, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+            HIPCHK(fetch_ints(e, rp.data(), rowptr_dev, (size_t)n + 1));
             col.resize((size_t)rp[n]);
-            if (rp[n] > 0) HIPCHK(hipMemcpy(col.data(), col_dev, sizeof(int) * col.size(), hipMemcpyDeviceToHost));
+            if (rp[n] > 0) HIPCHK(fetch_ints(e, col.data(), col_dev, col.size()));
         } else {
             std::vector<int> dense((size_t)n * stride);
-            HIPCHK(hipMemcpy(dense.data(), col_dev, sizeof(int) * dense.size(), hipMemcpyDeviceToHost));
+            HIPCHK(fetch_ints(e, dense.data(), col_dev, dense.size()));
             for (int i = 0; i < n; ++i) {
                 rp[i] = (int)col.size();
                 for (int j = 0; j < stride; ++j) if (dense[(size_t)i * stride + j] >= 0) col.push_back(dense[(size_t)i * stride + j]);
@@ -848,11 +855,11 @@ int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz)
     if (!e->g_host_valid) {                            // built on the device: fetch once
         HIPCHK(hipSetDevice(e->device));
         e->g_rowptr.resize((size_t)e->n + 1); e->g_col.resize(e->g_nnz); e->g_w.resize(e->g_nnz); e->g_rev.resize(e->g_nnz);
-        HIPCHK(hipMemcpy(e->g_rowptr.data(), e->d_rowptr.p, sizeof(int) * ((size_t)e->n + 1), hipMemcpyDeviceToHost));
+        HIPCHK(fetch_ints(e, e->g_rowptr.data(), e->d_rowptr.p, (size_t)e->n + 1));
         if (e->g_nnz) {
-            HIPCHK(hipMemcpy(e->g_col.data(), e->d_col.p, sizeof(int) * (size_t)e->g_nnz, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(e->g_w.data(), e->d_w.p, sizeof(int) * (size_t)e->g_nnz, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(e->g_rev.data(), e->d_rev.p, sizeof(int) * (size_t)e->g_nnz, hipMemcpyDeviceToHost));
+            HIPCHK(fetch_ints(e, e->g_col.data(), e->d_col.p, (size_t)e->g_nnz));
+            HIPCHK(fetch_ints(e, e->g_w.data(), e->d_w.p, (size_t)e->g_nnz));
+            HIPCHK(fetch_ints(e, e->g_rev.data(), e->d_rev.p, (size_t)e->g_nnz));
         }
         e->g_host_valid = true;
     }
@@ -1554,7 +1561,7 @@ int mh_get_expand_stats(mh_engine* e, long long stats[20])
     stats[16] = (long long)(x.barrier_ms * 1000.0);
     stats[17] = (long long)(x.relax_ms * 1000.0);
     stats[18] = (long long)(x.push_ms * 1000.0);
-    stats[19] = 0;
+    stats[19] = (long long)(x.tail_ms * 1000.0);
     return MH_OK;
     });
 }

@@ -88,7 +88,7 @@ enum { A_DELTA_S = 64, A_ENERGY_S = A_DELTA_S + STRIPES * STRIPE_LL, A_EXCESS_S 
        A_TOTAL = A_EXCESS_S + STRIPES * STRIPE_LL };
 static_assert(A_TOTAL <= EXPAND_ACC_WORDS, "accumulator block too small");
 enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_CORE_SUM = 3, A_OUTER = 4, A_RELAX = 5, A_PUSH = 6,
-       A_BARRIERS = 7, A_TICKS = 8, A_T_BAR = 9, A_T_RELAX = 10, A_T_PUSH = 11, A_COUNT = 16 /* mirrored to the host */ };
+       A_BARRIERS = 7, A_TICKS = 8, A_T_BAR = 9, A_T_RELAX = 10, A_T_PUSH = 11, A_T_TAIL = 12, A_TAIL_ROUNDS = 13, A_COUNT = 16 /* mirrored to the host */ };
 enum { ERR_OVERFLOW = 1, ERR_BARRIER_TIMEOUT = 2, ERR_NO_CONVERGENCE = 3 };
 
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -511,7 +511,8 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
     GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull };
     long long st_outer = 0, st_relax = 0, st_push = 0;
-    unsigned long long tk_relax = 0, tk_push = 0;
+    unsigned long long tk_relax = 0, tk_push = 0, tk_tail = 0;
+    long long st_tail = 0;                           // relabel/push rounds that began with fewer than 64 active rows
 #define PRIV(field, slot) s_priv[((field) * mslots + (slot)) * SOLVE_ROWS + lr]
 #define CUR(slot) (!MULTI || (slot) == cur)
 
@@ -795,6 +796,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
             d[0] = nact; d[1] = hmax; d[2] = (int)st_relax; d[3] = (int)(__builtin_amdgcn_s_memrealtime() - tick0);
         }
         if (nact == 0) break;                          // (then exact) finished: nobody with excess reaches the sink
+        const bool tail_round = nact < 64;
         if (outer == 0 && leader) atomicAdd(&flags[C_FLOW_MOVES], 1);
 
         // lock-free push-relabel (see the header of this kernel); a wave of pushes needs about as many cycles
@@ -921,6 +923,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
             if (nact == 0) break;
         }
         tk_push += __builtin_amdgcn_s_memrealtime() - tp0;
+        if (tail_round) { tk_tail += __builtin_amdgcn_s_memrealtime() - tr0; ++st_tail; }
     }
 
     // ---- read-out: whoever cannot reach the sink takes alpha ---------------------------------------
@@ -956,6 +959,8 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
         atomicAdd((unsigned long long*)&acc[A_T_BAR], bar.ticks);
         atomicAdd((unsigned long long*)&acc[A_T_RELAX], tk_relax);
         atomicAdd((unsigned long long*)&acc[A_T_PUSH], tk_push);
+        atomicAdd((unsigned long long*)&acc[A_T_TAIL], tk_tail);
+        atomicAdd((unsigned long long*)&acc[A_TAIL_ROUNDS], (unsigned long long)st_tail);
         atomicMax(&flags[C_XCD_USED], bar.xcds);
         if (trace) {
             int* tr = trace + 8 * (size_t)t;
@@ -1230,6 +1235,8 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     stats.barrier_ms = (double)w.h_acc[A_T_BAR] * 1e-5;
     stats.relax_ms = (double)w.h_acc[A_T_RELAX] * 1e-5;
     stats.push_ms = (double)w.h_acc[A_T_PUSH] * 1e-5;
+    stats.tail_ms = (double)w.h_acc[A_T_TAIL] * 1e-5;
+    stats.tail_rounds = w.h_acc[A_TAIL_ROUNDS];
     if (st) *st = stats;
     return hipSuccess;
 }

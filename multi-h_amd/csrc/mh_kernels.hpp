@@ -157,6 +157,8 @@ struct ExpandStats {
     long long barriers, outer_iterations;     // grid barriers / global relabels inside the solver launches
     double solve_ms;                          // time inside the solver launches (device clock of workgroup 0)
     double barrier_ms, relax_ms, push_ms;     // of which: inside grid barriers; global relabels; push phases (the last two include their barriers)
+    double tail_ms;                           // of which: relabel/push rounds that began with fewer than 64 rows still holding excess
+    long long tail_rounds;
 };
 
 hipError_t run_expansion(const Graph& g, const int* cost /* n x L */, int L, int potts,

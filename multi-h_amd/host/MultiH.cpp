@@ -112,7 +112,14 @@ bool MultiH::Process()
         std::cerr << "Error: Features are not set!\n";                       // M/MultiH.cpp:48
         return false;
     }
+    const bool timing = std::getenv("MULTIH_TIMING") != nullptr;          // diagnostic: where Process() spends its time
+    const auto t_process = std::chrono::system_clock::now();
+    auto stage = [&](const char* what) {
+        if (timing) printf("[Multi-H] %s done %.1f ms after Process() began\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::system_clock::now() - t_process).count());
+    };
     if (!EnsureEngine()) return false;
+    stage("engine");
 
     // GetFundamentalMatrixAndRefineData (M/MultiH.cpp:52, :770-848; §8(f) row 4): with
     // SetEpipolarGeometry the caller's F / e2 are used and the points are taken as already
@@ -135,6 +142,7 @@ bool MultiH::Process()
     }
     if (!Check(mh_set_correspondences(engine, s.data(), d.data(), a.data(), N), "mh_set_correspondences"))
         return false;
+    stage("correspondences on the device");
 
     if (!have_epipolar) {
         // GetFundamentalMatrixAndRefineData (M/MultiH.cpp:770-848) on the GPU: RANSAC over normalised
@@ -209,7 +217,9 @@ bool MultiH::Process()
         return false;
     }
 
+    stage("initial models");
     ClusterMergingAndLabeling();
+    stage("neighbourhood + alternation");
 
     if (cluster_homographies.size() > 1 && run_compatibility_check) {        // :78-86
         const int before = static_cast<int>(cluster_homographies.size());
@@ -477,9 +487,9 @@ void MultiH::ClusterMergingAndLabeling()
             long long st[20] = {};
             (void)mh_get_expand_stats(engine, st);
             printf("[Multi-H] iteration %d: %d clusters, changed %d, merging %.1f ms so far, labeling %.1f ms so far (this step %.1f ms: "
-                   "%lld cycles, %lld moves solved, core %lld / max %lld, %lld relabels, %lld barriers, solver %.1f ms)\n",
+                   "%lld cycles, %lld moves solved, core %lld / max %lld, %lld relabels, %lld barriers, solver %.1f ms of which tail rounds %.1f ms)\n",
                    iteration_number, (int)cluster_homographies.size(), changed ? 1 : 0, merge_s * 1e3, label_s * 1e3,
-                   seconds_since(t_label) * 1e3, st[0], st[10], st[11], st[12], st[14], st[13], (double)st[15] * 1e-3);
+                   seconds_since(t_label) * 1e3, st[0], st[10], st[11], st[12], st[14], st[13], (double)st[15] * 1e-3, (double)st[19] * 1e-3);
             std::vector<int> tr(8 * 64, 0);              // per-move log, when the caller switched it on (mh_set_tuning key 8)
             if (mh_get_expand_trace(engine, tr.data(), 64) == MH_OK)
                 for (int mv = 0; mv < 64; ++mv)
