@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Randomised stress of the WHOLE merge <-> label alternation: Process() of the host class (GPU engine) from
+SetInitialHomographies against the oracle's independent restatement of the loop (oracle/mh_oracle.cpp section 11,
+every alpha-expansion inside it by the reference's own GCO where oracle/_ref is built) on random scenes — labels,
+model count, GetIterationNumber() and GetEnergy() must be equal.  tests/test_gpu_alternation.py runs five fixed
+scenes of the same comparison.  Run on the GPU box:  SECONDS=600 SEED=1 python tools/stress_alternation.py"""
+import ctypes as C, importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+mh = importlib.import_module("multi-h_amd")
+import oracle_lib as O
+from test_gpu_alternation import _knn_hits, _initial_models, THR, LAM, LOCALITY
+budget = float(os.environ.get("SECONDS", 300))
+rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
+host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+dp = C.POINTER(C.c_double)
+host.mhh_set_post_filter(0)
+t0 = time.time(); runs = 0; used_ref_all = True
+while time.time() - t0 < budget:
+    n = int(rng.integers(600, 4000)); planes = int(rng.integers(2, 6)); seed = int(rng.integers(0, 1 << 30))
+    dup, strays = int(rng.integers(0, 5)), int(rng.integers(0, 3))
+    sc = mh.synth.make_scene(n, planes, seed=seed, with_neighbours=False, noise=float(rng.uniform(0.2, 1.2)),
+                             outlier_frac=float(rng.uniform(0.05, 0.5)))
+    H0 = _initial_models(sc, seed, dup, strays)
+    rowptr, col = _knn_hits(sc, 16)
+    lab_o, H_o, it_o, en_o, used_ref = O.cluster_merging_and_labeling(sc.src, sc.dst, sc.aff, H0, sc.F, sc.e2, LAM, THR, rowptr, col, seed)
+    used_ref_all = used_ref_all and used_ref
+    labels = np.full(n, -7, dtype=np.int32); Hout = np.zeros((64, 9)); it, en = C.c_int(-1), C.c_double(-1)
+    src, dst, aff, F, e2 = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.aff, sc.F, sc.e2))
+    k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n, F.ctypes.data_as(dp),
+                             e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(THR), C.c_double(LOCALITY), C.c_double(LAM), 20,
+                             C.c_ulonglong(seed), 0, 0, 0, H0.ctypes.data_as(dp), H0.shape[0],
+                             labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64, C.byref(it), C.byref(en), None, 0, 4)
+    ok = k == H_o.shape[0] and it.value == it_o and en.value == en_o and np.array_equal(labels, lab_o)
+    if not ok:
+        print("MISMATCH", dict(n=n, planes=planes, seed=seed, dup=dup, strays=strays, k=k, k_o=H_o.shape[0], it=it.value, it_o=it_o,
+                               en=en.value, en_o=en_o, diff=int((labels != lab_o).sum())))
+        sys.exit(1)
+    runs += 1
+print(f"alternation stress ok: {runs} random scenes in {time.time() - t0:.0f} s (expansions of the oracle side by the reference GCO: {used_ref_all})")
