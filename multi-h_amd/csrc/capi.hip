@@ -108,7 +108,7 @@ struct mh_engine {
     // labeling
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
-    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_trace, ew_saved, d_order;
+    DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_trace, ew_saved, d_order, d_wsum;
     int trace_moves = 0;                     // > 0: k_solve logs 8 ints per move (mh_set_tuning key 8)
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
@@ -345,6 +345,14 @@ static int upload_order(mh_engine* e)
     return MH_OK;
 }
 
+// per-site weight totals of the graph that is on the device (d_rowptr, d_w)
+static int upload_wsum(mh_engine* e)
+{
+    HIPCHK(e->d_wsum.reserve(e->n));
+    HIPCHK(launch_row_weight_sums(e->n, e->d_rowptr.p, e->d_w.p, e->d_wsum.p, e->stream));
+    return MH_OK;
+}
+
 // host copy (fallback path) -> device
 int upload_graph(mh_engine* e)
 {
@@ -362,6 +370,9 @@ int upload_graph(mh_engine* e)
     HIPCHK(hipStreamSynchronize(e->stream));
     int rc = upload_order(e);
     if (rc) return rc;
+    rc = upload_wsum(e);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
     e->g_nnz = nnz;
     e->g_host_valid = true;
     e->have_graph = true;
@@ -427,6 +438,8 @@ static int device_sym_graph(mh_engine* e, const int* rowptr_dev, int stride, con
     HIPCHK(launch_sym_finish(n, e->gb_start.p, e->gb_raw.p, e->gb_mult.p, e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->stream));
     int rc = upload_order(e);
     if (rc) return rc;
+    rc = upload_wsum(e);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
     e->g_nnz = nnz;
     e->g_host_valid = false;
@@ -479,7 +492,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     if (e->cost_L != e->m + 1) return fail(MH_ERR_NOT_SET, "data cost is stale; call mh_data_cost first");
     int rc = ensure_expand_work(e);
     if (rc) return rc;
-    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, e->g_nnz, e->d_order.p };
+    Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, e->g_nnz, e->d_order.p, e->d_wsum.p };
     // the solver launch must be resident as a whole (it synchronises through a grid barrier): at most half
     // the CUs, so that engines of other processes sharing the GPU can never starve each other's launches
     const int solve_grid = std::max(1, std::min(e->tune_expand[3], e->cu_count));
@@ -634,7 +647,7 @@ void mh_destroy(mh_engine* e)
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
-    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release();
+    e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release(); e->d_wsum.release();
     e->knn_tmp.release(); e->knn_part_i.release(); e->knn_part_d.release();
     e->gb_deg.release(); e->gb_start.release(); e->gb_cursor.release(); e->gb_raw.release(); e->gb_mult.release();
     e->gb_uniq.release(); e->gb_info.release(); e->gb_hits_rp.release(); e->gb_hits_col.release();

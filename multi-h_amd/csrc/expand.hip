@@ -175,6 +175,33 @@ __device__ __forceinline__ long long row_sum64(long long v)
     return v;
 }
 
+// Most sites of a move need no arc work at all — they are decided by their own numbers, or already carry alpha —
+// so the whole-graph kernels of a move run in two steps per wavefront: one LANE per site looks at the site's scalars
+// (64 sites per wave), then the sites that do need their arcs walked get LPN lanes each, four sites at a time.
+// for_flagged calls body(m) on the 16 lanes of a group with m = the wave lane whose site the group serves; `mask`
+// (the ballot of the lanes that asked for it) is wave-uniform, so every lane runs the loop and cross-lane reads of
+// per-site scalars (__shfl(value, m)) may precede the call.
+template <typename F>
+__device__ __forceinline__ void for_flagged(unsigned long long mask, F body)
+{
+    const int grp = (int)(threadIdx.x & 63) / LPN;
+    while (mask) {
+        int b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b[q] = mask ? (int)__builtin_ctzll(mask) : -1;
+            if (mask) mask &= mask - 1;
+        }
+        const int m = grp == 0 ? b[0] : grp == 1 ? b[1] : grp == 2 ? b[2] : b[3];
+        body(m);
+    }
+}
+// Sites per wavefront in step one.  64 would use every lane, but then a 50k-site graph is 782 waves — less than one
+// per SIMD — and a wave with many flagged sites serves them one group of four after the other (k_reduce at 11 labels:
+// 27 us against 16 us for the plain LPN-lanes-per-site mapping).  16 keeps 3 125 waves and at most four rounds.
+constexpr int SPW = 16;
+constexpr int SITES_PER_WBLOCK = 4 * SPW;      // per 256-thread workgroup
+
 // `label` is read (neighbours) and written (own site, pending move) in the same launch: a neighbour
 // j with took[j] reads as `pa` whether or not its row has already stored the new label.
 __global__ void __launch_bounds__(256)
@@ -183,53 +210,72 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
              int* __restrict__ cap, int* __restrict__ excess, int* __restrict__ sink_cap,
              int* __restrict__ decided, int* __restrict__ flags, long long* __restrict__ acc)
 {
-    const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
-    if (i >= g.n) return;
+    const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW;
+    const int i = s0 + lane;
+    const bool in = lane < SPW && i < g.n;
     const int pa = flags[C_PEND];
-    int li = label[i];
-    int cc = cur_cost[i];
-    if (pa >= 0 && took[i]) {                        // applyNewLabeling of the previous move, :423-441
-        li = pa;
-        cc = cost[(size_t)i * L + pa];
-        if (sub == 0) { label[i] = pa; cur_cost[i] = cc; }
+    int li = 0, cc = 0;
+    if (in) {
+        li = label[i];
+        cc = cur_cost[i];
+        if (pa >= 0 && took[i]) {                    // applyNewLabeling of the previous move, :423-441
+            li = pa;
+            cc = cost[(size_t)i * L + pa];
+            label[i] = pa; cur_cost[i] = cc;
+        }
     }
-    if (move_is_skipped(flags, t, L)) return;
-    const int k0 = g.rowptr[i], k1 = g.rowptr[i + 1];
-    if (li == alpha) {
-        if (sub == 0) { decided[i] = 3; excess[i] = 0; sink_cap[i] = 0; }
-        for (int k = k0 + sub; k < k1; k += LPN) cap[k] = 0;
-        return;
+    if (__shfl(move_is_skipped(flags, t, L) ? 1 : 0, 0)) return;      // one evaluation per wave: C_ERROR may be raised meanwhile
+    // step one.  A site that carries alpha is not in the graph (its neighbours clear the arcs towards it, both
+    // directions).  A site whose own costs already outweigh every n-link it has is on the sink side whatever its
+    // neighbours are: S <= cc + potts * wsum and in <= potts * wsum, so K - cc > 2 * potts * wsum implies -tr > in below.
+    long long K = 0;
+    bool walk = false;
+    if (in) {
+        if (li == alpha) decided[i] = 3;
+        else {
+            K = cost[(size_t)i * L + alpha];
+            if (reduce_on && K - cc > 2ll * potts * g.wsum[i]) decided[i] = 2;
+            else walk = true;
+        }
     }
-    long long S = 0, out = 0, in = 0;
-    for (int k = k0 + sub; k < k1; k += LPN) {
-        const int j = g.col[k];
-        const int wk = g.w[k] * potts;
-        int lj = label[j];
-        if (pa >= 0 && took[j]) lj = pa;
-        if (lj == alpha) { S += wk; cap[k] = 0; }
-        else if (j < i) { if (li != lj) S += wk; cap[k] = wk; out += wk; if (li == lj) in += wk; }
-        else { const int c = (li == lj) ? wk : 0; cap[k] = c; out += c; in += wk; }
-    }
-    S = row_sum64<LPN>(S) + cc;
-    out = row_sum64<LPN>(out);
-    in = row_sum64<LPN>(in);
-    if (sub != 0) return;
-    const long long K = cost[(size_t)i * L + alpha];
-    const long long tr = S - K;
-    if (tr > 0x7fffffffll || -tr > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
-    const int ex = tr > 0 ? (int)tr : 0;
-    excess[i] = ex;
-    sink_cap[i] = tr < 0 ? (int)(-tr) : 0;
-    // first dominance test (see k_reduce): nothing is decided yet, so there is nothing to fold
-    int verdict = 0;
-    if (reduce_on) {
-        if (tr > out) verdict = 1;
-        else if (-tr > in) verdict = 2;
-    }
-    decided[i] = verdict;
-    // total excess of the move (the reference's flow counter is an int: Graph<int,int,int>), striped
-    if (ex > 0) atomicAdd((unsigned long long*)&acc[A_EXCESS_S + (blockIdx.x % STRIPES) * STRIPE_LL], (unsigned long long)ex);
+    for_flagged(__ballot(walk), [&](int m) {
+        const int mm = m < 0 ? 0 : m;
+        const int li_m = __shfl(li, mm), cc_m = __shfl(cc, mm);
+        const long long K_m = __shfl(K, mm);
+        if (m < 0) return;
+        const int im = s0 + m;
+        const int k0 = g.rowptr[im], k1 = g.rowptr[im + 1];
+        long long S = 0, out = 0, inn = 0;
+        for (int k = k0 + sub; k < k1; k += LPN) {
+            const int j = g.col[k];
+            const int wk = g.w[k] * potts;
+            int lj = label[j];
+            if (pa >= 0 && took[j]) lj = pa;
+            if (lj == alpha) { S += wk; cap[k] = 0; cap[g.rev[k]] = 0; }
+            else if (j < im) { if (li_m != lj) S += wk; cap[k] = wk; out += wk; if (li_m == lj) inn += wk; }
+            else { const int c = (li_m == lj) ? wk : 0; cap[k] = c; out += c; inn += wk; }
+        }
+        S = row_sum64<LPN>(S) + cc_m;
+        out = row_sum64<LPN>(out);
+        inn = row_sum64<LPN>(inn);
+        if (sub != 0) return;
+        const long long tr = S - K_m;
+        if (tr > 0x7fffffffll || -tr > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+        const int ex = tr > 0 ? (int)tr : 0;
+        excess[im] = ex;
+        sink_cap[im] = tr < 0 ? (int)(-tr) : 0;
+        // first dominance test (see k_reduce): nothing is decided yet, so there is nothing to fold
+        int verdict = 0;
+        if (reduce_on) {
+            if (tr > out) verdict = 1;
+            else if (-tr > inn) verdict = 2;
+        }
+        decided[im] = verdict;
+        // total excess of the move (the reference's flow counter is an int: Graph<int,int,int>), striped
+        if (ex > 0) atomicAdd((unsigned long long*)&acc[A_EXCESS_S + (blockIdx.x % STRIPES) * STRIPE_LL], (unsigned long long)ex);
+    });
 }
 
 // Dominance reduction (see the header).  net(u) = excess - sink_cap.  An undecided site first folds its
@@ -244,7 +290,7 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
 // The fixed point is reached inside k_solve; these launches take the bulk of the cascade off it.
 // COMPACT: sites still undecided when their row finishes are appended to the core list.
 template <bool COMPACT>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decided,
          int* __restrict__ flags, long long* __restrict__ acc, int* __restrict__ core, int ROUNDS)
 {
@@ -252,11 +298,14 @@ k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decid
     // one workgroup, and the sites that are busy in a move are neighbours in the image: were they also neighbours in
     // the list (input sorted along a scan line, a Z-curve ...) a few CUs would issue all the uncoalesced requests of
     // a phase.  Measured with the core in Z-curve order: 55-60 ms of solver time per LabelingStep instead of 20.
-    const int slot = blockIdx.x * (blockDim.x / LPN) + threadIdx.x / LPN;
-    const int u = (COMPACT && slot < g.n) ? g.order[slot] : slot;
+    const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
+    const int slot = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW + lane;
+    const int u = (lane < SPW && slot < g.n) ? (COMPACT ? g.order[slot] : slot) : -1;
     __shared__ int s_skip;                               // one evaluation per workgroup: C_ERROR may be raised meanwhile
-    if (threadIdx.x == 0) s_skip = move_is_skipped(flags, t, L) ? 1 : 0;
+    __shared__ int s_cnt, s_base;
+    __shared__ int s_list[SITES_PER_WBLOCK];
+    if (threadIdx.x == 0) { s_skip = move_is_skipped(flags, t, L) ? 1 : 0; s_cnt = 0; }
     __syncthreads();
     const bool skipped = s_skip != 0;
     if (!COMPACT && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -272,53 +321,48 @@ k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decid
         if (!skipped && ex > 0x7fffffffll) flags[C_ERROR] = ERR_OVERFLOW;
     }
     if (skipped) return;
-    bool mine = false;
-    if (u < g.n) {
-        const int du = LD(&decided[u]);
-        if (du == 0) {
-            const int k0 = g.rowptr[u], k1 = g.rowptr[u + 1];
-            long long net = (long long)excess[u] - sink_cap[u];
-            bool dirty = false;
-            int verdict = 0;
-            for (int r = 0; r < ROUNDS; ++r) {
-                long long add = 0, out = 0, in = 0;
-                for (int k = k0 + sub; k < k1; k += LPN) {
-                    const int kr = g.rev[k];
-                    const int co = cap[k], ci = cap[kr];
-                    if ((co | ci) == 0) continue;
-                    const int dv = LD(&decided[g.col[k]]);
-                    if (dv == 1) { add += ci; cap[k] = 0; cap[kr] = 0; }
-                    else if (dv == 2) { add -= co; cap[k] = 0; cap[kr] = 0; }
-                    else { out += co; in += ci; }
-                }
-                add = row_sum64<LPN>(add); out = row_sum64<LPN>(out); in = row_sum64<LPN>(in);
-                if (add != 0) { net += add; dirty = true; }
-                if (net > out) verdict = 1;
-                else if (-net > in) verdict = 2;
-                if (verdict) break;
+    // step one: who is still undecided; step two: LPN lanes per such site
+    const bool open = u >= 0 && LD(&decided[u]) == 0;
+    for_flagged(__ballot(open), [&](int m) {
+        const int um = __shfl(u, m < 0 ? 0 : m);
+        if (m < 0) return;
+        const int k0 = g.rowptr[um], k1 = g.rowptr[um + 1];
+        long long net = (long long)excess[um] - sink_cap[um];
+        bool dirty = false;
+        int verdict = 0;
+        for (int r = 0; r < ROUNDS; ++r) {
+            long long add = 0, out = 0, in = 0;
+            for (int k = k0 + sub; k < k1; k += LPN) {
+                const int kr = g.rev[k];
+                const int co = cap[k], ci = cap[kr];
+                if ((co | ci) == 0) continue;
+                const int dv = LD(&decided[g.col[k]]);
+                if (dv == 1) { add += ci; cap[k] = 0; cap[kr] = 0; }
+                else if (dv == 2) { add -= co; cap[k] = 0; cap[kr] = 0; }
+                else { out += co; in += ci; }
             }
-            if (sub == 0) {
-                if (dirty) {
-                    if (net > 0x7fffffffll || -net > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
-                    excess[u] = net > 0 ? (int)net : 0;
-                    sink_cap[u] = net < 0 ? (int)(-net) : 0;
-                }
-                if (verdict) ST(&decided[u], verdict);
-            }
-            mine = verdict == 0;
+            add = row_sum64<LPN>(add); out = row_sum64<LPN>(out); in = row_sum64<LPN>(in);
+            if (add != 0) { net += add; dirty = true; }
+            if (net > out) verdict = 1;
+            else if (-net > in) verdict = 2;
+            if (verdict) break;
         }
-    }
+        if (sub == 0) {
+            if (dirty) {
+                if (net > 0x7fffffffll || -net > 0x7fffffffll) atomicExch(&flags[C_ERROR], ERR_OVERFLOW);
+                excess[um] = net > 0 ? (int)net : 0;
+                sink_cap[um] = net < 0 ? (int)(-net) : 0;
+            }
+            if (verdict) ST(&decided[um], verdict);
+            else if (COMPACT) s_list[atomicAdd(&s_cnt, 1)] = um;
+        }
+    });
     if (COMPACT) {
-        __shared__ int s_cnt, s_base;
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        int off = 0;
-        if (mine && sub == 0) off = atomicAdd(&s_cnt, 1);
         __syncthreads();
         const int shard = blockIdx.x % EXPAND_CORE_SHARDS;
         if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(&flags[C_CORE + shard], s_cnt);
         __syncthreads();
-        if (mine && sub == 0) core[(size_t)shard * g.n + s_base + off] = u;
+        if ((int)threadIdx.x < s_cnt) core[(size_t)shard * g.n + s_base + threadIdx.x] = s_list[threadIdx.x];
     }
 }
 
@@ -396,6 +440,7 @@ __device__ __forceinline__ bool grid_sync_first(GridBarrier& b)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (b.P == 1) { b.xcds = 1; b.xcd_wgs = 1; return true; }   // a core of at most 64 sites: the workgroup's own barrier is the grid's
     if (threadIdx.x == 0) {
         b.s_red[6] = 0;
         atomicAdd(&b.flags[C_XCD + b.xcd * C_LINE], 1);
@@ -430,6 +475,15 @@ __device__ __forceinline__ bool grid_sync(GridBarrier& b, bool c_changed, bool c
     { const u64 b1 = __ballot(c_active); if (b1 && (threadIdx.x & 63) == 0) atomicAdd(&b.s_red[1], __popcll(b1)); }
     if (c_hmax > 0) atomicMax(&b.s_red[2], c_hmax);
     __syncthreads();
+    if (b.P == 1) {                                             // one workgroup: nothing leaves the CU
+        any_changed = b.s_red[0];
+        n_active = b.s_red[1];
+        hmax = b.s_red[2];
+        __syncthreads();                                        // everybody has read before the next barrier clears the words
+        ++b.seq;
+        b.ticks += __builtin_amdgcn_s_memrealtime() - t_in;
+        return true;
+    }
     if (threadIdx.x == 0) {
         const int slot = (int)(b.seq & 3u), next = (int)((b.seq + 2u) & 3u);
         int* mine = b.flags + C_XCD + b.xcd * C_LINE;
@@ -1010,27 +1064,36 @@ k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int 
     if (threadIdx.x == 0) s_last = move_is_skipped(flags, t, L) ? 1 : 0;
     __syncthreads();
     if (s_last) return;
-    const int i = blockIdx.x * SITES_PER_BLOCK + threadIdx.x / LPN;
+    // step one: every site records whether it moves; step two: the sites that move walk their arcs.  A pair of
+    // neighbours changes its Potts term only if one of them moves: it is counted from the moving end, or — both
+    // moving — from the end with the larger index.
+    const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
+    const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW;
+    const int i = s0 + lane;
     long long mine = 0;
-    if (i < g.n) {
-        const int oi = label[i];
-        const bool ti = decided[i] == 1;
-        const int ni = ti ? alpha : oi;
-        if (sub == 0) {
-            took[i] = ti ? 1 : 0;
-            if (ti) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
-        }
-        for (int k = g.rowptr[i] + sub; k < g.rowptr[i + 1]; k += LPN) {
-            const int j = g.col[k];
-            if (j < i) {
-                const int oj = label[j];
-                const int nj = decided[j] == 1 ? alpha : oj;
-                const int dn = (ni != nj) - (oi != oj);
-                mine += (long long)dn * g.w[k] * potts;
-            }
-        }
+    int oi = 0;
+    bool ti = false;
+    if (lane < SPW && i < g.n) {
+        oi = label[i];
+        ti = decided[i] == 1;
+        took[i] = ti ? 1 : 0;
+        if (ti) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
     }
+    for_flagged(__ballot(ti), [&](int m) {
+        const int oi_m = __shfl(oi, m < 0 ? 0 : m);
+        if (m < 0) return;
+        const int im = s0 + m;
+        for (int k = g.rowptr[im] + sub; k < g.rowptr[im + 1]; k += LPN) {
+            const int j = g.col[k];
+            const bool tj = decided[j] == 1;
+            if (tj && j > im) continue;
+            const int oj = label[j];
+            const int nj = tj ? alpha : oj;
+            const int dn = (alpha != nj) - (oi_m != oj);
+            mine += (long long)dn * g.w[k] * potts;
+        }
+    });
     s[threadIdx.x] = mine;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
@@ -1154,8 +1217,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 {
     const dim3 grid1((g.n + 255) / 256), blk(256);                          // one thread per site
     const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site, 256 threads
-    const int sites_big = 1024 / LPN;
-    const dim3 grid_big((g.n + sites_big - 1) / sites_big), blk_big(1024); // LPN lanes per site, 1024 threads
+    const dim3 grid_w((g.n + SITES_PER_WBLOCK - 1) / SITES_PER_WBLOCK);    // one lane per site first, then LPN lanes for the sites that need them
     ExpandStats stats = {};
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, s, w.flags, w.acc);
     RET_IF(hipGetLastError());
@@ -1188,11 +1250,11 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
         old_energy = energy;
         for (int alpha = 0; alpha < L; ++alpha, ++t) {
             ++stats.moves;
-            hipLaunchKernelGGL(k_move_setup, grid, blk, 0, s, g, cost, L, potts, alpha, t, w.reduce_rounds > 0 ? 1 : 0,
+            hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.reduce_rounds > 0 ? 1 : 0,
                                w.label, w.cur_cost, w.took, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_big, blk_big, 0, s, g, L, t, w.cap, w.excess,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
                                w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_big, blk_big, 0, s, g, L, t, w.cap, w.excess,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
                                w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
             hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), solve_lds, s, g, L, t, w.cap, w.sent, w.excess,
                                w.sink_cap, w.height, w.decided, w.core, w.flags, w.acc,
@@ -1201,7 +1263,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                                w.saved_flow ? w.saved_flow + (size_t)alpha * g.nnz : nullptr,
                                w.saved_flow ? w.saved_sink + (size_t)alpha * g.n : nullptr,
                                (w.saved_flow && cycle > 1) ? 1 : 0, mslots, sp);
-            hipLaunchKernelGGL(k_delta, grid, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
+            hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
                                w.decided, w.took, w.flags, w.acc);
             RET_IF(hipGetLastError());
             stats.launches += 5;

@@ -202,6 +202,25 @@ k_sym_rev(int n, const int* __restrict__ rowptr, const int* __restrict__ col, in
     }
 }
 
+__global__ void __launch_bounds__(256)
+k_row_wsum(int n, const int* __restrict__ rowptr, const int* __restrict__ w, int* __restrict__ wsum)
+{
+    const int i = blockIdx.x * (256 / GL) + threadIdx.x / GL;
+    const int sub = threadIdx.x % GL;
+    if (i >= n) return;
+    long long t = 0;
+    for (int k = rowptr[i] + sub; k < rowptr[i + 1]; k += GL) t += w[k];
+#pragma unroll
+    for (int m = GL / 2; m >= 1; m >>= 1) t += __shfl_xor(t, m, GL);
+    if (sub == 0) wsum[i] = t > 0x7fffffffll ? 0x7fffffff : (int)t;
+}
+
+hipError_t launch_row_weight_sums(int n, const int* rowptr, const int* w, int* wsum, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_row_wsum, dim3((n + 256 / GL - 1) / (256 / GL)), dim3(256), 0, s, n, rowptr, w, wsum);
+    return hipGetLastError();
+}
+
 hipError_t launch_hits_filter(const Points& p, int stride, float r2, int* col, int* err, hipStream_t s)
 {
     const long long total = (long long)p.n * stride;

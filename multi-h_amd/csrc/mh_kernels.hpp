@@ -106,6 +106,7 @@ struct Graph {              // symmetric weighted CSR in HBM
     int n, nnz;
     const int* order;       // n    a fixed pseudo-random permutation of the sites: the alpha-expansion's solver takes its
                             //      core sites in this order so that a workgroup never owns a spatial cluster (expand.hip)
+    const int* wsum;        // n    sum of w over the site's row: bounds every n-link total of the site (expand.hip, k_move_setup)
 };
 
 struct ExpandWork {         // scratch owned by the engine
@@ -194,6 +195,8 @@ hipError_t launch_hits_filter(const Points& p, int stride, float r2, int* col, i
 hipError_t launch_sym_count(int n, const int* rowptr, int stride, const int* col, int* deg, int* start /* n+1 */, int* info, hipStream_t s);
 hipError_t launch_sym_build(int n, const int* rowptr, int stride, const int* col, const int* start, int* cursor, int* raw,
                             int* mult, int* uniq, int* out_rowptr /* n+1 */, int* info, hipStream_t s);
+// wsum[i] = sum of w over row i
+hipError_t launch_row_weight_sums(int n, const int* rowptr, const int* w, int* wsum, hipStream_t s);
 hipError_t launch_sym_finish(int n, const int* start, const int* raw, const int* mult, const int* rowptr, int* col, int* w,
                              int* rev, hipStream_t s);
 

@@ -10,7 +10,8 @@ Multi-GPU: the propose stage shards (each rank owns M/G hypotheses of every batc
 the int32 scores per greedy round); labeling and re-estimation run replicated and
 deterministic.  Every rank must end with the same labels — checked here — and the result must not
 depend on G.  Env: N K ITERS HYP ITER_HYP; LOOP_BACKEND=gloo LOOP_DEVICE=0 put several ranks on one
-GPU (the parity test's setup)."""
+GPU (the parity test's setup).  INIT=stable: the reference's own initialisation (per-point homographies, mean shift,
+3-point fits) instead of the DLT batch."""
 import ctypes as C, hashlib, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,7 +51,7 @@ k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.cty
                          F.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2),
                          C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(1234), HYP, 32, ITERS,
                          None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256,
-                         C.byref(it), C.byref(en), C.byref(secs), ITER_HYP, 4)
+                         C.byref(it), C.byref(en), C.byref(secs), ITER_HYP, -1 if os.environ.get("INIT") == "stable" else 4)
 wall = time.time() - t0
 digest = hashlib.sha256(labels.tobytes() + Hout[:max(k, 0)].tobytes()).hexdigest()[:16]
 same = True
