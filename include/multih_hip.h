@@ -212,8 +212,8 @@ MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int*
  * push-relabel after the reduction, 8 kernel launches, 9 moves actually run (the others were skipped on the
  * device as provably idempotent), 10 moves whose undecided core was not empty, 11 sum and 12 maximum of the
  * core sizes, 13 grid barriers, 14 global relabels, 15 microseconds spent inside the solver launches, of which
- * 16 inside grid barriers, 17 in global relabels and 18 in push phases (both including their barriers), 19 in relabel/push rounds that began with fewer than 64 solver
- * rows still holding excess (the tail of a move)}. */
+ * 16 inside grid barriers, 17 in global relabels and 18 in push phases (both including their barriers), 19 in
+ * relabel/push rounds that began with fewer than 64 solver rows still holding excess (the tail of a move)}. */
 MH_API int mh_get_expand_stats(mh_engine* e, long long stats[20]);
 /* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid
@@ -240,12 +240,12 @@ enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K
 MH_API int mh_profile_enable(mh_engine* e, int on);
 MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);
-/* Tuning and diagnostic knobs for tools/ (defaults are the measured optima).  Keys 2..10 change the SCHEDULE of the
+/* Tuning and diagnostic knobs for tools/ (defaults are the measured optima).  Keys 2..11 change the SCHEDULE of the
  * alpha-expansion or what is logged, never a result: 2..5 solver schedule (frontier rounds per barrier interval, most
  * push cycles per phase, push phases per global relabel, workgroups of the solver launch), 6 dominance-reduction
  * rounds per launch (0 = off), 7 mean-shift iterations per host round trip, 8 moves logged by mh_get_expand_trace
  * (0 = off), 9 move whose relabels are logged one by one, 10 push cycles per phase as a multiple of the last
- * relabel's depth.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);
