@@ -504,7 +504,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     // flow recycling (expand.hip, k_solve): L x (nnz + n) ints, cleared per expansion; left out (every move starts from
     // the zero flow) beyond 8 GiB.  Flows are not kept from one call to the next: measured in the alternation, the
     // re-estimated models move the problems far enough for a kept flow to cost more rounds than the zero flow.
-    const size_t recycle_words = (size_t)e->cost_L * ((size_t)g.nnz + (size_t)g.n + 1);       // + one depth hint per label
+    const size_t recycle_words = (size_t)e->cost_L * ((size_t)g.nnz + (size_t)g.n);
     if (e->tune_recycle && recycle_words <= ((size_t)2 << 30)) {
         HIPCHK(e->ew_saved.reserve(recycle_words));
         HIPCHK(hipMemsetAsync(e->ew_saved.p, 0, sizeof(int) * recycle_words, e->stream));

@@ -545,8 +545,7 @@ template <bool MULTI>
 __device__ __forceinline__ void
 solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_cap, int* height, int* decided,
            const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
-           int* __restrict__ saved_flow, int* __restrict__ saved_sink, int* __restrict__ depth_hint, int warm, int mslots,
-           const SolveParams& sp,
+           int* __restrict__ saved_flow, int* __restrict__ saved_sink, int warm, int mslots, const SolveParams& sp,
            int* s_priv, int* s_red, const int (&pre)[EXPAND_CORE_SHARDS + 1], int K, int P)
 {
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
@@ -762,11 +761,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
     if (!MULTI && site0 >= 0) need_arcs();
 
     // ---- phase 1: global relabel <-> push until no site with excess can reach the sink ---------------
-    // (a recycled flow leaves the residual graph about as deep as the label's last expansion found it: its first relabel
-    // is given that many rounds per interval instead of growing to them over several intervals, each with a barrier)
     int outer = 0, epoch = 0, hprev = 4;
-    if (warm && depth_hint) { const int d = *depth_hint; if (d > hprev) hprev = d; }
-    int hlast = 0;
     bool exact = false;
     for (;; ++outer) {
         if (outer >= sp.max_outer) { if (leader) atomicExch(&flags[C_ERROR], ERR_NO_CONVERGENCE); break; }
@@ -849,7 +844,6 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
             if (!any || nact) { exact = !any; break; }
         }
         hprev = hmax;
-        hlast = hmax;
         tk_relax += __builtin_amdgcn_s_memrealtime() - tr0;
         if (detail && leader && outer < 2048) {
             int* d = detail + 4 * (size_t)outer;
@@ -1022,7 +1016,6 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
         atomicAdd((unsigned long long*)&acc[A_T_TAIL], tk_tail);
         atomicAdd((unsigned long long*)&acc[A_TAIL_ROUNDS], (unsigned long long)st_tail);
         atomicMax(&flags[C_XCD_USED], bar.xcds);
-        if (depth_hint) *depth_hint = hlast;
         if (trace) {
             int* tr = trace + 8 * (size_t)t;
             tr[0] = K; tr[1] = P; tr[2] = (int)st_outer; tr[3] = (int)st_relax; tr[4] = (int)st_push; tr[5] = (int)bar.seq;
@@ -1034,8 +1027,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
 __global__ void __launch_bounds__(SOLVE_THREADS)
 k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, int* height, int* decided,
         const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
-        int* __restrict__ saved_flow, int* __restrict__ saved_sink, int* __restrict__ depth_hint, int warm, int mslots,
-        SolveParams sp)
+        int* __restrict__ saved_flow, int* __restrict__ saved_sink, int warm, int mslots, SolveParams sp)
 {
     extern __shared__ int s_priv[];                  // F_FIELDS x mslots x SOLVE_ROWS
     __shared__ int s_red[8];
@@ -1054,9 +1046,9 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
     if (P > (int)gridDim.x) P = (int)gridDim.x;
     if ((int)blockIdx.x >= P) return;
     if (K <= P * SOLVE_ROWS) solve_body<false>(g, t, cap, sent, excess, sink_cap, height, decided, core, flags, acc, trace, detail,
-                                                saved_flow, saved_sink, depth_hint, warm, mslots, sp, s_priv, s_red, pre, K, P);
+                                                saved_flow, saved_sink, warm, mslots, sp, s_priv, s_red, pre, K, P);
     else solve_body<true>(g, t, cap, sent, excess, sink_cap, height, decided, core, flags, acc, trace, detail,
-                          saved_flow, saved_sink, depth_hint, warm, mslots, sp, s_priv, s_red, pre, K, P);
+                          saved_flow, saved_sink, warm, mslots, sp, s_priv, s_red, pre, K, P);
 }
 
 // Energy difference of the candidate labeling (sites with decided == 1 take alpha) and, by the last
@@ -1270,7 +1262,6 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                                (w.trace && t == w.detail_move) ? w.trace + 8 * (size_t)w.trace_moves : nullptr,
                                w.saved_flow ? w.saved_flow + (size_t)alpha * g.nnz : nullptr,
                                w.saved_flow ? w.saved_sink + (size_t)alpha * g.n : nullptr,
-                               w.saved_flow ? w.saved_sink + (size_t)L * g.n + alpha : nullptr,
                                (w.saved_flow && cycle > 1) ? 1 : 0, mslots, sp);
             hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
                                w.decided, w.took, w.flags, w.acc);

@@ -135,8 +135,7 @@ struct ExpandWork {         // scratch owned by the engine
     int detail_move;        // move whose global relabels are logged behind the trace (4 ints each, at most 2048): {active sites,
                             //   largest finite height, relabel intervals so far, ticks so far}; -1 none
     // flow recycling (expand.hip, k_solve): per label the net arc flows (L x nnz) and sink flows (L x n) its last
-    // expansion ended with, followed by L words "depth of that expansion's last relabel"; null = every move starts
-    // from the zero flow
+    // expansion ended with; null = every move starts from the zero flow
     int* saved_flow;
     int* saved_sink;
 };
