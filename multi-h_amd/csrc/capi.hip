@@ -132,8 +132,8 @@ struct mh_engine {
     int tune_ms_batch = 6;                   // mean-shift climb iterations per host round trip
     int tune_reduce = 4;                     // dominance-reduction rounds per launch (0 = off)
     int tune_recycle = 1;                    // from the second cycle on a label's max-flow starts from the flow its last expansion left (0 = off, A/B)
-    int tune_expand[4] = { 128, 256, 1, 256 };
-    int tune_push_mult = 4;                  // push cycles per phase = this x (depth of the last relabel + 3)  // solver: relax rounds per barrier interval, push cycles per phase, push phases per relabel, workgroups
+    int tune_expand[4] = { 128, 512, 1, 256 };
+    int tune_push_mult = 6;                  // push cycles per phase = this x (depth of the last relabel + 3)  // solver: relax rounds per barrier interval, push cycles per phase, push phases per relabel, workgroups
     ExpandStats last_expand{};
 
     double bbox[4] = { NAN, NAN, NAN, NAN };   // xmin xmax ymin ymax of the source points

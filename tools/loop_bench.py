@@ -30,6 +30,8 @@ if world > 1:
 host = C.CDLL(os.path.join(ROOT, "multi-h_amd", "libmultih_host.so"))
 host.mhh_set_device(device)
 if "RECYCLE" in os.environ: host.mhh_set_engine_tuning(11, int(os.environ["RECYCLE"]))      # alpha-expansion flow recycling A/B
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):                                    # e.g. TUNE=3=512,10=6 (mh_set_tuning keys)
+    host.mhh_set_engine_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 if "TRACE" in os.environ: host.mhh_set_engine_tuning(8, 64)                                     # per-move solver log (with MULTIH_TIMING=1)
 if "KNN" in os.environ: host.mhh_set_neighbourhood(int(os.environ["KNN"]), C.c_double(0.0))
 hook = None
