@@ -91,7 +91,8 @@ MH_API int mh_build_neighbors_knn_radius(mh_engine* e, int k, double radius);
  * (nullable) receives the number of directed hits found. */
 MH_API int mh_build_neighbors_radius(mh_engine* e, double radius, long long max_hits, long long* hits_out);
 /* Copy the symmetric weighted graph the engine derived (rowptr n+1, col/w nnz).  Pass NULLs to
- * query nnz only. */
+ * query nnz only.  The graph is built and kept on the device (csrc/graph.hip); the host copy is fetched by the
+ * first call after a build. */
 MH_API int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nnz);
 
 /* ---- epipolar front half --------------------------- */
