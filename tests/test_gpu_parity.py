@@ -194,7 +194,7 @@ def test_dominance_reduction_changes_nothing(engine, synth, oracle, lam):
             got[rounds] = st
         assert got[4]["flow_moves"] <= got[0]["flow_moves"]
     finally:
-        engine.set_tuning(6, 4)
+        engine.set_tuning(6, 2)
         engine.set_params(2.6, THR, 0.005, LAM, 20)
 
 
@@ -230,7 +230,7 @@ def test_expand_solver_paths(engine, synth, oracle, case):
         st = engine.expand_stats()
     finally:
         engine.set_tuning(5, 256)
-        engine.set_tuning(6, 4)
+        engine.set_tuning(6, 2)
     assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), case
     if case in ("rows_walk_several_sites", "no_reduction_large_core"):
         assert st["core_max"] > grid * 64, "the case did not reach the several-sites-per-row path"
