@@ -241,12 +241,13 @@ enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K
 MH_API int mh_profile_enable(mh_engine* e, int on);
 MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);
-/* Tuning and diagnostic knobs for tools/ (defaults are the measured optima).  Keys 2..11 change the SCHEDULE of the
+/* Tuning and diagnostic knobs for tools/ (defaults are the measured optima).  Keys 2..12 change the SCHEDULE of the
  * alpha-expansion or what is logged, never a result: 2..5 solver schedule (frontier rounds per barrier interval, most
  * push cycles per phase, push phases per global relabel, workgroups of the solver launch), 6 dominance-reduction
  * rounds per launch (0 = off), 7 mean-shift iterations per host round trip, 8 moves logged by mh_get_expand_trace
  * (0 = off), 9 move whose relabels are logged one by one, 10 push cycles per phase as a multiple of the last
- * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow), 12
+ * dominance-reduction launches per move (1 or 2).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

@@ -131,6 +131,7 @@ struct mh_engine {
     int residual_mode = MH_RESIDUAL_FORWARD;
     int tune_ms_batch = 6;                   // mean-shift climb iterations per host round trip
     int tune_reduce = 2;                     // dominance-reduction rounds per launch (0 = off); 2 measured best (loop 0.262 s at 4, 0.250 s at 2)
+    int tune_reduce_launches = 1;            // reduction launches per move in front of the solver (1 = the compacting one alone, 2; loop 0.250 vs 0.254 s)
     int tune_recycle = 1;                    // from the second cycle on a label's max-flow starts from the flow its last expansion left (0 = off, A/B)
     int tune_expand[4] = { 128, 512, 1, 256 };
     int tune_push_mult = 6;                  // push cycles per phase = this x (depth of the last relabel + 3)  // solver: relax rounds per barrier interval, push cycles per phase, push phases per relabel, workgroups
@@ -499,7 +500,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_sent.p, e->ew_excess.p, e->ew_sink.p,
                   e->ew_height.p, e->ew_decided.p, e->ew_took.p, e->ew_core.p, e->ew_flags.p, e->ew_acc.p,
                   e->h_flags, e->h_acc, e->h_flags_dev, e->h_acc_dev,
-                  e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], solve_grid, e->tune_push_mult, e->tune_reduce,
+                  e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], solve_grid, e->tune_push_mult, e->tune_reduce, e->tune_reduce_launches,
                   nullptr, 0, -1, nullptr, nullptr };
     // flow recycling (expand.hip, k_solve): L x (nnz + n) ints, cleared per expansion; left out (every move starts from
     // the zero flow) beyond 8 GiB.  Flows are not kept from one call to the next: measured in the alternation, the
@@ -1729,6 +1730,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 9 && value >= -1) { e->detail_move = value; return MH_OK; }
     if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }
     if (key == 11 && (value == 0 || value == 1)) { e->tune_recycle = value; return MH_OK; }
+    if (key == 12 && (value == 1 || value == 2)) { e->tune_reduce_launches = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -7,7 +7,7 @@
 // graph.h:478-488).  Energies are int32 like the reference's
 // (GCoptimization.h:166-170); totals are accumulated in int64 and checked.
 //
-// The whole sweep is driven from the device: the host enqueues FIVE launches per move and looks at
+// The whole sweep is driven from the device: the host enqueues FOUR launches per move and looks at
 // the control words once per cycle (the energy test of :1045).
 //
 // Per move (label alpha, fixed order 0..L-1, :1285-1286; t = running move index):
@@ -21,7 +21,7 @@
 //                               cap(j->i)= (l_i==l_j) ? w*potts : 0              (energy.h:221-252)
 //                  turns t-links into excess / sink capacity (Graph::add_tweights keeps only the
 //                  difference) and takes the first dominance verdict from the site's own numbers.
-//   k_reduce x2    dominance reduction (exact): a site whose net source surplus exceeds the total
+//   k_reduce       dominance reduction (exact; a second launch in front of it is a schedule option): a site whose net source surplus exceeds the total
 //                  capacity of its outgoing n-links is on the source side of EVERY minimum cut; one
 //                  whose net sink surplus exceeds its incoming capacity can always reach the sink.
 //                  Such sites are decided, their n-links are folded into the neighbours' t-links,
@@ -292,7 +292,7 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
 template <bool COMPACT>
 __global__ void __launch_bounds__(256)
 k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decided,
-         int* __restrict__ flags, long long* __restrict__ acc, int* __restrict__ core, int ROUNDS)
+         int* __restrict__ flags, long long* __restrict__ acc, int* __restrict__ core, int ROUNDS, int housekeep)
 {
     // COMPACT walks the sites in a fixed pseudo-random order (g.order).  The solver gives 64 consecutive core sites to
     // one workgroup, and the sites that are busy in a move are neighbours in the image: were they also neighbours in
@@ -308,12 +308,10 @@ k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decid
     if (threadIdx.x == 0) { s_skip = move_is_skipped(flags, t, L) ? 1 : 0; s_cnt = 0; }
     __syncthreads();
     const bool skipped = s_skip != 0;
-    if (!COMPACT && blockIdx.x == 0 && threadIdx.x == 0) {
-        // housekeeping of the move, for the launches behind this one
+    if (housekeep && blockIdx.x == 0 && threadIdx.x == 0) {
+        // housekeeping of the move, for the launches behind this one (the first reduction launch of a move does it;
+        // the core counters and the solver's barrier words are cleared by k_delta, behind the solver launch that used them)
         flags[C_PEND] = -1;                              // k_move_setup has applied it
-        for (int s = 0; s < EXPAND_CORE_SHARDS; ++s) flags[C_CORE + s] = 0;
-        for (int s = C_XCD; s < C_TOP + C_LINE; ++s) flags[s] = 0;      // k_solve's barrier state
-        flags[C_ARRIVE] = 0;
         flags[C_TICKET] = 0;
         for (int s = 0; s < SUBTICKETS; ++s) flags[C_SUBTICKET + s * C_LINE] = 0;
         long long ex = 0;
@@ -1123,7 +1121,13 @@ k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int 
             flags[C_PEND] = alpha;
             flags[C_ACCEPTED] += 1;
         }
-        if (threadIdx.x == 0) flags[C_MOVES_RUN] += 1;
+        if (threadIdx.x == 0) {
+            flags[C_MOVES_RUN] += 1;
+            // for the next move: the core list is empty again, the solver's barrier words are clear
+            for (int s = 0; s < EXPAND_CORE_SHARDS; ++s) flags[C_CORE + s] = 0;
+            for (int s = C_XCD; s < C_TOP + C_LINE; ++s) flags[s] = 0;
+            flags[C_ARRIVE] = 0;
+        }
     }
 }
 
@@ -1252,10 +1256,11 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             ++stats.moves;
             hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.reduce_rounds > 0 ? 1 : 0,
                                w.label, w.cur_cost, w.took, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
-                               w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
+            if (w.reduce_launches > 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
+                                   w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds, 1);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
-                               w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds);
+                               w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds, w.reduce_launches > 1 ? 0 : 1);
             hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), solve_lds, s, g, L, t, w.cap, w.sent, w.excess,
                                w.sink_cap, w.height, w.decided, w.core, w.flags, w.acc,
                                (w.trace && t < w.trace_moves) ? w.trace : nullptr,
@@ -1266,8 +1271,8 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
                                w.decided, w.took, w.flags, w.acc);
             RET_IF(hipGetLastError());
-            stats.launches += 5;
-            if (w.reduce_rounds > 0) stats.reduce_launches += 2;
+            stats.launches += w.reduce_launches > 1 ? 5 : 4;
+            if (w.reduce_rounds > 0) stats.reduce_launches += w.reduce_launches > 1 ? 2 : 1;
         }
         hipLaunchKernelGGL(k_apply_pending, grid1, blk, 0, s, g.n, cost, L, w.label, w.cur_cost, w.took, w.flags);
         hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.flags, w.acc);
