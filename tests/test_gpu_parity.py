@@ -637,6 +637,20 @@ def test_full_size_labeling_equals_the_reference_gco(engine, synth, oracle):
     lab_r, e_r = oracle.ref_expand_formula(sc.src, sc.dst, H, LAM, THR2, sc.hit_rowptr, sc.hit_col)
     assert int(energy) == e_r and np.array_equal(lab_r - 1, lab)
     assert cycles >= 2 and (lab >= 0).sum() > 30000
+    # the same step with every solver row owning several sites (48 workgroups for cores of ten thousand sites) and
+    # with the flows recycled or not: the schedule never shows in the result
+    try:
+        for grid, recycle in ((48, 1), (48, 0), (256, 0)):
+            engine.set_tuning(5, grid)
+            engine.set_tuning(11, recycle)
+            engine.set_models(H)
+            lab2, energy2, cycles2 = engine.labeling_step(False, np.full(sc.n, -1, np.int32))
+            assert int(energy2) == e_r and cycles2 == cycles and np.array_equal(lab2, lab), (grid, recycle)
+            if grid == 48:
+                assert engine.expand_stats()["core_max"] > 48 * 64
+    finally:
+        engine.set_tuning(5, 256)
+        engine.set_tuning(11, 1)
 
 
 @pytest.mark.parametrize("n,planes,M,max_models", [(3000, 3, 4000, 12), (5000, 3, 10000, 16)])
