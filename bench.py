@@ -127,14 +127,27 @@ def full_loop_extra(a):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(N=str(a.points), K=str(a.planes), HYP=str(a.models), ITERS="20")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loop_bench.py")], env=env, capture_output=True, text=True, timeout=600)
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not line:
-        return {"error": (r.stdout + r.stderr)[-400:]}
-    rec = json.loads(line[-1])
-    return {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 20 propose-expand iterations",
-            "iterations": 20, "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
-            "process_s": rec["total_s"], "ms_per_iteration": rec["loop_s"] / 20 * 1e3, "digest": rec["digest"]}
+
+    def run(iter_hyp: int):
+        e = dict(env, ITER_HYP=str(iter_hyp))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loop_bench.py")], env=e, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return None, (r.stdout + r.stderr)[-400:]
+        return json.loads(line[-1]), None
+
+    rec, err = run(0)
+    if rec is None:
+        return {"error": err}
+    out = {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 100000 proposals, then 20 merge/label/re-estimate iterations",
+           "iterations": 20, "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
+           "process_s": rec["total_s"], "ms_per_iteration": rec["loop_s"] / 20 * 1e3, "digest": rec["digest"]}
+    # the same with a fresh batch of proposals in EVERY iteration (PEARL re-proposal on the points left unexplained)
+    rec2, err2 = run(a.models)
+    out["with_reproposal"] = ({"iter_hypotheses": a.models, "clusters": rec2["clusters"], "energy": rec2["energy"],
+                               "loop_s": rec2["loop_s"], "process_s": rec2["total_s"], "digest": rec2["digest"]}
+                              if rec2 is not None else {"error": err2})
+    return out
 
 
 def spawn_ranks(n: int) -> int:

@@ -63,8 +63,8 @@ def test_bench_launcher_reports_a_failing_rank():
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
-def _loop(world):
-    env = _clean_env(N="50000", K="10", HYP="100000", ITERS="20", LOOP_BACKEND="gloo", LOOP_DEVICE="0")
+def _loop(world, iter_hyp=0):
+    env = _clean_env(N="50000", K="10", HYP="100000", ITERS="20", ITER_HYP=str(iter_hyp), LOOP_BACKEND="gloo", LOOP_DEVICE="0")
     script = os.path.join(ROOT, "tools", "loop_bench.py")
     if world == 1:
         cmd = [sys.executable, script]
@@ -77,7 +77,7 @@ def _loop(world):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, f"loop_bench_world{world}.json"), "w") as f:
+    with open(os.path.join(OUT, f"loop_bench_world{world}{'_reproposal' if iter_hyp else ''}.json"), "w") as f:
         json.dump(rec, f)
     return rec
 
@@ -89,4 +89,14 @@ def test_configs4_full_loop_at_size_is_independent_of_world_size():
     assert one["clusters"] >= 5, "10 planes were generated; merging and the compatibility check keep the supported ones"
     two = _loop(2)
     assert two["ranks_identical"] and two["exchanges"] > 0
+    assert two["digest"] == one["digest"] and two["clusters"] == one["clusters"] and two["energy"] == one["energy"]
+
+
+def test_configs4_with_a_proposal_batch_in_every_iteration_is_independent_of_world_size():
+    """configs[4] read literally — "20 propose-expand iterations": every iteration draws a fresh batch of 100 000 DLT
+    hypotheses on the points the labeling leaves unexplained (sharded over the ranks like the first batch)."""
+    one = _loop(1, iter_hyp=100000)
+    assert one["iter_hypotheses"] == 100000 and one["iterations"] == 19 and one["clusters"] >= 5
+    two = _loop(2, iter_hyp=100000)
+    assert two["ranks_identical"] and two["exchanges"] > one["exchanges"]
     assert two["digest"] == one["digest"] and two["clusters"] == one["clusters"] and two["energy"] == one["energy"]

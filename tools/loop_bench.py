@@ -34,6 +34,12 @@ for kv in filter(None, os.environ.get("TUNE", "").split(",")):                  
     host.mhh_set_engine_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 if "TRACE" in os.environ: host.mhh_set_engine_tuning(8, 64)                                     # per-move solver log (with MULTIH_TIMING=1)
 if "KNN" in os.environ: host.mhh_set_neighbourhood(int(os.environ["KNN"]), C.c_double(0.0))
+if world > 1 and "LOOP_DEVICE" in os.environ:
+    # Rehearsal with several ranks on ONE GPU: the alpha-expansion's solver launch synchronises through a grid barrier
+    # and must be resident as a whole, so engines that share a device split its CUs between them (each rank's solver
+    # would otherwise wait for workgroups the other rank's launch keeps off the chip until the barrier times out).
+    # Results never depend on the solver's grid.  One process per GPU — the deployment — needs none of this.
+    host.mhh_set_engine_tuning(5, max(1, 256 // world))
 hook = None
 if world > 1:
     backend = os.environ.get("LOOP_BACKEND", "nccl")
