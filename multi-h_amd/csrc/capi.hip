@@ -121,6 +121,8 @@ struct mh_engine {
     long long* h_acc = nullptr;
     int* h_flags_dev = nullptr;
     long long* h_acc_dev = nullptr;
+    DevBuf<double> sel_pts[4];               // the active points of a greedy-selection round, packed (select.hip)
+    DevBuf<int> sel_pack_count;
     DevBuf<int> knn_tmp, knn_part_i;
     DevBuf<float> knn_part_d;
 
@@ -650,6 +652,8 @@ void mh_destroy(mh_engine* e)
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
     e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release(); e->d_wsum.release();
     e->knn_tmp.release(); e->knn_part_i.release(); e->knn_part_d.release();
+    for (int c = 0; c < 4; ++c) e->sel_pts[c].release();
+    e->sel_pack_count.release();
     e->gb_deg.release(); e->gb_start.release(); e->gb_cursor.release(); e->gb_raw.release(); e->gb_mult.release();
     e->gb_uniq.release(); e->gb_info.release(); e->gb_hits_rp.release(); e->gb_hits_col.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
@@ -1395,7 +1399,15 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     unsigned long long* key_local = e->sel_keys.p;
     unsigned long long* key_global = world > 1 ? e->sel_keys.p + 1 : e->sel_keys.p;
 
-    int Mc = M, cur = 0, selected = 0;
+    // The support set only shrinks (the inliers of every selected model leave it), and the score kernel pays per point
+    // it sweeps: every round scores the PACKED active points.  Their number is known on the host without a copy — the
+    // caller's mask at the start, minus each selected model's count afterwards.
+    int active = n;
+    if (point_mask) { active = 0; for (int i = 0; i < n; ++i) active += point_mask[i] != 0 ? 1 : 0; }
+    for (int c = 0; c < 4; ++c) HIPCHK(e->sel_pts[c].reserve((size_t)n + 2));
+    HIPCHK(e->sel_pack_count.reserve(1));
+
+    int Mc = M, cur = 0, selected = 0, packed_as = -1;
     bool first = true;
     std::vector<int> counts_host;
     for (int round = 0; round < max_models; ++round) {
@@ -1403,7 +1415,19 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         const int* orig = first ? nullptr : e->sel_orig[cur].p;
         if (Mc > 0) {
             ScopedTimer t(e, MH_K_SCORE);
-            HIPCHK(launch_score(e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p, e->tune_score_variant, s));
+            if (active == n) {
+                HIPCHK(launch_score(e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p, e->tune_score_variant, s));
+            } else if (active > 0) {
+                HIPCHK(launch_sel_pack_points(e->pts(), e->mask.p, e->sel_pts[0].p, e->sel_pts[1].p, e->sel_pts[2].p, e->sel_pts[3].p,
+                                              e->sel_pack_count.p, s));
+                packed_as = active;
+                Points packed = e->pts();                     // (same bounding box: a superset's is valid)
+                packed.x1 = e->sel_pts[0].p; packed.y1 = e->sel_pts[1].p; packed.x2 = e->sel_pts[2].p; packed.y2 = e->sel_pts[3].p;
+                packed.n = active;
+                HIPCHK(launch_score(packed, Hs, Mc, thr2, nullptr, e->sel_counts.p, e->tune_score_variant, s));
+            } else {
+                HIPCHK(hipMemsetAsync(e->sel_counts.p, 0, sizeof(int) * (size_t)Mc, s));
+            }
         }
         HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, key_local, world > 1 ? e->sel_scores.p : nullptr, s));
         if (world > 1) {
@@ -1431,6 +1455,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         if (best < need) break;
         if (counts_out) counts_out[selected] = best;
         ++selected;
+        active -= best;                                   // the selected model's inliers have left the support set
         Mc = e->h_sel[2];
         cur ^= 1;
         first = false;
@@ -1445,7 +1470,11 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         }
     }
     if (point_mask) { HIPCHK(hipMemcpyAsync(point_mask, e->mask.p, n, hipMemcpyDeviceToHost, s)); ++e->copies_d2h; }
+    int packed_n = packed_as;
+    if (packed_as >= 0) { HIPCHK(hipMemcpyAsync(&packed_n, e->sel_pack_count.p, sizeof(int), hipMemcpyDeviceToHost, s)); ++e->copies_d2h; }
     HIPCHK(hipStreamSynchronize(s));
+    if (packed_n != packed_as)                           // the host's bookkeeping of the support set against the device's own count
+        return fail(MH_ERR_HIP, "greedy selection: the packed support set does not have the expected size");
     return MH_OK;
     });
 }

@@ -171,6 +171,9 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
                                 hipStream_t s);
 
 // --- select.hip ------------------------------------------------------------
+// packs the points with mask != 0 into cx1.. (any order); *count = their number
+hipError_t launch_sel_pack_points(const Points& p, const unsigned char* mask, double* cx1, double* cy1, double* cx2, double* cy2,
+                                  int* count, hipStream_t s);
 hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned long long* key, int* scores_full, hipStream_t s);
 hipError_t launch_sel_argmax_gathered(const int* gathered, int total, unsigned long long* key, hipStream_t s);
 hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need,

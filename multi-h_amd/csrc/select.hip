@@ -145,6 +145,36 @@ __global__ void k_sel_publish(int* __restrict__ rec, unsigned long long* __restr
     keys[0] = 0; keys[1] = 0;
 }
 
+// The points that are still in the support set, packed: the re-scoring of a round then sweeps only them (the score
+// kernel is bound by FP64 work per pair, so a pass costs what the points it sees cost).  The order of the packed
+// points is whatever the atomics make it — an inlier COUNT does not depend on it.  `count` must be zero on entry.
+__global__ void __launch_bounds__(256)
+k_sel_pack_points(Points p, const unsigned char* __restrict__ mask, double* __restrict__ cx1, double* __restrict__ cy1,
+                  double* __restrict__ cx2, double* __restrict__ cy2, int* __restrict__ count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < p.n && mask[i] != 0;
+    const unsigned long long m = __ballot(on);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(count, (int)__popcll(m));
+    base = __shfl(base, (int)__builtin_ctzll(m));
+    if (on) {
+        const int pos = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+        cx1[pos] = p.x1[i]; cy1[pos] = p.y1[i]; cx2[pos] = p.x2[i]; cy2[pos] = p.y2[i];
+    }
+}
+
+hipError_t launch_sel_pack_points(const Points& p, const unsigned char* mask, double* cx1, double* cy1, double* cx2, double* cy2,
+                                  int* count, hipStream_t s)
+{
+    hipError_t he = hipMemsetAsync(count, 0, sizeof(int), s);
+    if (he != hipSuccess) return he;
+    hipLaunchKernelGGL(k_sel_pack_points, dim3((p.n + 255) / 256), dim3(256), 0, s, p, mask, cx1, cy1, cx2, cy2, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned long long* key, int* scores_full, hipStream_t s)
 {
     if (Mc <= 0) return hipSuccess;

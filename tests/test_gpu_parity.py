@@ -683,10 +683,10 @@ def test_greedy_selection_on_the_device(engine, synth, n, planes, M, max_models)
     assert counters.tolist() == picks and counts.tolist() == counts_ref
     assert np.array_equal(H.view(np.uint64), H_all[picks].view(np.uint64))
     assert np.array_equal(mask_out, mask)
-    # fewer rounds, same number of copies (mask up, H + counters + mask down)
+    # fewer rounds, same number of copies (mask up; H, counters, mask and one check word down)
     engine.select_greedy(THR2, need, 2, np.ones(n, dtype=np.uint8))
     copies_two = engine.copy_stats(reset=True)
-    assert copies_full == copies_two and sum(copies_full) <= 4
+    assert copies_full == copies_two and sum(copies_full) <= 5
     # a restricted support mask in: only those points are ever counted or claimed
     half = (np.arange(n) % 2).astype(np.uint8)
     H2, counters2, counts2, m2 = engine.select_greedy(THR2, need, max_models, half)
