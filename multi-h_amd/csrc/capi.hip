@@ -1409,7 +1409,6 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
 
     int Mc = M, cur = 0, selected = 0, packed_as = -1;
     bool first = true;
-    std::vector<int> counts_host;
     for (int round = 0; round < max_models; ++round) {
         const double* Hs = first ? e->H.p : e->sel_cand_H[cur].p;
         const int* orig = first ? nullptr : e->sel_orig[cur].p;
