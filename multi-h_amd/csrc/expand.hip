@@ -760,7 +760,6 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
 
     // ---- phase 1: global relabel <-> push until no site with excess can reach the sink ---------------
     int outer = 0, epoch = 0, hprev = 4;
-    bool exact = false;
     for (;; ++outer) {
         if (outer >= sp.max_outer) { if (leader) atomicExch(&flags[C_ERROR], ERR_NO_CONVERGENCE); break; }
         ++st_outer;
@@ -839,7 +838,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
             if (!grid_sync(bar, spoke, active, my_h, any, nact, hmax)) return;
             // no announcement in a whole interval: the distances are exact.  Otherwise every finite height is still
             // realised by a residual path, which is all the pushes need: go on as soon as somebody can push.
-            if (!any || nact) { exact = !any; break; }
+            if (!any || nact) break;
         }
         hprev = hmax;
         tk_relax += __builtin_amdgcn_s_memrealtime() - tr0;
