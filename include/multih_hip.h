@@ -131,7 +131,7 @@ MH_API int mh_refine_correspondences(mh_engine* e, const double F[9], const doub
 MH_API int mh_local_homographies(mh_engine* e, double locality, double* H_out, double* feat_out);
 /* MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157) on n rows of d <= 16 doubles:
  * every climb (:62-123) runs on the GPU, the sequential seed/merge/vote logic (:52-56,:100-146) on
- * the host; seeds come from the counter RNG instead of rand(), 64 at a time from the rows unvisited
+ * the host; seeds come from the counter RNG instead of rand(), 256 at a time from the rows unvisited
  * at that moment (their climbs share the launches; a seed visited by an earlier climb of its batch
  * is dropped — DESIGN.md 3.8).  modes: up to max_modes x d;
  * assign: per row the index of its mode (-1 if none); n_modes: number of modes found. */

@@ -76,7 +76,7 @@ hipError_t launch_refine_points(const Points& p, const Affines& a, const double 
                                 double* out /* n x 8 */, hipStream_t s);
 
 // --- meanshift.hip ----------------------------------------------------------
-constexpr int MS_BATCH = 64;   // climbs per batch: part of the definition of the seed order (meanshift.hip; the oracle draws alike)
+constexpr int MS_BATCH = 256;   // climbs per batch: part of the definition of the seed order (meanshift.hip; the oracle draws alike)
 struct MeanShiftWork {      // every per-climb array holds MS_BATCH slices
     const double* data;      // n x d row-major
     int n, d;

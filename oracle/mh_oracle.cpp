@@ -919,7 +919,7 @@ MHO_API void mho_haf_point(const double* x1, const double* y1, const double* x2,
 // MeanShiftClustering<double>::Cluster (MeanShiftClustering.h:23-157) with the engine's counter RNG
 // and the engine's summation order for the member sums (strided tree), so that the GPU climbs can be
 // compared bit for bit.  Returns the number of modes; modes (k x d), assign (n).
-static const int MHO_MS_BATCH = 64;   // climbs whose seeds are drawn together (the engine's MS_BATCH)
+static const int MHO_MS_BATCH = 256;   // climbs whose seeds are drawn together (the engine's MS_BATCH)
 MHO_API int mho_mean_shift(const double* data, int n, int d, double bw, unsigned long long seed,
                            double* modes, int max_modes, int* assign)
 {
