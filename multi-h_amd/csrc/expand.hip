@@ -815,7 +815,9 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
                         } else {
                             for (int k = k0 + sub; k < k1; k += SLPN) {
                                 const int kr = g.rev[k];
-                                if (LD(&cap[kr]) - LD(&sent[kr]) + LD(&sent[k]) > 0) atomicMin(&height[g.col[k]], ebits | (h + 1));
+                                const int ckr = LD(&cap[kr]);
+                                if ((LD(&cap[k]) | ckr) == 0) continue;      // folded arc: the neighbour is decided, its counter is stale
+                                if (ckr - LD(&sent[kr]) + LD(&sent[k]) > 0) atomicMin(&height[g.col[k]], ebits | (h + 1));
                             }
                         }
                         hprop = h;
@@ -929,7 +931,12 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
                     } else {                                        // any degree: one arc per cycle, arcs walked in memory
                         long long key = 0x7fffffffffffffffll;       // (height << 32) | arc
                         for (int k = k0 + sub; k < k1; k += SLPN) {
-                            if (LD(&cap[k]) - LD(&sent[k]) + LD(&sent[g.rev[k]]) > 0) {
+                            // An arc whose pair has no capacity left leads to a neighbour decided in this move: it is not in
+                            // the graph, and neither its counter (last written in an earlier move) nor its height word
+                            // (another move's epoch numbering) means anything here.
+                            const int ck = LD(&cap[k]), kr = g.rev[k];
+                            if ((ck | LD(&cap[kr])) == 0) continue;
+                            if (ck - LD(&sent[k]) + LD(&sent[kr]) > 0) {
                                 const int w = LD(&height[g.col[k]]);
                                 const int hv = (w >> H_SHIFT) == (ebits >> H_SHIFT) ? (w & H_MASK) : INF;
                                 const long long cand = ((long long)hv << 32) | (unsigned int)k;

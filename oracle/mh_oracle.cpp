@@ -1779,4 +1779,233 @@ MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1,
     return nh;
 }
 
-MHO_API int mho_abi_version(void) { return 1; }
+// ---------------------------------------------------------------------------
+// 12. Around the loop: stable point sets, propose + greedy selection, post-filter, Process()   
+// ---------------------------------------------------------------------------
+// Process() of the reference (M/MultiH.cpp:42-98) from "F is known" on:
+//     ComputeLocalHomographies + EstablishStablePointSets (:696-717, :604-694)   -> mho_establish_stable_point_sets
+//     ClusterMergingAndLabeling (:224-312)                                       -> section 11
+//     HomographyCompatibilityCheck when more than one cluster is left (:78-86, :100-222) -> mho_compatibility_check
+//     at most one cluster left: labels reset, HandleDegenerateCase (:88-94, :719-741)   -> mho_handle_degenerate
+// north_star's propose route (random 4-tuples -> DLT -> take the best-supported hypothesis, take its inliers out of the
+// support set, score again; the scheme of the dead M/MultipleHomographies.h:146-175) has no live reference code:
+// mho_select_greedy is its definition.  rand() is replaced by the splitmix64 counters of the product everywhere.
+
+// Sequential best-first selection over a fixed hypothesis list.  Per round: inlier counts over the points still in the
+// support set (strict d2 < thr2, the score of :430-443); the best count wins, the LOWEST hypothesis index on ties; stop
+// when the best count is below `need`; the winner's inliers leave the support set.  mask: in/out (1 = in the set).
+MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                              const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
+                              double* H_out /* max_models*9 */, long long* index_out, int* counts_out)
+{
+    int selected = 0;
+    std::vector<int> counts(M);
+    for (int round = 0; round < max_models; ++round) {
+        mho_score(x1, y1, x2, y2, N, H, M, thr2, mask, counts.data());
+        int best = -1, bm = -1;
+        for (int m = 0; m < M; ++m) if (counts[m] > best) { best = counts[m]; bm = m; }
+        if (bm < 0 || best < need) break;
+        const double* h = H + 9 * (size_t)bm;
+        for (int q = 0; q < 9; ++q) H_out[9 * (size_t)selected + q] = h[q];
+        if (index_out) index_out[selected] = bm;
+        if (counts_out) counts_out[selected] = best;
+        ++selected;
+        for (int i = 0; i < N; ++i)
+            if (mask[i] && fwd_d2(h, x1[i], y1[i], x2[i], y2[i]) < thr2) mask[i] = 0;
+    }
+    return selected;
+}
+
+// ComputeLocalHomographies (:696-717) + EstablishStablePointSets (:604-694): per-point HAF homographies and their 10-D
+// features (mho_haf_point), mean shift with band width thr_h (the engine-order restatement mho_mean_shift, see its
+// header and DESIGN.md 3.8 for what that order defines), one LM-refined 3-point homography per cluster of >= 3 points
+// (:664-688).  A per-point solve that degenerates leaves non-finite features; the product parks such rows at 1e300 so
+// that the L1 ball test never sees a NaN, and so does this.  Returns the number of models (H_out: capacity max_models*9).
+MHO_API int mho_establish_stable_point_sets(const double* x1, const double* y1, const double* x2, const double* y2,
+                                            const double* aff, int N, const double* F, const double* e2, double locality,
+                                            double thr_h, uint64_t ms_seed, double* H_out, int max_models)
+{
+    std::vector<double> feat(10 * (size_t)N);
+    mho_haf_point(x1, y1, x2, y2, aff, N, F, e2, locality, nullptr, feat.data());
+    for (double& f : feat) if (!std::isfinite(f)) f = 1e300;
+    std::vector<int> assign(N);
+    std::vector<double> modes(10 * (size_t)N);
+    const int k = mho_mean_shift(feat.data(), N, 10, thr_h, ms_seed, modes.data(), N, assign.data());
+    std::vector<std::vector<int>> members(k);
+    for (int i = 0; i < N; ++i) if (assign[i] >= 0) members[assign[i]].push_back(i);       // MeanShiftClustering.h:148-156
+    int nh = 0;
+    for (int c = 0; c < k; ++c) {
+        const int ni = (int)members[c].size();
+        if (ni < 3) continue;                                                               // :667
+        std::vector<double> p1(2 * (size_t)ni), p2(2 * (size_t)ni);
+        for (int j = 0; j < ni; ++j) {
+            const int i = members[c][j];
+            p1[2 * j] = x1[i]; p1[2 * j + 1] = y1[i]; p2[2 * j] = x2[i]; p2[2 * j + 1] = y2[i];
+        }
+        double Hc[9];
+        if (!homography_3pt(p1.data(), p2.data(), ni, F, Hc, true)) continue;               // :685 (a non-finite fit is dropped)
+        if (nh < max_models) for (int q = 0; q < 9; ++q) H_out[9 * (size_t)nh + q] = Hc[q];
+        ++nh;
+    }
+    return nh;
+}
+
+// HomographyCompatibilityCheck, M/MultiH.cpp:100-222, the loop as written: per cluster with at least
+// max(min_inliers, 4) points, 501 trials (:128, SURVEY A-10) of { erase three randomly indexed points from the cluster's
+// vectors (:138-151), 3-point homography without refinement (:154), squared transfer error of the REMAINING points into
+// the first N-3 entries of an N-entry buffer (:158-173), sort all N entries — the last three are leftovers of the
+// previous trial, zeros in the first (:136,:175) — "median" = element rest/2 or the mean of elements rest/2 and
+// rest/2 + 1 (:176), re-append the three points at positions N-1, N-2, N-3 (:178-189) }; the cluster is removed when the
+// same kind of median over the 501 trial values exceeds thr^2 * 81/16 (:192-195) or when it has fewer than min_inliers
+// points (:199-200); labels are compacted from the last cluster down (:205-221).
+// rand() (:142): draw number c is u = (splitmix64(seed + c) >> 11) * 2^-53, one counter running through the clusters in
+// order.  A trial whose fit has a non-finite entry counts every distance as 1e300, and so does a NaN distance
+// (std::sort on NaN is undefined in the reference; this fixes an order).  medians (nullable): per cluster, NaN = not tested.
+MHO_API int mho_compatibility_check(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
+                                    const double* F, double sqr_thr, int min_inliers, uint64_t seed, double* medians)
+{
+    std::vector<std::vector<double>> src(nh), dst(nh);                           // :102-115
+    for (int i = 0; i < n; ++i) {
+        const int l = labels[i];
+        if (l > -1 && l < nh) {
+            src[l].push_back(src_xy[2 * i]); src[l].push_back(src_xy[2 * i + 1]);
+            dst[l].push_back(dst_xy[2 * i]); dst[l].push_back(dst_xy[2 * i + 1]);
+        }
+    }
+    std::vector<char> remove(nh, 0);
+    uint64_t counter = 0;
+    for (int c = 0; c < nh; ++c) {
+        std::vector<double>& sp = src[c];
+        std::vector<double>& dp = dst[c];
+        const int N = (int)(sp.size() / 2);
+        const int trials = 501;                                                  // MAX(501, MIN(501, ...)), :128
+        if (medians) medians[c] = std::nan("");
+        if (N >= std::max(min_inliers, 4)) {                                     // :134
+            std::vector<double> distances(trials), dist((size_t)N, 0.0);        // :132, :136
+            for (int t = 0; t < trials; ++t) {
+                double ms[6], md[6];
+                for (int j = 0; j < 3; ++j) {                                    // :139-151
+                    const double u = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
+                    const int cur = (int)(sp.size() / 2);
+                    const int idx = (int)((cur - 1) * u);                        // :142
+                    ms[2 * j] = sp[2 * idx]; ms[2 * j + 1] = sp[2 * idx + 1];
+                    md[2 * j] = dp[2 * idx]; md[2 * j + 1] = dp[2 * idx + 1];
+                    sp.erase(sp.begin() + 2 * idx, sp.begin() + 2 * idx + 2);
+                    dp.erase(dp.begin() + 2 * idx, dp.begin() + 2 * idx + 2);
+                }
+                double Hc[9];
+                const bool ok = homography_3pt(ms, md, 3, F, Hc, false);         // :154
+                const int rest = (int)(sp.size() / 2);
+                for (int j = 0; j < rest; ++j) {                                 // :158-173
+                    double d2 = std::nan("");
+                    if (ok) d2 = fwd_d2(Hc, sp[2 * j], sp[2 * j + 1], dp[2 * j], dp[2 * j + 1]);
+                    dist[j] = std::isnan(d2) ? 1e300 : d2;
+                }
+                std::sort(dist.begin(), dist.end());                             // :175 — all N entries
+                distances[t] = rest % 2 ? dist[rest / 2] : 0.5 * (dist[rest / 2] + dist[rest / 2 + 1]);   // :176
+                sp.resize(2 * (size_t)N);                                        // :178-189
+                dp.resize(2 * (size_t)N);
+                for (int j = 0; j < 3; ++j) {
+                    const int p2 = N - j - 1;
+                    sp[2 * p2] = ms[2 * j]; sp[2 * p2 + 1] = ms[2 * j + 1];
+                    dp[2 * p2] = md[2 * j]; dp[2 * p2 + 1] = md[2 * j + 1];
+                }
+            }
+            std::sort(distances.begin(), distances.end());                       // :192
+            const double median = trials % 2 ? distances[trials / 2] : 0.5 * (distances[trials / 2] + distances[trials / 2 + 1]);
+            if (medians) medians[c] = median;
+            remove[c] = median > sqr_thr * 81.0 / 16.0;                          // :195
+        } else if (N < min_inliers)
+            remove[c] = 1;                                                       // :199-200
+    }
+    int kept = nh;
+    for (int c = nh - 1; c >= 0; --c) {                                          // :205-221
+        if (!remove[c]) continue;
+        for (int j = 0; j < n; ++j) {
+            if (labels[j] == c) labels[j] = -1;
+            else if (labels[j] > c) --labels[j];
+        }
+        for (int q = c; q + 1 < kept; ++q) memcpy(H + 9 * (size_t)q, H + 9 * (size_t)(q + 1), 9 * sizeof(double));
+        --kept;
+    }
+    return kept;
+}
+
+// HandleDegenerateCase, M/MultiH.cpp:719-741: cv::findHomography(RANSAC) on the correspondences, its inliers get label
+// 0, everything else -1, one model.  cv::findHomography is not under /root/reference ("parity unpinned"); the build's
+// definition, here as in the product: the best-supported (first maximum) of max(hypotheses, 1000) 4-point DLT
+// hypotheses drawn with counters 0.. of `seed`.
+MHO_API void mho_handle_degenerate(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                                   double thr2, uint64_t seed, int hypotheses, int* labeling, double* H_out)
+{
+    const int M = std::max(hypotheses, 1000);
+    std::vector<int> idx(4 * (size_t)M), counts(M);
+    std::vector<double> H(9 * (size_t)M);
+    mho_sample4(seed, 0, M, N, idx.data());
+    mho_dlt4(x1, y1, x2, y2, idx.data(), M, H.data(), nullptr, nullptr);
+    mho_score(x1, y1, x2, y2, N, H.data(), M, thr2, nullptr, counts.data());
+    int best = 0;
+    for (int m = 1; m < M; ++m) if (counts[m] > counts[best]) best = m;
+    for (int i = 0; i < N; ++i)
+        labeling[i] = fwd_d2(&H[9 * (size_t)best], x1[i], y1[i], x2[i], y2[i]) < thr2 ? 0 : -1;
+    for (int q = 0; q < 9; ++q) H_out[q] = H[9 * (size_t)best + q];
+}
+
+// Process(), M/MultiH.cpp:42-98, from a known F (the product's SetEpipolarGeometry route: the correspondences count as
+// already refined, so "original" and working points coincide).  init_mode: 0 = the given H0 (n_init models, what
+// EstablishStablePointSets would hand over), 1 = stable point sets (the reference's own route), 2 = north_star's
+// propose (hypotheses 4-point DLT models from counters 0.., greedy selection of at most max_propose with at least
+// max(min_inliers, 8) inliers).  Seeds follow the product: mean shift of the stable sets seed ^ 0x57ab1e, MergingSteps
+// seed ^ 0x4d53 ^ (c << 20), post-filter seed ^ 0xc0117a7, degenerate case seed ^ 0xdead.  post_filter = 0 skips
+// :78-86 (the loop's own output).  Returns the number of models; H: capacity max_models*9.
+MHO_API int mho_process(const double* x1, const double* y1, const double* x2, const double* y2, const double* aff, int N,
+                        const double* F, const double* e2, double thr_h, double locality, double lambda, int min_inliers,
+                        double straightness, uint64_t seed, int init_mode, const double* H0, int n_init, int hypotheses,
+                        int max_propose, const int* hit_rowptr, const int* hit_col, mho_expand_hook expand,
+                        int post_filter, double* H, int max_models, int* labeling, int* iterations, double* energy_out,
+                        int* removed_by_filter, int* took_degenerate_tail)
+{
+    const double thr2 = thr_h * thr_h;
+    std::vector<double> models((size_t)max_models * 9, 0.0);
+    int nh = 0;
+    if (init_mode == 0) {
+        nh = std::min(n_init, max_models);
+        std::copy(H0, H0 + 9 * (size_t)nh, models.begin());
+    } else if (init_mode == 1) {
+        nh = mho_establish_stable_point_sets(x1, y1, x2, y2, aff, N, F, e2, locality, thr_h, seed ^ 0x57ab1eull,
+                                             models.data(), max_models);
+        if (nh > max_models) return -1;
+    } else {
+        std::vector<int> idx(4 * (size_t)hypotheses);
+        std::vector<double> Hh(9 * (size_t)hypotheses);
+        mho_sample4(seed, 0, hypotheses, N, idx.data());
+        mho_dlt4(x1, y1, x2, y2, idx.data(), hypotheses, Hh.data(), nullptr, nullptr);
+        std::vector<unsigned char> mask(N, 1);
+        nh = mho_select_greedy(x1, y1, x2, y2, N, Hh.data(), hypotheses, thr2, std::max(min_inliers, 8),
+                               std::min(max_propose, max_models), mask.data(), models.data(), nullptr, nullptr);
+    }
+    if (iterations) *iterations = 0;
+    if (energy_out) *energy_out = 0.0;
+    nh = mho_cluster_merging_and_labeling(x1, y1, x2, y2, aff, N, models.data(), nh, max_models, F, e2, lambda, thr_h,
+                                          straightness, hit_rowptr, hit_col, seed, expand, labeling, iterations, energy_out);
+    if (nh > max_models) return -1;
+    if (removed_by_filter) *removed_by_filter = 0;
+    if (took_degenerate_tail) *took_degenerate_tail = 0;
+    if (nh > 1 && post_filter) {                                                 // :78-86
+        std::vector<double> s(2 * (size_t)N), d(2 * (size_t)N);
+        for (int i = 0; i < N; ++i) { s[2 * i] = x1[i]; s[2 * i + 1] = y1[i]; d[2 * i] = x2[i]; d[2 * i + 1] = y2[i]; }
+        const int kept = mho_compatibility_check(s.data(), d.data(), N, labeling, models.data(), nh, F, thr2, min_inliers,
+                                                 seed ^ 0xc0117a7ull, nullptr);
+        if (removed_by_filter) *removed_by_filter = nh - kept;
+        nh = kept;
+    }
+    if (nh <= 1) {                                                               // :88-94
+        mho_handle_degenerate(x1, y1, x2, y2, N, thr2, seed ^ 0xdeadull, hypotheses, labeling, models.data());
+        nh = 1;
+        if (took_degenerate_tail) *took_degenerate_tail = 1;
+    }
+    for (int i = 0; i < nh; ++i) for (int q = 0; q < 9; ++q) H[9 * (size_t)i + q] = models[9 * (size_t)i + q];
+    return nh;
+}
+
+MHO_API int mho_abi_version(void) { return 2; }

@@ -336,6 +336,71 @@ def cluster_merging_and_labeling(src, dst, aff, H0, F, e2, lam, thr_h, rowptr, c
     return lab, H[:k].copy(), int(it.value), float(en.value), hook is not None
 
 
+def select_greedy(src, dst, H, thr2, need, max_models, mask=None):
+    """The oracle's sequential best-first selection (oracle/mh_oracle.cpp section 12).  Returns
+    (H_selected, hypothesis indices, counts, mask_out)."""
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    m = np.ones(x1.size, np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).copy()
+    Hs = np.zeros((max_models, 9))
+    idx = np.zeros(max_models, np.int64)
+    cnt = np.zeros(max_models, np.int32)
+    k = lib().mho_select_greedy(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], C.c_double(thr2), int(need),
+                                int(max_models), m.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(Hs),
+                                idx.ctypes.data_as(C.POINTER(C.c_longlong)), _i(cnt))
+    return Hs[:k].copy(), idx[:k].copy(), cnt[:k].copy(), m
+
+
+def compatibility_check(src, dst, labels, H, F, sqr_thr, min_inliers, seed):
+    """HomographyCompatibilityCheck (M/MultiH.cpp:100-222) as the oracle restates it, on the oracle's own 3-point solver.
+    Returns (labels_out, H_kept, medians)."""
+    s, d = f64(src).reshape(-1, 2), f64(dst).reshape(-1, 2)
+    H = f64(H).reshape(-1, 9).copy()
+    lab = i32(labels).copy()
+    med = np.full(H.shape[0], np.nan)
+    k = lib().mho_compatibility_check(_d(s), _d(d), s.shape[0], _i(lab), _d(H), H.shape[0], _d(f64(F)), C.c_double(sqr_thr),
+                                      int(min_inliers), C.c_ulonglong(seed), _d(med))
+    return lab, H[:k].copy(), med
+
+
+def establish_stable_point_sets(src, dst, aff, F, e2, locality, thr_h, ms_seed, max_models=None):
+    x1, y1, x2, y2 = soa(src, dst)
+    cap = x1.size if max_models is None else max_models
+    H = np.zeros((cap, 9))
+    k = lib().mho_establish_stable_point_sets(_d(x1), _d(y1), _d(x2), _d(y2), _d(f64(aff)), x1.size, _d(f64(F)), _d(f64(e2)),
+                                              C.c_double(locality), C.c_double(thr_h), C.c_ulonglong(ms_seed), _d(H), cap)
+    return H[:k].copy()
+
+
+def process(src, dst, aff, F, e2, thr_h, locality, lam, min_inliers, seed, rowptr, col, *, init_H=None, init_mode=None,
+            hypotheses=0, max_propose=32, post_filter=True, use_reference_gco=True, straightness=0.005, max_models=None):
+    """The oracle's Process() from a known F (oracle/mh_oracle.cpp section 12; M/MultiH.cpp:42-98).  init_mode 0 = init_H,
+    1 = stable point sets, 2 = DLT proposals + greedy selection.  Returns a dict: labels, H, iterations, energy,
+    removed_by_filter, degenerate_tail, used_reference_gco."""
+    x1, y1, x2, y2 = soa(src, dst)
+    if init_mode is None:
+        init_mode = 0 if init_H is not None else 2
+    H0 = f64(init_H).reshape(-1, 9) if init_H is not None else np.zeros((0, 9))
+    cap = max_models or (x1.size if init_mode == 1 else max(256, H0.shape[0]))
+    H = np.zeros((cap, 9))
+    rowptr, col = i32(rowptr), i32(col)
+    lab = np.empty(x1.size, dtype=np.int32)
+    it, en, rem, deg = C.c_int(0), C.c_double(0), C.c_int(0), C.c_int(0)
+    hook = None
+    if use_reference_gco and ref() is not None:
+        hook = C.cast(ref().ref_gco_expand_table, _EXPAND_HOOK)
+    fn = lib().mho_process
+    fn.restype = C.c_int
+    k = fn(_d(x1), _d(y1), _d(x2), _d(y2), _d(f64(aff)), x1.size, _d(f64(F)), _d(f64(e2)), C.c_double(thr_h),
+           C.c_double(locality), C.c_double(lam), int(min_inliers), C.c_double(straightness), C.c_ulonglong(seed),
+           int(init_mode), _d(H0) if H0.size else None, H0.shape[0], int(hypotheses), int(max_propose), _i(rowptr), _i(col),
+           hook if hook is not None else _EXPAND_HOOK(0), int(bool(post_filter)), _d(H), cap, _i(lab), C.byref(it),
+           C.byref(en), C.byref(rem), C.byref(deg))
+    assert k >= 0, "the oracle's model capacity was too small"
+    return {"labels": lab, "H": H[:k].copy(), "iterations": int(it.value), "energy": float(en.value),
+            "removed_by_filter": int(rem.value), "degenerate_tail": bool(deg.value), "used_reference_gco": hook is not None}
+
+
 # ---- reference GCO (oracle/_ref) -----------------------------------------
 
 def ref_expand_table(cost, rowptr, col, potts_v, init_labels=None):

@@ -47,35 +47,121 @@ def _initial_models(sc, seed, duplicates, strays):
     return np.ascontiguousarray(np.concatenate(H, axis=0))
 
 
-@pytest.mark.parametrize("n,planes,seed,duplicates,strays", [(1000, 3, 2, 2, 0), (1000, 2, 7, 0, 2), (5000, 3, 1234, 3, 1),
-                                                             (5000, 5, 11, 0, 0), (3000, 4, 5, 4, 2)])
-def test_process_loop_equals_the_oracle_alternation(mh, engine_lib, synth, oracle, n, planes, seed, duplicates, strays):
-    sc = synth.make_scene(n, planes, seed=seed, with_neighbours=False)
-    H0 = _initial_models(sc, seed, duplicates, strays)
-    rowptr, col = _knn_hits(sc, 16)
-    lab_o, H_o, it_o, en_o, used_ref = oracle.cluster_merging_and_labeling(sc.src, sc.dst, sc.aff, H0, sc.F, sc.e2, LAM, THR,
-                                                                            rowptr, col, seed)
+def _run_process(mh, sc, seed, *, H0=None, hypotheses=0, max_models=0, stable_sets=False, post_filter=True, min_inliers=20):
+    """Process() of the host class (multi-h_amd/host/MultiH.cpp) through its C hook, F given."""
     host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
     dp = C.POINTER(C.c_double)
+    n = sc.n
     labels = np.full(n, -7, dtype=np.int32)
-    Hout = np.zeros((64, 9))
+    Hout = np.zeros((1024, 9))
     it, en = C.c_int(-1), C.c_double(-1)
     src, dst, aff = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.aff))
     F, e2 = np.ascontiguousarray(sc.F), np.ascontiguousarray(sc.e2)
-    host.mhh_set_post_filter(0)
+    H0c = None if H0 is None else np.ascontiguousarray(H0)
+    host.mhh_set_post_filter(1 if post_filter else 0)
     try:
         k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n,
                                  F.ctypes.data_as(dp), e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(THR),
-                                 C.c_double(LOCALITY), C.c_double(LAM), 20, C.c_ulonglong(seed), 0, 0, 0,
-                                 H0.ctypes.data_as(dp), H0.shape[0], labels.ctypes.data_as(C.POINTER(C.c_int)),
-                                 Hout.ctypes.data_as(dp), 64, C.byref(it), C.byref(en), None, 0, 4)
+                                 C.c_double(LOCALITY), C.c_double(LAM), min_inliers, C.c_ulonglong(seed), hypotheses, max_models, 0,
+                                 None if H0c is None else H0c.ctypes.data_as(dp), 0 if H0c is None else H0c.shape[0],
+                                 labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 1024, C.byref(it),
+                                 C.byref(en), None, 0, -1 if stable_sets else 4)
     finally:
         host.mhh_set_post_filter(1)
-    assert k == H_o.shape[0], f"models: GPU {k}, oracle {H_o.shape[0]}"
-    assert it.value == it_o, f"GetIterationNumber(): GPU {it.value}, oracle {it_o}"
-    assert en.value == en_o, f"GetEnergy(): GPU {en.value}, oracle {en_o}"
-    assert np.array_equal(labels, lab_o), f"{int((labels != lab_o).sum())} labels differ"
-    if k > 1:
-        scale = np.max(np.abs(H_o), axis=1, keepdims=True)
-        assert np.max(np.abs(Hout[:k] - H_o) / scale) <= 1e-9
-    assert k >= 2 and it_o >= 1
+    return k, labels, Hout[:max(k, 0)].copy(), it.value, en.value
+
+
+def _assert_same_result(got, want):
+    k, labels, H, it, en = got
+    assert k == want["H"].shape[0], f"models: GPU {k}, oracle {want['H'].shape[0]}"
+    assert it == want["iterations"], f"GetIterationNumber(): GPU {it}, oracle {want['iterations']}"
+    assert en == want["energy"], f"GetEnergy(): GPU {en}, oracle {want['energy']}"
+    assert np.array_equal(labels, want["labels"]), f"{int((labels != want['labels']).sum())} labels differ"
+    if k > 0:
+        scale = np.max(np.abs(want["H"]), axis=1, keepdims=True)
+        assert np.max(np.abs(H - want["H"]) / scale) <= 1e-9
+
+
+@pytest.mark.parametrize("post_filter", [False, True])
+@pytest.mark.parametrize("n,planes,seed,duplicates,strays", [(1000, 3, 2, 2, 0), (1000, 2, 7, 0, 2), (5000, 3, 1234, 3, 1),
+                                                             (5000, 5, 11, 0, 0), (3000, 4, 5, 4, 2)])
+def test_process_loop_equals_the_oracle_alternation(mh, engine_lib, synth, oracle, n, planes, seed, duplicates, strays, post_filter):
+    """post_filter False: the loop's own output (:76).  True: Process() as the reference runs it, with
+    HomographyCompatibilityCheck behind the loop (:78-86) and the degenerate tail (:88-94) — the oracle's
+    mho_compatibility_check is the literal restatement of :100-222 on the oracle's own 3-point solver."""
+    sc = synth.make_scene(n, planes, seed=seed, with_neighbours=False)
+    H0 = _initial_models(sc, seed, duplicates, strays)
+    rowptr, col = _knn_hits(sc, 16)
+    want = oracle.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, seed, rowptr, col, init_H=H0,
+                          post_filter=post_filter)
+    got = _run_process(mh, sc, seed, H0=H0, post_filter=post_filter)
+    _assert_same_result(got, want)
+    assert got[0] >= 2 and want["iterations"] >= 1
+
+
+def _thin_out_plane(sc, plane, keep, rng):
+    """The scene with all but `keep` correspondences of one plane taken away: a plane too small to survive the
+    post-filter's minimum_inlier_number test (M/MultiH.cpp:199-200) although the loop keeps its model."""
+    members = np.flatnonzero(sc.gt_label == plane)
+    drop = rng.permutation(members)[keep:]
+    sel = np.ones(sc.n, bool)
+    sel[drop] = False
+    sc.src, sc.dst, sc.aff, sc.gt_label = sc.src[sel], sc.dst[sel], sc.aff[sel], sc.gt_label[sel]
+    return sc
+
+
+@pytest.mark.parametrize("n,planes,seed,keep", [(4000, 5, 29, 14), (2000, 3, 23, 9), (2500, 4, 37, 10)])
+def test_post_filter_removes_a_cluster_like_the_oracle(mh, engine_lib, synth, oracle, n, planes, seed, keep):
+    """A Process() run in which HomographyCompatibilityCheck actually changes the result: one plane has fewer points
+    than minimum_inlier_number, so its cluster is removed and the labels behind it are compacted (:205-221)."""
+    sc = _thin_out_plane(synth.make_scene(n, planes, seed=seed, outlier_frac=0.1, with_neighbours=False), planes - 2, keep,
+                         np.random.default_rng(seed))
+    H0 = _initial_models(sc, seed, 1, 0)
+    rowptr, col = _knn_hits(sc, 16)
+    loop_only = oracle.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, seed, rowptr, col, init_H=H0,
+                               post_filter=False)
+    want = oracle.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, seed, rowptr, col, init_H=H0)
+    assert want["removed_by_filter"] >= 1 and want["H"].shape[0] == loop_only["H"].shape[0] - want["removed_by_filter"], \
+        "the scene should make the post-filter remove a cluster"
+    _assert_same_result(_run_process(mh, sc, seed, H0=H0), want)
+
+
+def test_process_ends_in_the_degenerate_tail_like_the_oracle(mh, engine_lib, synth, oracle):
+    """One plane only: the loop stops with a single model (:280-285), Process() resets the labels and takes
+    HandleDegenerateCase (:88-94) — the build's definition: the best of 1000 DLT hypotheses, its inliers labelled 0."""
+    sc = synth.make_scene(1500, 1, seed=41, with_neighbours=False)
+    H0 = _initial_models(sc, 41, 1, 1)
+    rowptr, col = _knn_hits(sc, 16)
+    want = oracle.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, 41, rowptr, col, init_H=H0)
+    assert want["degenerate_tail"] and want["H"].shape[0] == 1
+    got = _run_process(mh, sc, 41, H0=H0)
+    _assert_same_result(got, want)
+    assert (got[1] == 0).sum() > 0.6 * sc.n
+
+
+@pytest.mark.parametrize("n,planes,seed,hyp", [(3000, 3, 3, 2000), (4000, 5, 9, 4000)])
+def test_process_from_dlt_proposals_equals_the_oracle(mh, engine_lib, synth, oracle, n, planes, seed, hyp):
+    """Process() on its default route, end to end: `hyp` counter-RNG 4-tuples -> batched DLT (k_dlt4) -> greedy
+    selection on the device (mh_select_greedy) -> loop -> post-filter, against the oracle doing the same with its own
+    DLT, its sequential selection (mho_select_greedy) and the reference's GCO."""
+    sc = synth.make_scene(n, planes, seed=seed, with_neighbours=False)
+    rowptr, col = _knn_hits(sc, 16)
+    want = oracle.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, seed, rowptr, col, init_mode=2,
+                          hypotheses=hyp, max_propose=16)
+    got = _run_process(mh, sc, seed, hypotheses=hyp, max_models=16)
+    _assert_same_result(got, want)
+    assert got[0] >= 2
+
+
+@pytest.mark.parametrize("n,planes,seed", [(1200, 3, 6)])
+def test_process_from_stable_point_sets_equals_the_oracle(mh, engine_lib, synth, oracle, n, planes, seed):
+    """The reference's own initialisation end to end (INIT_STABLE_SETS): per-point HAF homographies (k_haf_point), the
+    N x 10 mean shift on the device, one LM-refined 3-point fit per cluster (EstablishStablePointSets, :604-694), then
+    the loop and the post-filter, against oracle/mh_oracle.cpp sections 8b + 11 + 12.  The initial set is a few hundred
+    models, so the first LabelingSteps run with hundreds of labels."""
+    sc = synth.make_scene(n, planes, seed=seed, with_neighbours=False)
+    rowptr, col = _knn_hits(sc, 16)
+    want = oracle.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, seed, rowptr, col, init_mode=1)
+    got = _run_process(mh, sc, seed, stable_sets=True)
+    _assert_same_result(got, want)
+    assert got[0] >= 2

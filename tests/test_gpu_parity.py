@@ -238,6 +238,59 @@ def test_expand_solver_paths(engine, synth, oracle, case):
     assert st["host_syncs"] <= st["cycles"] + 2
 
 
+def _radius_hits(sc, radius):
+    """radiusMatch(1/locality) answered exactly in the reference's float32 (x1,y1,x2,y2) space (M/MultiH.cpp:233-253),
+    self hits included like FLANN's (LabelingStep skips them, :537)."""
+    pv = np.concatenate([sc.src, sc.dst], axis=1).astype(np.float32)
+    diff = pv[:, None, :] - pv[None, :, :]
+    sq = diff * diff
+    d = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]) + sq[..., 3]
+    hit = d <= np.float32(radius) ** 2
+    rowptr = np.concatenate([[0], np.cumsum(hit.sum(axis=1))]).astype(np.int32)
+    return rowptr, np.nonzero(hit)[1].astype(np.int32)
+
+
+@pytest.mark.parametrize("lam,grid", [(0.5, 256), (0.05, 256), (0.05, 2)])
+def test_expand_on_a_dense_radius_graph(engine, synth, oracle, lam, grid):
+    """The reference's own neighbourhood rule (every correspondence within 1/locality pixels) gives sites HUNDREDS of
+    arcs, far above the 48 a solver row keeps in registers, so almost every core site walks its arcs in memory
+    (csrc/expand.hip, the `!fast` branches of k_solve).  On that path an arc towards a neighbour decided earlier in the
+    move has no capacity in either direction, while that neighbour's flow counter and height word are leftovers of
+    older moves: they must never be read as residual capacity (r02 advisor finding).  Several cycles, flow recycling
+    on and off, one and several sites per solver row — always the oracle's labels, energy and cycle count."""
+    sc = synth.make_scene(1500, 4, seed=31, noise=1.0, outlier_frac=0.3, with_neighbours=False)
+    rowptr, col = _radius_hits(sc, 300.0)
+    H = _models(sc, np.random.default_rng(31), extra=4)
+    engine.set_params(2.6, THR, 0.005, lam, 20)
+    try:
+        engine.set_correspondences(sc.src, sc.dst, sc.aff)
+        engine.set_epipolar(sc.F, sc.e2)
+        engine.set_neighbors_csr(rowptr, col)
+        rp, _, _ = engine.get_sym_graph()
+        assert np.median(np.diff(rp)) > 96, "the scene should put the typical site on the arcs-in-memory path"
+        engine.set_models(H)
+        cost = engine.data_cost()
+        lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, rowptr, col, oracle.potts(lam))
+        assert cyc_ref >= 3
+        init = (sc.gt_label + 1).astype(np.int32)
+        lab_w_ref, e_w_ref, cyc_w_ref, _ = oracle.expand(cost, rowptr, col, oracle.potts(lam), init_labels=init)
+        engine.set_tuning(5, grid)
+        for recycle in (1, 0):
+            for reduce_rounds in (2, 0):
+                engine.set_tuning(11, recycle)
+                engine.set_tuning(6, reduce_rounds)
+                labels, energy, cycles = engine.expand()
+                assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), (recycle, reduce_rounds)
+                labels, energy, cycles = engine.expand(init)
+                assert energy == e_w_ref and cycles == cyc_w_ref and np.array_equal(labels, lab_w_ref), (recycle, reduce_rounds, "warm")
+        assert engine.expand_stats()["moves_solved"] > 0
+    finally:
+        engine.set_tuning(5, 256)
+        engine.set_tuning(6, 2)
+        engine.set_tuning(11, 1)
+        engine.set_params(2.6, THR, 0.005, LAM, 20)
+
+
 def test_flow_recycling_changes_rounds_not_labels(engine, synth, oracle):
     """From the second cycle on the max-flow of a move starts from the flow the previous expansion on the same label
     ended with (csrc/expand.hip, k_solve).  The read-out of a maximum flow does not depend on where the flow started:

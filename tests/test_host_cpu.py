@@ -276,3 +276,60 @@ def test_host_3pt_solver_agrees_with_the_oracles_independent_restatement(host, s
                     assert ok
                     a, b = H_host / H_host[8], H_or / H_or[8]
                     assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(b))), (k, noise, fn)
+
+
+@pytest.mark.parametrize("sizes,min_inliers", [((700, 523, 64, 17), 20), ((10, 21, 19), 4), ((40, 33, 5), 0)])
+def test_compatibility_check_equals_the_oracles_restatement(host, synth, oracle, sizes, min_inliers):
+    """The product's post-filter (host/merge_step.cpp: selection instead of sorting, threads, stale entries threaded
+    through afterwards) against the ORACLE's literal restatement of M/MultiH.cpp:100-222 (oracle/mh_oracle.cpp
+    section 12: erase/append on the cluster vectors, N-entry buffer, one full sort per trial), which runs on the
+    oracle's OWN 3-point solver.  Every decision must be equal — which clusters go, the compacted labels, the kept
+    homographies — and the median-of-medians agree to 1e-6 relative (the two 3-point solvers differ in the last bits).
+    Covers a cluster below min_inliers (:199-200), one with scrambled matches (median test, :195), the tiny-cluster
+    path and min_inliers = 0 with a cluster of 5 (tested, as N >= 4)."""
+    planes = len(sizes)
+    sc = synth.make_scene(6000, planes, seed=11 + planes, noise=0.4, outlier_frac=0.0, with_neighbours=False)
+    rng = np.random.default_rng(5)
+    labels = np.full(sc.n, -1, dtype=np.int32)
+    for c, sz in enumerate(sizes):
+        members = np.flatnonzero(sc.gt_label == c)[:sz]
+        assert members.size == sz
+        labels[members] = c
+    scr = np.flatnonzero(labels == 1)
+    sc.dst[scr[::2]] = rng.uniform(0, 1000, size=(scr[::2].size, 2))           # cluster 1: half scrambled -> removed by the median test
+    src, dst, F = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.F))
+    seed = 4242
+    H = sc.H_true.copy()
+    lab = labels.copy()
+    med = np.zeros(planes)
+    kept = host.mhh_compatibility_medians(src.ctypes.data_as(_dp), dst.ctypes.data_as(_dp), sc.n,
+                                          lab.ctypes.data_as(C.POINTER(C.c_int)), H.ctypes.data_as(_dp), planes,
+                                          F.ctypes.data_as(_dp), C.c_double(2.2 ** 2), min_inliers, C.c_ulonglong(seed),
+                                          med.ctypes.data_as(_dp))
+    lab_o, H_o, med_o = oracle.compatibility_check(src, dst, labels, sc.H_true, F, 2.2 ** 2, min_inliers, seed)
+    assert kept == H_o.shape[0]
+    assert np.array_equal(lab, lab_o)
+    assert np.array_equal(H[:kept], H_o)
+    assert np.array_equal(np.isnan(med), np.isnan(med_o))
+    t = ~np.isnan(med_o)
+    assert t.any() and np.max(np.abs(med[t] - med_o[t]) / med_o[t]) <= 1e-6
+    assert kept < planes, "the case should remove a cluster"
+    assert (lab_o[labels == 1] == -1).all()
+
+
+def test_oracle_greedy_selection_known_answer(synth, oracle):
+    """mho_select_greedy on hypotheses whose supports are known: the ground-truth planes (each supported by its own
+    region) among duplicates and junk.  Picks come in order of support, a duplicate of a picked plane finds its inliers
+    gone, junk never reaches `need`, ties go to the lower index."""
+    sc = synth.make_scene(2000, 3, seed=3, noise=0.3, outlier_frac=0.2, with_neighbours=False)
+    junk = np.eye(3).reshape(1, 9) * np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1.0]])
+    H = np.concatenate([junk, sc.H_true[1:2], sc.H_true, sc.H_true[0:1]], axis=0)        # 0 junk, 1 = plane 1, 2..4 planes, 5 = plane 0
+    Hs, idx, cnt, mask = oracle.select_greedy(sc.src, sc.dst, H, 2.2 ** 2, 8, 10)
+    support = np.array([int((sc.gt_label == k).sum()) for k in range(3)])
+    first_of_plane = {0: 2, 1: 1, 2: 4}                                                 # lowest index carrying each plane
+    order = [first_of_plane[k] for k in np.argsort(-support, kind="stable")]
+    assert idx.tolist() == order
+    assert (np.diff(cnt) <= 0).all() and cnt[-1] >= 8
+    assert mask.sum() == sc.n - cnt.sum()
+    full = oracle.score(sc.src, sc.dst, H, 2.2 ** 2)
+    assert cnt[0] == full[idx[0]]

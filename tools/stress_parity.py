@@ -17,6 +17,15 @@ while time.time() - t0 < budget:
     thr = float(rng.choice([1.0, 2.2, 4.0]))
     sc = mh.synth.make_scene(n, k, seed=seed, knn=min(knn, n - 1), symmetric=sym, noise=float(rng.uniform(0.1, 2.0)),
                              outlier_frac=float(rng.uniform(0, 0.6)))
+    if n <= 2500 and rng.integers(0, 4) == 0:
+        # the reference's own rule — every correspondence within a radius — gives degrees far above the 48 arcs a solver
+        # row keeps in registers: the arcs-in-memory path of k_solve
+        pv = np.concatenate([sc.src, sc.dst], axis=1).astype(np.float32)
+        sq = (pv[:, None, :] - pv[None, :, :]) ** 2
+        hit = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]) + sq[..., 3] <= np.float32(rng.uniform(80.0, 400.0)) ** 2
+        sc.hit_rowptr = np.concatenate([[0], np.cumsum(hit.sum(axis=1))]).astype(np.int32)
+        sc.hit_col = np.nonzero(hit)[1].astype(np.int32)
+        lam = float(rng.choice([0.01, 0.05, 0.5]))
     e.set_params(2.6, thr, 0.005, lam, 20)
     e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2); e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
     e.set_tuning(5, int(rng.choice([256, 256, 32, 8, 2])))    # solver workgroups: few of them give every solver row several sites
