@@ -124,6 +124,60 @@ def test_sampling_and_dlt4(engine, synth, oracle, n, m, seed):
         assert np.max(np.abs(p - sc.dst[idx[t]])) < 1e-6 * 1000
 
 
+def test_dlt4_on_degenerate_samples(engine, synth, oracle):
+    """Hypotheses from degenerate 4-tuples — three or four collinear points, repeated correspondences, a point set
+    squeezed onto a line — are scored like any other in the bench and in Process(), so the GPU must treat them like the
+    oracle: same NaN pattern in H, same bits where H is finite (both sides run the same rounded operations in the same
+    order, also on a rank-deficient system), and therefore the same inlier count for EVERY hypothesis, including the
+    ones whose conditioning witness is below the 1e-6 the well-conditioned test cuts at."""
+    sc = synth.make_scene(400, 2, seed=13, with_neighbours=False)
+    rng = np.random.default_rng(13)
+    n = sc.n
+    line = rng.permutation(n)[:160]                      # 40 % of the sources on one line: collinear triples and quadruples
+    t = rng.uniform(0, 1000, size=line.size)
+    sc.src[line] = np.stack([t, 0.5 * t + 100.0], axis=1)
+    dup = rng.permutation(n)[:60]                        # repeated correspondences (distinct indices, equal coordinates)
+    sc.src[dup[30:]] = sc.src[dup[:30]]
+    sc.dst[dup[30:]] = sc.dst[dup[:30]]
+    sc.dst[rng.permutation(n)[:40], 1] = 250.0           # some targets on a horizontal line
+    _load(engine, sc, neighbours=False)
+    M = 4096
+    engine.propose_dlt4(5, 0, M)
+    idx = engine.get_samples()
+    assert np.array_equal(idx, oracle.sample4(5, 0, M, n))
+    H = engine.get_models()
+    with np.errstate(all="ignore"):
+        H_ref, wit, _ = oracle.dlt4(sc.src, sc.dst, idx)
+    bad = ~(wit > 1e-6)
+    assert bad.sum() >= 50, "the scene should produce plenty of degenerate samples"
+    assert np.array_equal(np.isnan(H), np.isnan(H_ref)), "NaN pattern differs"
+    fin = ~np.isnan(H_ref)
+    assert np.array_equal(H[fin].view(np.uint64), H_ref[fin].view(np.uint64)), \
+        f"{int((H[fin].view(np.uint64) != H_ref[fin].view(np.uint64)).sum())} finite entries differ in their bits"
+    cnt = engine.score(THR2)
+    with np.errstate(all="ignore"):
+        cnt_ref = oracle.score(sc.src, sc.dst, H_ref, THR2)
+    assert np.array_equal(cnt, cnt_ref), f"counts differ for {int((cnt != cnt_ref).sum())} hypotheses"
+    R, cnt_r = engine.residual_matrix(THR2)
+    assert np.array_equal(cnt_r, cnt_ref)
+    # four identical correspondences: the Hartley scale is 1/0, every entry of H is NaN on both sides
+    sc2 = synth.make_scene(24, 1, seed=14, with_neighbours=False)
+    sc2.src[:10] = sc2.src[0]
+    sc2.dst[:10] = sc2.dst[0]
+    _load(engine, sc2, neighbours=False)
+    engine.propose_dlt4(6, 0, M)
+    idx2 = engine.get_samples()
+    H2 = engine.get_models()
+    with np.errstate(all="ignore"):
+        H2_ref, _, _ = oracle.dlt4(sc2.src, sc2.dst, idx2)
+        cnt2_ref = oracle.score(sc2.src, sc2.dst, H2_ref, THR2)
+    assert np.isnan(H2_ref).any(axis=1).sum() >= 20, "the scene should produce all-NaN hypotheses"
+    assert np.array_equal(np.isnan(H2), np.isnan(H2_ref))
+    fin2 = ~np.isnan(H2_ref)
+    assert np.array_equal(H2[fin2].view(np.uint64), H2_ref[fin2].view(np.uint64))
+    assert np.array_equal(engine.score(THR2), cnt2_ref)
+
+
 def test_moments_and_collinearity(engine, synth, oracle):
     sc = synth.make_scene(3000, 3, seed=5, with_neighbours=False)
     H = _models(sc, np.random.default_rng(1))
@@ -707,7 +761,7 @@ def test_full_size_labeling_equals_the_reference_gco(engine, synth, oracle):
 
 
 @pytest.mark.parametrize("n,planes,M,max_models", [(3000, 3, 4000, 12), (5000, 3, 10000, 16)])
-def test_greedy_selection_on_the_device(engine, synth, n, planes, M, max_models):
+def test_greedy_selection_on_the_device(engine, synth, oracle, n, planes, M, max_models):
     """mh_select_greedy (csrc/select.hip) against the selection spelt out on the host with the primitives it replaced —
     masked re-score of the WHOLE batch, first maximum, the winner's inliers leave the mask: same hypotheses in the same
     order with the same counts, same homographies, same final mask.  (The device version prunes hypotheses that
@@ -736,6 +790,12 @@ def test_greedy_selection_on_the_device(engine, synth, n, planes, M, max_models)
     assert counters.tolist() == picks and counts.tolist() == counts_ref
     assert np.array_equal(H.view(np.uint64), H_all[picks].view(np.uint64))
     assert np.array_equal(mask_out, mask)
+    # ... and against the ORACLE's own sequential selection (oracle/mh_oracle.cpp section 12) over the oracle's own DLT
+    # of the same counter-RNG tuples: same hypotheses in the same order, same counts, same final support set
+    H_o_all, _, _ = oracle.dlt4(sc.src, sc.dst, oracle.sample4(77, 0, M, n))
+    Hs_o, idx_o, cnt_o, mask_o = oracle.select_greedy(sc.src, sc.dst, H_o_all, THR2, need, max_models)
+    assert idx_o.tolist() == picks and cnt_o.tolist() == counts_ref and np.array_equal(mask_o, mask_out)
+    assert np.max(np.abs(H - Hs_o)) <= 1e-6
     # fewer rounds, same number of copies (mask up; H, counters, mask and one check word down)
     engine.select_greedy(THR2, need, 2, np.ones(n, dtype=np.uint8))
     copies_two = engine.copy_stats(reset=True)
