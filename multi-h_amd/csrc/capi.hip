@@ -129,6 +129,7 @@ struct mh_engine {
     bool profiling = false;
     KernelTimer timers[MH_K_COUNT_];
     int tune_residual_variant = 0;
+    int tune_ld = 0;                         // measurement builds only: row pitch of R in doubles (0 = residual_ld)
     int tune_score_variant = 0;
     int residual_mode = MH_RESIDUAL_FORWARD;
     int tune_ms_batch = 6;                   // mean-shift climb iterations per host round trip
@@ -1323,7 +1324,13 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     int rc = require_models(e);
     if (rc) return rc;
     e->ldr = residual_ld(e->n);
-    HIPCHK(e->R.reserve((size_t)e->m * (size_t)e->ldr));
+    size_t r_elems = (size_t)e->m * (size_t)e->ldr;
+#ifdef MH_TUNING
+    if (e->tune_ld > 0) { e->ldr = std::max<long long>(e->tune_ld, e->ldr); r_elems = (size_t)e->m * (size_t)e->ldr; }
+    // the tile-major measurement variants write whole 16-model x 1024-point blocks
+    r_elems = std::max(r_elems, (size_t)((e->m + 15) / 16 * 16) * (size_t)((e->n + 1023) / 1024 * 1024));
+#endif
+    HIPCHK(e->R.reserve(r_elems));
     HIPCHK(e->counts.reserve(e->m));
     {
         ScopedTimer t(e, MH_K_RESIDUAL);
@@ -1745,6 +1752,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
 #ifdef MH_TUNING
     if (key == 0) { e->tune_residual_variant = value; return MH_OK; }
     if (key == 1) { e->tune_score_variant = value; return MH_OK; }
+    if (key == 13 && value >= 0) { e->tune_ld = value; return MH_OK; }
 #else
     if (key == 0 || key == 1) {
         if (value == 0) return MH_OK;

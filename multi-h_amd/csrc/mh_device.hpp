@@ -123,6 +123,31 @@ __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, d
     return d2;
 }
 
+// The fast path of fwd_d2_fast alone, for callers that have proved ALL its preconditions beforehand for every lane
+// (model_pre and model_far for the model, point_pre for every point of the wave's tile): the same rounded operations in
+// the same order, so the same bits as `/`, and nothing else.
+__device__ __forceinline__ double fwd_d2_lean(double h0, double h1, double h2, double h3, double h4, double h5,
+                                              double h6, double h7, double h8, double x, double y, double x2, double y2)
+{
+    const double s = h6 * x + h7 * y + h8;
+    const double nx = h0 * x + h1 * y + h2;
+    const double ny = h3 * x + h4 * y + h5;
+    double r = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = nx * r;
+    double d = __builtin_fma(-s, q, nx);
+    const double u = __builtin_fma(d, r, q);
+    q = ny * r;
+    d = __builtin_fma(-s, q, ny);
+    const double v = __builtin_fma(d, r, q);
+    const double dx = x2 - u;
+    const double dy = y2 - v;
+    return dx * dx + dy * dy;
+}
+
 // NOT the product arithmetic: the same residual with fused multiply-adds (20 FP64 operations per
 // pair instead of 28).  It rounds differently from the reference (last-bit differences in d2, and
 // therefore possibly different inlier decisions within an ulp of the threshold), so it exists only

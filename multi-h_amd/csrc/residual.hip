@@ -33,8 +33,14 @@ namespace mh {
 // PPL = points per lane (even), MC = models per workgroup.
 // WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
 // NT: non-temporal stores for the R stream.  FAST: shared-reciprocal division (mh_device.hpp).
+// LEAN: per tile and wave, a wave-uniform test — every lane holds real points (a full tile), every point meets the
+// fast division's precondition, no point is masked out — selects, for the models whose own preconditions hold
+// (model_pre, model_far), a sweep without any per-pair bookkeeping: no fallback branch, no exec masking around the stores,
+// no validity mask on the inlier ballot.  Same arithmetic, same bits; what goes is scalar and branch work.
+// TILED (tuning): R stored tile-major — [model block][point tile][MC][TILE] — so that a workgroup writes one contiguous
+// 128-KiB block per tile instead of MC row segments.
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -46,7 +52,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     constexpr int WAVE_PTS = 64 * PPL;          // points per wave per tile
     constexpr int TILE = 4 * WAVE_PTS;          // points per workgroup per tile
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (tells the compiler it is wave-uniform)
     // swapxy (tuning): slice index in blockIdx.x, so that consecutive workgroups write neighbouring
     // chunks of the same rows of R
     const int bx = swapxy ? blockIdx.y : blockIdx.x;
@@ -133,6 +139,15 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
             }
         }
 
+        bool tile_lean = false;                 // wave-uniform
+        if (LEAN) {
+            bool lane_ok = true;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) lane_ok = lane_ok && ok[q] && pok[q];
+            tile_lean = (wbase + WAVE_PTS <= N) && (__builtin_amdgcn_ballot_w64(lane_ok) == ~0ull);
+        }
+        const int tile_idx = base / TILE;       // TILED: which point tile this is
+
         // Not unrolled on purpose: an unrolled model loop lets LICM hoist all MC*9
         // coefficients out of the point sweep (288 registers at MC = 16).
 #pragma unroll 1
@@ -144,8 +159,10 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                 const double* h = HSGPR ? (H + 9 * (size_t)m) : (s_h + 9 * mi);
                 const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5],
                              h6 = h[6], h7 = h[7], h8 = h[8];
-                const bool hok = s_hok[mi] != 0;           // wave-uniform
-                const bool far = FAST && !CONTRACT && s_far[mi] != 0;
+                // wave-uniform by construction (every lane reads the same LDS word); readfirstlane tells the compiler so,
+                // which keeps the choice of sweep a scalar branch instead of an exec-mask dance
+                const bool hok = __builtin_amdgcn_readfirstlane(s_hok[mi]) != 0;
+                const bool far = FAST && !CONTRACT && __builtin_amdgcn_readfirstlane(s_far[mi]) != 0;
                 const bool aok = SYM ? (s_aok[mi] != 0) : false;
                 int c_m = 0;
                 // the chunk loop, once with the per-pair |s| compare and once without (the model's horizon is provably far
@@ -187,7 +204,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                         }
                         if (WRITE_R) {
                             const int n = wbase + c * 128 + lane * 2;
-                            double* dstp = R + (size_t)m * ldr + n;
+                            double* dstp = TILED ? R + ((size_t)bx * ntiles_all + tile_idx) * ((size_t)MC * TILE) + (size_t)mi * TILE + (n - base)
+                                                 : R + (size_t)m * ldr + n;
                             if (n + 1 < N) {
                                 if (NT) {
                                     __builtin_nontemporal_store(d0s, dstp);
@@ -203,7 +221,29 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                         c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1s < thr2) & okm[2 * c + 1]);
                     }
                 };
-                if (far) sweep(std::false_type{});
+                // where row m (or, TILED, this workgroup's block) starts for this wave's first chunk
+                auto row_ptr = [&](int n) -> double* {
+                    if (TILED) return R + ((size_t)bx * ntiles_all + tile_idx) * ((size_t)MC * TILE) + (size_t)mi * TILE + (n - base);
+                    return R + (size_t)m * ldr + n;
+                };
+                if (LEAN && FAST && !SYM && !CONTRACT && !CALIB && tile_lean && hok && far) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const double d0 = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c], py[2 * c], qx[2 * c], qy[2 * c]);
+                        const double d1 = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1], py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
+                        if (WRITE_R) {
+                            double* dstp = row_ptr(wbase + c * 128 + lane * 2);
+                            if (NT) {
+                                __builtin_nontemporal_store(d0, dstp);
+                                __builtin_nontemporal_store(d1, dstp + 1);
+                            } else {
+                                *reinterpret_cast<double2*>(dstp) = make_double2(d0, d1);
+                            }
+                        }
+                        c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 < thr2));
+                        c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1 < thr2));
+                    }
+                } else if (far) sweep(std::false_type{});
                 else sweep(std::true_type{});
                 // lane mi accumulates model mi: read-modify-write of that one lane through the scalar unit
                 const int c_new = __builtin_amdgcn_readlane(cnt, mi) + c_m;
@@ -224,7 +264,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0, int swapxy = 0)
@@ -253,7 +293,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     }
     dim3 grid(gx, psplit);
     if (swapxy) grid = dim3(psplit, gx);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy,
                        p.xmin, p.xmax, p.ymin, p.ymax);
     return hipGetLastError();
@@ -288,6 +328,14 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 8: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 8
     case 9: return launch_rs<6, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 6
     case 10: return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // fused multiply-adds: NOT bit-exact
+    case 20: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean sweep on clean tiles
+    case 21: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // lean + tile-major R
+    case 22: return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);          // lean + nt stores
+    case 23: return launch_rs<4, 16, true, false, false, true, false, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // tile-major R alone
+    case 24: return launch_rs<4, 16, true, false, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration, tile-major R
+    case 25: return launch_rs<6, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 6
+    case 26: return launch_rs<8, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 8
+    case 27: return launch_rs<2, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 2
     default: break;
     }
 #endif

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Energy per (point, model) pair of the residual kernel's variants (runs on the GPU box through gpurun).
+
+For each variant the kernel is launched back to back for SECONDS while a thread samples the board's power sensor and
+the shader clock; J per launch = mean power x mean launch time, pJ per pair = that / (N x M).  If a kernel is bound by
+the board's power cap, variants that do less work per pair draw the SAME power and finish sooner (time follows energy);
+if it is bound by something else, power falls below the cap.  Writes gpurun_out/energy_probe.json; the copy under
+profiles/ is what DESIGN.md section 7 cites.
+
+Measurement variants live in the tuning library only:
+    MH_LIB=multi-h_amd/libmultih_hip_tuning.so python tools/energy_probe.py"""
+import glob, importlib, json, os, subprocess, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+mh = importlib.import_module("multi-h_amd")
+N, M = int(os.environ.get("N", 50000)), int(os.environ.get("M", 100000))
+SECONDS = float(os.environ.get("SECONDS", 3.0))
+VARIANTS = os.environ.get("RV", "0,20,2,22,3,10,7").split(",")
+
+
+def find_sensor():
+    for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+        for f in sorted(glob.glob(pat)):
+            try:
+                if int(open(f).read()) > 0:
+                    return f
+            except Exception:
+                pass
+    return None
+
+
+SENSOR = find_sensor()
+
+
+def sclk_file():
+    f = glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")
+    return f[0] if f else None
+
+
+SCLK = sclk_file()
+
+
+def read_power():
+    if SENSOR:
+        try:
+            return int(open(SENSOR).read()) * 1e-6
+        except Exception:
+            return None
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--json"], capture_output=True, text=True, timeout=10)
+        d = json.loads(r.stdout)
+        for card in d.values():
+            for k, v in card.items():
+                if "ower" in k:
+                    return float(str(v).split()[0])
+    except Exception:
+        return None
+    return None
+
+
+def read_sclk():
+    if not SCLK:
+        return None
+    try:
+        for line in open(SCLK):
+            if "*" in line:
+                return float(line.split(":")[1].strip().lower().replace("mhz", "").replace("*", "").strip())
+    except Exception:
+        return None
+    return None
+
+
+class Sampler(threading.Thread):
+    def __init__(self):
+        super().__init__(daemon=True)
+        self.stop = False
+        self.p, self.c = [], []
+
+    def run(self):
+        while not self.stop:
+            p = read_power()
+            if p is not None:
+                self.p.append(p)
+            c = read_sclk()
+            if c is not None:
+                self.c.append(c)
+            time.sleep(0.02 if SENSOR else 0.2)
+
+
+sc = mh.synth.make_scene(N, 10, seed=1234, with_neighbours=False)
+e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+e.set_correspondences(sc.src, sc.dst, sc.aff)
+e.propose_dlt4(1234, 0, M)
+thr2 = 2.2 ** 2
+out = {"points": N, "models": M, "seconds_per_variant": SECONDS, "power_sensor": SENSOR or "rocm-smi --showpower",
+       "idle_power_W": read_power(), "variants": []}
+
+
+def measure(name, launch, kid, pairs_bytes):
+    launch(); e.synchronize()
+    s = Sampler(); s.start()
+    e.profile_reset(); e.profile_enable(True)
+    t0 = time.time(); launches = 0
+    while time.time() - t0 < SECONDS:
+        for _ in range(20):
+            launch()
+        e.synchronize(); launches += 20
+    wall = time.time() - t0
+    s.stop = True; s.join()
+    n, ms = e.profile_get(kid); e.profile_enable(False)
+    ms /= max(n, 1)
+    # the first fifth of the samples still sees the ramp from the previous state
+    p = s.p[len(s.p) // 5:] or [float("nan")]
+    c = s.c[len(s.c) // 5:] or [float("nan")]
+    P = sum(p) / len(p)
+    rec = {"variant": name, "ms_per_launch": ms, "launches": launches, "busy_fraction": ms * launches / (wall * 1e3),
+           "power_W_mean": P, "power_W_min": min(p), "power_W_max": max(p), "power_samples": len(p), "sclk_MHz_mean": sum(c) / len(c),
+           "J_per_launch": P * ms * 1e-3, "pJ_per_pair": P * ms * 1e-3 / (N * M) * 1e12,
+           "GBps_equivalent": pairs_bytes / ms / 1e6}
+    out["variants"].append(rec)
+    print(json.dumps(rec), flush=True)
+    time.sleep(1.0)
+
+
+names = {"0": "product (PPL 4, MC 16, checked sweep)", "20": "lean sweep on clean tiles", "2": "nt stores", "22": "lean + nt stores",
+         "3": "compiler IEEE division (41 VALU/pair)", "10": "fused multiply-adds (20 FP64 ops/pair, NOT bit-exact)",
+         "7": "store-only calibration (no arithmetic)", "21": "lean + tile-major R", "23": "tile-major R", "24": "store-only, tile-major R",
+         "25": "lean PPL 6", "26": "lean PPL 8", "27": "lean PPL 2"}
+for v in VARIANTS:
+    v = v.strip()
+    if not v:
+        continue
+    try:
+        e.set_tuning(0, int(v))
+    except Exception as ex:
+        print(f"variant {v}: not in this library ({ex})", flush=True)
+        continue
+    measure(f"residual {v}: {names.get(v, '')}", lambda: e.residual_matrix(thr2, fetch_R=False, fetch_counts=False), 1, 8.0 * N * M)
+e.set_tuning(0, 0)
+measure("fused score (no stores)", lambda: e.score(thr2, fetch=False), 2, 8.0 * N * M)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "energy_probe.json")), "w") as f:
+    json.dump(out, f, indent=1)
