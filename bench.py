@@ -5,8 +5,12 @@ One "step" = one pass of the propose-score hot path over one hypothesis batch:
     propose   M 4-tuples (counter RNG) -> batched 4-point DLT          (k_dlt4)
     score     N x M forward-transfer residual matrix written to HBM,
               inlier counts fused into the same kernel                 (k_residual)
-    gather    (N_gpus > 1) RCCL all-gather of the per-model int32 scores
-    select    best model (arg-max of the scores) on every rank, identical everywhere
+    gather    (N_gpus > 1) RCCL all-gather of the per-model int32 scores, enqueued on the engine's stream by the
+              native transport (multi-h_amd/host/rccl_transport.cpp: ncclAllGather; no Python in the exchange)
+    select    best model on every rank, identical everywhere (the engine's own arg-max kernel, csrc/select.hip)
+The steps are software-pipelined: the DLT solve of batch i+1 (LDS-bound) runs on the engine's second stream while the
+residual sweep of batch i (HBM/FP64-bound) runs on the main one (mh_prefetch_dlt4 / mh_adopt_prefetched).  Every
+timed step still proposes one batch and scores one batch; nothing is cached or skipped.
 Workload at N=1 = BASELINE.json configs[2]: 50 000 correspondences / 10 planes,
 100 000 hypotheses (the configuration the metric is quoted on; it fits one GPU:
 R is 40 GB of the 288 GB).  Inputs are resident in HBM before the timed region.
@@ -110,6 +114,20 @@ def labeling_extra(mh, eng, a, thr2, lam):
     gpu_ms = (time.perf_counter() - t0) * 1e3
     out = {"sites": sc.n, "labels": H.shape[0] + 1, "neighbour_hits": int(sc.hit_col.size),
            "gpu_labeling_step_ms": gpu_ms, "energy": int(energy), "cycles": int(cycles)}
+    # B4: per-label HAF re-estimation, GPU kernel vs the oracle's restatement of
+    # GetHomographyHAFNonminimal (M/MultiH.cpp:913-989) on one host core, same labels
+    eng.set_models(H)
+    eng.reestimate(lab)
+    eng.profile_reset(); eng.profile_enable(True)
+    for _ in range(5):
+        eng.set_models(H)
+        H_gpu = eng.reestimate(lab)
+    n_re, ms_re = eng.profile_get(5)
+    eng.profile_enable(False)
+    t0 = time.perf_counter()
+    H_cpu, _ = O.haf_reestimate(sc.src, sc.dst, sc.aff, lab, H, sc.F, sc.e2)
+    out["reestimate"] = {"gpu_kernel_ms": ms_re / max(n_re, 1), "cpu_port_ms": (time.perf_counter() - t0) * 1e3, "cores": 1,
+                         "identical_bits": bool(np.array_equal(H_gpu.view(np.uint64), H_cpu.view(np.uint64)))}
     if O.ref() is not None:
         t0 = time.perf_counter()
         lab_r, e_r = O.ref_expand_formula(sc.src, sc.dst, H, lam, thr2, sc.hit_rowptr, sc.hit_col)
@@ -226,6 +244,38 @@ def main():
     eng.set_correspondences(sc.src, sc.dst, sc.aff)
     eng.set_epipolar(sc.F, sc.e2)
 
+    # Multi-GPU transport of the score exchange.  On a real node: RCCL through the engine's native transport
+    # (libmultih_rccl.so) — torch.distributed only carries the 128-byte unique id to the other ranks once, outside the
+    # timed region.  MH_BENCH_BACKEND=gloo (several ranks rehearsing on ONE GPU, which RCCL refuses): the
+    # host-synchronised torch.distributed hook instead.
+    transport_kind = None
+    keep = []
+    if world > 1:
+        import ctypes
+        if backend == "nccl":
+            rl = ctypes.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so"))
+            rl.mhr_last_error.restype = ctypes.c_char_p
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (ctypes.c_ubyte * 128)()
+                if rl.mhr_unique_id(buf) != 0:
+                    raise SystemExit("mhr_unique_id: " + rl.mhr_last_error().decode())
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            uid = uid.to(dev)
+            dist.broadcast(uid, src=0)
+            raw = (ctypes.c_ubyte * 128)(*uid.cpu().tolist())
+            comm = ctypes.c_void_p()
+            if rl.mhr_init(ctypes.byref(comm), rank, world, raw, local_rank) != 0:
+                raise SystemExit("mhr_init: " + rl.mhr_last_error().decode())
+            eng.set_transport(rank, world, stream_fn=rl.mhr_allgather, ctx=comm)
+            keep += [rl, comm]
+            transport_kind = "native RCCL (ncclAllGather on the engine's stream, libmultih_rccl.so)"
+        else:
+            hook = sharding.make_allgather_hook(world, dev)
+            eng.set_transport(rank, world, host_fn=hook)
+            keep.append(hook)
+            transport_kind = f"torch.distributed hook over {backend} (rehearsal)"
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -239,42 +289,56 @@ def main():
         else:
             sizes = sharding.shard_counts(a.models, world)   # one batch of M split across the GPUs (configs[3])
         M = sizes[rank]
-        gathered = torch.empty(sum(sizes), dtype=torch.int32, device=dev) if world > 1 else None
+        total = sum(sizes)
 
-        def step(i: int):
+        def first_of(i: int) -> int:
             if scaling == "weak":
-                first = sharding.batch_first(i, world, rank, M)     # disjoint RNG counters per (step, rank)
-            else:
-                first = i * a.models + sharding.shard_range(a.models, world, rank)[0]
-            eng.propose_dlt4(a.seed, first, M)
-            eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
-            ptr, _ = eng.device_buffer(0)
-            counts = torch.as_tensor(_DevView(ptr, M, "<i4"), device=dev)
-            scores = sharding.gather_scores(counts, world, out=gathered, sizes=sizes)
-            return sharding.select_best(scores), scores
+                return sharding.batch_first(i, world, rank, M)     # disjoint RNG counters per (step, rank)
+            return i * a.models + sharding.shard_range(a.models, world, rank)[0]
 
+        def step(i: int, last: bool = False):
+            eng.adopt_prefetched()                           # batch i (its DLT ran beside the previous sweep)
+            eng.prefetch_dlt4(a.seed, first_of(i + 1), M)    # batch i+1 on the second stream, beside this sweep
+            eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
+            return eng.select_best(total, fetch=last)        # (all-gather +) arg-max on the engine's stream
+
+        eng.prefetch_dlt4(a.seed, first_of(0), M)
         for i in range(warmup):
             step(i)
         fence()
         eng.profile_reset()
         eng.profile_enable(True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
+        marks[0].record()
         last = None
         for i in range(steps):
-            last = step(warmup + i)
+            last = step(warmup + i, last=(i == steps - 1))
+            marks[i + 1].record()
         fence()
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         n_res, ms_res = eng.profile_get(1)       # MH_K_RESIDUAL
-        n_dlt, ms_dlt = eng.profile_get(0)       # MH_K_DLT4
-        (best, score), scores = last
+        n_dlt, ms_dlt = eng.profile_get(0)       # MH_K_DLT4 (on the second stream, beside the sweep)
+        best, score = last
         import hashlib
+        import numpy as np
+        if world > 1:
+            ptr, _ = eng.device_buffer(5)        # MH_BUF_GATHERED_SCORES: world x longest, -1 padded
+            longest = max(sizes)
+            g = torch.as_tensor(_DevView(ptr, world * longest, "<i4"), device=dev).cpu().numpy().reshape(world, longest)
+            scores = np.concatenate([g[r, :sizes[r]] for r in range(world)])
+        else:
+            ptr, _ = eng.device_buffer(0)
+            scores = torch.as_tensor(_DevView(ptr, M, "<i4"), device=dev).cpu().numpy()
         return {"sizes": sizes, "M": M, "dt": float(tt.item()), "res_ms": ms_res / max(n_res, 1),
-                "dlt_ms": ms_dlt / max(n_dlt, 1), "best_model": int(best.item()), "best_score": int(score.item()),
-                "scores_sha256": hashlib.sha256(scores.cpu().numpy().tobytes()).hexdigest()[:16]}
+                "dlt_ms": ms_dlt / max(n_dlt, 1), "best_model": int(best), "best_score": int(score),
+                "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "step_ms_max": per_step[-1],
+                "scores_sha256": hashlib.sha256(np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]}
 
     head = run_mode(a.scaling, a.steps, a.warmup)
     other = None
@@ -292,6 +356,23 @@ def main():
     n_sc, ms_sc = eng.profile_get(2)         # MH_K_SCORE
     eng.profile_enable(False)
     fused_ms = ms_sc / max(n_sc, 1)
+    # ... the DLT solver alone on an idle chip (inside the steps it runs beside the sweep on the second stream) ...
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for i in range(5):
+        eng.propose_dlt4(a.seed, i * M, M)
+    eng.synchronize()
+    n_d, ms_d = eng.profile_get(0)
+    dlt_alone_ms = ms_d / max(n_d, 1)
+    # ... and the s = 4 variant of the matrix: the int32 data cost of every hypothesis against every point
+    eng.profile_reset()
+    for _ in range(4):
+        eng.cost_matrix(fetch_C=False, fetch_counts=False)
+    eng.synchronize()
+    n_cm, ms_cm = eng.profile_get(6)         # MH_K_COSTMATRIX
+    eng.profile_enable(False)
+    cost_ms = ms_cm / max(n_cm, 1)
+    cost_bytes = 4.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
     avg_res_ms = head["res_ms"]
     alg_bytes = 8.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
     achieved = alg_bytes / (avg_res_ms * 1e-3) / 1e9
@@ -333,8 +414,23 @@ def main():
                        "parallelism": f"hypothesis-sharded x{world}"},
             "residual_kernel_GBps": achieved,
             "pair_evals_per_s": total_hyp * N / dt,
-            "kernel_ms": {"k_residual": avg_res_ms, "k_dlt4": head["dlt_ms"], "k_score_fused": fused_ms},
+            "step_ms": {"median": head["step_ms_median"], "min": head["step_ms_min"], "max": head["step_ms_max"],
+                        "mean_wall": dt / a.steps * 1e3, "note": "HIP events on the engine's stream at every step boundary"},
+            "kernel_ms": {"k_residual": avg_res_ms, "k_dlt4_beside_the_sweep": head["dlt_ms"], "k_dlt4_alone": dlt_alone_ms,
+                          "k_score_fused": fused_ms, "k_cost_matrix_int32": cost_ms},
+            "step_minus_residual_ms": head["step_ms_median"] - avg_res_ms,
+            "transport": transport_kind,
             "fused_score_hypotheses_per_s_per_gpu": M / (fused_ms * 1e-3),
+            # fused score kernel: FP64-issue bound.  28 rounded FP64 operations per pair (M/MultiH.cpp:434-441 with two IEEE
+            # divisions sharing one refined reciprocal) against the chip's FP64 vector issue rate at its 2.4 GHz maximum
+            # (256 CUs x 4 SIMDs x 16 lanes per clock = 39.3 T operations/s, i.e. the 78.6 TFLOP/s spec counting an FMA as two)
+            "fused_score_fp64": {"ops_per_pair": 28, "ops_per_s": 28.0 * N * M / (fused_ms * 1e-3),
+                                 "peak_ops_per_s_at_2.4GHz": 256 * 4 * 16 * 2.4e9,
+                                 "utilisation_vs_2.4GHz_peak": 28.0 * N * M / (fused_ms * 1e-3) / (256 * 4 * 16 * 2.4e9)},
+            "cost_matrix_s4": {"what": "int32 PEARL data cost of every hypothesis against every point, materialised (mh_cost_matrix): "
+                                       "the s = 4 variant of SURVEY 8(d); FP64-issue bound (a second IEEE division per pair), not HBM bound",
+                               "ms": cost_ms, "algorithmic_bytes_per_launch": cost_bytes, "GBps": cost_bytes / (cost_ms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": cost_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes,

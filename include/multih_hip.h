@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 1
+#define MH_ABI_VERSION 2
 
 /* exported even when the library is built with -fvisibility=hidden */
 #if defined(__GNUC__) || defined(__clang__)
@@ -167,6 +167,11 @@ MH_API int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, 
  * written to HBM by one kernel that also produces the inlier counts.  R_host (nullable)
  * receives a host copy — leave NULL to keep the matrix on the device only. */
 MH_API int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts);
+/* The s = 4 variant of the matrix: the int32 PEARL data cost (dataEnergy, M/MultiH.cpp:473-504, label =
+ * model + 1) of every current model against every point, model-major C[m*n + i], written to HBM by one kernel that also
+ * produces the inlier counts (strict d2 < thr_hom^2).  Uses the engine's lambda and thr_hom (mh_set_params).  C_host
+ * (nullable) receives a host copy. */
+MH_API int mh_cost_matrix(mh_engine* e, int* C_host, int* counts);
 /* Copy rows [first, first+count) of the resident residual matrix (valid after
  * mh_residual_matrix) to the host, tightly packed count x n doubles. */
 MH_API int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host);
@@ -177,22 +182,49 @@ MH_API int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_val
  * model set is left untouched.  Used by the sharded propose stage, where the winning hypothesis
  * of a round may live on another rank. */
 MH_API int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int label_value, int* labels /* in/out n */);
+/* ---- multi-GPU transport (one process per GPU, hypotheses sharded, correspondences replicated) ------
+ * The reference is a single process; the one exchange north_star adds is an all-gather of per-model inlier scores.
+ * The engine calls the transport with DEVICE pointers: send `bytes_per_rank` bytes, receive world * bytes_per_rank in
+ * rank order.  Two kinds (give exactly one; both NULL with world = 1 clears the transport):
+ *   stream_fn  enqueues the collective on `hip_stream` (the engine's stream) and returns at once — ncclAllGather of
+ *              RCCL; multi-h_amd/host/rccl_transport.cpp is that function.  No host synchronisation, no Python.
+ *   host_fn    is called with the engine's stream idle and returns once recv_dev is complete (the torch.distributed
+ *              hook of multi-h_amd/sharding.py, used to rehearse several ranks on one GPU over gloo).
+ * Rank r owns the hypotheses [r * base + min(r, rem), ...) of a batch of total_m (base = total_m / world, rem = total_m
+ * % world, the first rem shards one longer) as its resident model set. */
+typedef int (*mh_allgather_stream_fn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank,
+                                      void* hip_stream);
+typedef int (*mh_allgather_dev_fn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank);
+MH_API int mh_set_transport(mh_engine* e, int rank, int world, mh_allgather_stream_fn stream_fn, mh_allgather_dev_fn host_fn,
+                            void* ctx);
 /* Greedy model selection over the resident hypothesis batch, on the device (csrc/select.hip): up to `max_models`
  * rounds of {score the candidates over the points still in the support mask, take the best — highest count, lowest
- * hypothesis counter on ties —, stop if it has fewer than `need` inliers, take its inliers out of the mask}.  This is
- * the sequential-RANSAC scheme of the dead M/MultipleHomographies.h:146-175 behind MultiH::ProposeModels.
+ * position in the WHOLE batch on ties —, stop if it has fewer than `need` inliers, take its inliers out of the mask}.
+ * This is the sequential-RANSAC scheme of the dead M/MultipleHomographies.h:146-175 behind MultiH::ProposeModels.
  * point_mask (n bytes, nullable = all ones): in = points that may support a model, out = points no selected model
  * explains.  H_out: max_models x 9; counters_out / counts_out (nullable): position of each selected hypothesis in the
- * batch and its inlier count when selected.  Per round the host reads three control words from mapped memory; no
- * host<->device copy is issued inside the loop (mh_get_copy_stats).
- * Sharded batch (one process per GPU, rank r of `world` holds its shard of the batch as the resident model set):
- * `exchange` all-gathers DEVICE buffers in rank order (RCCL on a real node) — per round the int32 score vectors of
- * `shard_longest` entries per rank (north_star's exchange) and the 72-byte H every rank offers; counters_out then
- * index the gathered vector (rank * shard_longest + position).  world = 1: exchange = NULL, shard_longest ignored. */
-typedef int (*mh_allgather_dev_fn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank);
+ * whole batch and its inlier count when selected.  Per round the host reads five control words from mapped memory; no
+ * host<->device copy is issued inside the loop (mh_get_copy_stats).  Forward transfer error only (MH_ERR_INVALID in
+ * symmetric mode).
+ * Sharded batch (a transport is set; total_m = size of the whole batch, 0 = the resident set is the whole batch): in the
+ * first round the ranks all-gather their int32 score vectors (north_star's exchange); in every round they all-gather
+ * one 88-byte record each — {best score and its position, that hypothesis' H, an error word} — and pick the same
+ * winner.  Outputs do not depend on the number of ranks.  A rank-local failure travels in the error word, so all ranks
+ * leave the loop together. */
 MH_API int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsigned char* point_mask,
-                            double* H_out, long long* counters_out, int* counts_out, int* selected_out,
-                            int rank, int world, int shard_longest, mh_allgather_dev_fn exchange, void* ctx);
+                            double* H_out, long long* counters_out, int* counts_out, int* selected_out, long long total_m);
+/* Pipelined propose: mh_prefetch_dlt4 prepares the batch (seed, first .. first+m-1) in the engine's SPARE model buffer on a
+ * second stream, concurrently with whatever the main stream is doing (the DLT solver is LDS-bound, the residual sweep
+ * HBM/FP64-bound; csrc/dlt4.hip); mh_adopt_prefetched makes it the current model set — the main stream waits for the
+ * side stream's event, the host does not wait at all.  Same hypotheses, bit for bit, as mh_propose_dlt4. */
+MH_API int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int m);
+MH_API int mh_adopt_prefetched(mh_engine* e);
+/* Best-supported model of the scored batch (highest resident inlier count, lowest position in the whole batch on ties) by
+ * the engine's own arg-max kernel.  With a transport and world > 1 the ranks first all-gather their int32 score vectors
+ * on the engine's stream (BASELINE configs[3]; the gathered vector stays resident: MH_BUF_GATHERED_SCORES) and every
+ * rank finds the same winner.  best_index / best_count both NULL: enqueue only (no host synchronisation; a later call
+ * with outputs, or mh_synchronize, completes it). */
+MH_API int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* best_count);
 /* Number of explicit host<->device copies mh_select_greedy has issued since the last reset. */
 MH_API int mh_get_copy_stats(mh_engine* e, long long* h2d, long long* d2h, int reset);
 /* Per-model inlier moments {n, Sx, Sy, Sxx, Sxy, Syy} and smallest eigenvalue of the 3x3
@@ -229,7 +261,7 @@ MH_API int mh_reestimate(mh_engine* e, const int* labels, double* H_out);
 MH_API int mh_labeling_step(mh_engine* e, int warm, int* labeling, double* energy, int* cycles);
 
 /* ---- device-side access (bench / multi-GPU plumbing) --------------------- */
-enum { MH_BUF_COUNTS = 0, MH_BUF_MODELS = 1, MH_BUF_RESIDUALS = 2, MH_BUF_LABELS = 3, MH_BUF_COST = 4 };
+enum { MH_BUF_COUNTS = 0, MH_BUF_MODELS = 1, MH_BUF_RESIDUALS = 2, MH_BUF_LABELS = 3, MH_BUF_COST = 4, MH_BUF_GATHERED_SCORES = 5 };
 /* Device pointer and size in bytes of a resident buffer (valid until the next call that
  * re-allocates it).  Used to wrap the per-model scores in a tensor for the RCCL all-gather. */
 MH_API int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long* bytes);
@@ -237,7 +269,7 @@ MH_API int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned lo
 /* Per-kernel HIP-event timing on the engine's stream.  When enabled every launch of the
  * instrumented kernels is bracketed by events; stats are resolved at the next synchronize. */
 enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K_EXPAND = 4,
-       MH_K_REESTIMATE = 5, MH_K_COUNT_ = 6 };
+       MH_K_REESTIMATE = 5, MH_K_COSTMATRIX = 6, MH_K_COUNT_ = 7 };
 MH_API int mh_profile_enable(mh_engine* e, int on);
 MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);

@@ -21,6 +21,7 @@ BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libmultih_hip.so")
 HOST_LIB = os.path.join(HERE, "libmultih_host.so")
 HARNESS = os.path.join(HERE, "multih_harness")
+RCCL_LIB = os.path.join(HERE, "libmultih_rccl.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
@@ -71,6 +72,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(HOST, f) for f in ("MultiH.cpp", "merge_step.cpp")]
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "multih_hip.h"))
+    hdrs.append(os.path.join(ROOT, "include", "multih_rccl.h"))
     cxx = os.environ.get("CXX", "g++")
     flags = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-Wall", "-I" + os.path.join(ROOT, "include"),
              "-I" + HOST]
@@ -79,9 +81,18 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
             print("[build] host layer (class MultiH over the C ABI)")
         _run([cxx] + flags + ["-shared", "-o", HOST_LIB] + srcs +
              ["-L" + HERE, "-lmultih_hip", "-Wl,-rpath,$ORIGIN"])
+    # the native multi-GPU transport (RCCL's ncclAllGather on the engine's stream): a library of its own, so that neither
+    # the engine nor the host class depends on librccl
+    rccl_src = os.path.join(HOST, "rccl_transport.cpp")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if os.path.exists(rccl_src) and (force or _newer(RCCL_LIB, [rccl_src] + hdrs)):
+        if verbose:
+            print("[build] RCCL transport (libmultih_rccl.so)")
+        _run([cxx, "-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include", "-I" + HOST, "-I" + os.path.join(ROOT, "include"),
+              "-shared", "-o", RCCL_LIB, rccl_src, "-L" + rocm + "/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + rocm + "/lib"])
     main = os.path.join(HOST, "main.cpp")
-    if os.path.exists(main) and (force or _newer(HARNESS, [main, HOST_LIB] + hdrs)):
-        _run([cxx] + flags + ["-o", HARNESS, main, "-L" + HERE, "-lmultih_host", "-lmultih_hip",
+    if os.path.exists(main) and (force or _newer(HARNESS, [main, HOST_LIB, RCCL_LIB] + hdrs)):
+        _run([cxx] + flags + ["-o", HARNESS, main, "-L" + HERE, "-lmultih_host", "-lmultih_hip", "-ldl",
                               "-Wl,-rpath,$ORIGIN"])
     return HOST_LIB
 

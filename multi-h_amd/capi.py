@@ -17,7 +17,7 @@ MH_OK = 0
 ERR_NAMES = {-1: "MH_ERR_NO_DEVICE", -2: "MH_ERR_INVALID", -3: "MH_ERR_HIP", -4: "MH_ERR_NOT_SET",
              -5: "MH_ERR_OVERFLOW"}
 BUF_COUNTS, BUF_MODELS, BUF_RESIDUALS, BUF_LABELS, BUF_COST = 0, 1, 2, 3, 4
-K_DLT4, K_RESIDUAL, K_SCORE, K_DATACOST, K_EXPAND, K_REESTIMATE = 0, 1, 2, 3, 4, 5
+K_DLT4, K_RESIDUAL, K_SCORE, K_DATACOST, K_EXPAND, K_REESTIMATE, K_COSTMATRIX = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/multih_hip.h declares (tests check the export table against this)
 SYMBOLS = [
@@ -27,7 +27,7 @@ SYMBOLS = [
     "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
-    "mh_residual_matrix", "mh_get_residual_rows", "mh_select_greedy", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_get_expand_trace", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
@@ -274,12 +274,20 @@ class Engine:
                                                 _p(cnt, C.c_int) if fetch_counts else None))
         return R, cnt
 
+    def cost_matrix(self, fetch_C: bool = True, fetch_counts: bool = True):
+        """mh_cost_matrix: int32 data cost of every model against every point (model-major), fused inlier counts."""
+        m = self.model_count
+        Cm = np.empty((m, self.n), dtype=np.int32) if fetch_C else None
+        cnt = np.empty(m, dtype=np.int32) if fetch_counts else None
+        self._check(self.lib.mh_cost_matrix(self._h, _p(Cm, C.c_int) if fetch_C else None, _p(cnt, C.c_int) if fetch_counts else None))
+        return Cm, cnt
+
     def get_residual_rows(self, first: int, count: int):
         rows = np.empty((count, self.n), dtype=np.float64)
         self._check(self.lib.mh_get_residual_rows(self._h, int(first), int(count), _p(rows, C.c_double)))
         return rows
 
-    def select_greedy(self, thr2: float, need: int, max_models: int, mask=None):
+    def select_greedy(self, thr2: float, need: int, max_models: int, mask=None, total_m: int = 0):
         """Greedy selection over the resident batch on the device (mh_select_greedy, one rank).
         Returns (H [k,9], counters [k], counts [k], mask_out or None)."""
         H = np.zeros((int(max_models), 9))
@@ -290,8 +298,31 @@ class Engine:
         self._check(self.lib.mh_select_greedy(self._h, C.c_double(thr2), int(need), int(max_models),
                                               None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)),
                                               _p(H, C.c_double), counters.ctypes.data_as(C.POINTER(C.c_longlong)),
-                                              _p(counts, C.c_int), C.byref(k), 0, 1, 0, None, None))
+                                              _p(counts, C.c_int), C.byref(k), C.c_longlong(int(total_m))))
         return H[:k.value].copy(), counters[:k.value].copy(), counts[:k.value].copy(), m
+
+    def set_transport(self, rank: int, world: int, stream_fn=None, host_fn=None, ctx=None):
+        """mh_set_transport: stream_fn = a C function pointer that enqueues the all-gather on the engine's stream
+        (mhr_allgather of libmultih_rccl.so), host_fn = a host-synchronised ctypes hook (sharding.make_allgather_hook)."""
+        self._transport_keepalive = (stream_fn, host_fn, ctx)
+        self._check(self.lib.mh_set_transport(self._h, int(rank), int(world), C.cast(stream_fn, C.c_void_p) if stream_fn else None,
+                                              C.cast(host_fn, C.c_void_p) if host_fn else None,
+                                              ctx if isinstance(ctx, C.c_void_p) else C.c_void_p(ctx or 0)))
+
+    def prefetch_dlt4(self, seed: int, first: int, m: int):
+        self._check(self.lib.mh_prefetch_dlt4(self._h, C.c_ulonglong(seed), C.c_longlong(first), int(m)))
+
+    def adopt_prefetched(self):
+        self._check(self.lib.mh_adopt_prefetched(self._h))
+
+    def select_best(self, total_m: int = 0, fetch: bool = True):
+        """(index in the whole batch, count) of the best-supported model; fetch=False only enqueues."""
+        if not fetch:
+            self._check(self.lib.mh_select_best(self._h, C.c_longlong(int(total_m)), None, None))
+            return None
+        idx, cnt = C.c_longlong(0), C.c_int(0)
+        self._check(self.lib.mh_select_best(self._h, C.c_longlong(int(total_m)), C.byref(idx), C.byref(cnt)))
+        return int(idx.value), int(cnt.value)
 
     def copy_stats(self, reset=False):
         a, b = C.c_longlong(0), C.c_longlong(0)

@@ -82,13 +82,33 @@ struct mh_engine {
     DevBuf<int> samples, counts;
     DevBuf<double> R;
     long long ldr = 0;
+    DevBuf<int> C;                            // mh_cost_matrix
+    long long ldc = 0;
     DevBuf<unsigned char> mask;
     DevBuf<double> moments, min_eig;
     // greedy selection (select.hip): two candidate lists, control words, exchange buffers
     DevBuf<int> sel_orig[2], sel_counts, sel_rec, sel_scores, sel_gathered;
-    DevBuf<double> sel_cand_H[2], sel_out_H, sel_my_H, sel_all_H;
+    DevBuf<double> sel_cand_H[2], sel_out_H;
+    DevBuf<SelRecord> sel_records;             // [0] this rank's offer, [1 .. world] the gathered offers
     DevBuf<long long> sel_counter;
     DevBuf<unsigned long long> sel_keys;
+    // transport of the sharded propose stage (mh_set_transport): stream-ordered (RCCL) or host-synchronised (test hook)
+    int t_rank = 0, t_world = 1;
+    mh_allgather_stream_fn t_stream_fn = nullptr;
+    mh_allgather_dev_fn t_host_fn = nullptr;
+    void* t_ctx = nullptr;
+    // pipelined propose (mh_prefetch_dlt4): the spare batch and the second stream it is prepared on
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_side = nullptr, ev_main = nullptr;
+    DevBuf<double> H_next;
+    DevBuf<int> samples_next;
+    int m_next = 0;
+    bool next_valid = false;
+    // best model of a scored batch (mh_select_best)
+    DevBuf<unsigned long long> best_key;
+    int* h_best = nullptr;                     // mapped pinned: count, global index, sequence number
+    int* h_best_dev = nullptr;
+    int best_seq = 0;
     int* h_sel = nullptr;                      // mapped pinned mirror of the control words
     int* h_sel_dev = nullptr;
     long long copies_h2d = 0, copies_d2h = 0;  // explicit host<->device copies issued by mh_select_greedy (mh_get_copy_stats)
@@ -165,17 +185,18 @@ int guarded(Fn&& fn)
 struct ScopedTimer {
     mh_engine* e;
     int k;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(mh_engine* e_, int k_) : e(e_), k(k_)
+    ScopedTimer(mh_engine* e_, int k_, hipStream_t on = nullptr) : e(e_), k(k_), st(on ? on : e_->stream)
     {
         if (!e->profiling) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        (void)hipEventRecord(a, e->stream);
+        (void)hipEventRecord(a, st);
     }
     ~ScopedTimer()
     {
         if (!a) return;
-        (void)hipEventRecord(b, e->stream);
+        (void)hipEventRecord(b, st);
         e->timers[k].pending.emplace_back(a, b);
     }
 };
@@ -642,7 +663,7 @@ void mh_destroy(mh_engine* e)
     e->x1.release(); e->y1.release(); e->x2.release(); e->y2.release();
     e->a11.release(); e->a12.release(); e->a21.release(); e->a22.release();
     e->d_rowptr.release(); e->d_col.release(); e->d_w.release(); e->d_rev.release();
-    e->H.release(); e->samples.release(); e->counts.release(); e->R.release(); e->mask.release();
+    e->H.release(); e->samples.release(); e->counts.release(); e->R.release(); e->C.release(); e->mask.release();
     e->moments.release(); e->min_eig.release();
     e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
     e->fund_inl.release(); e->fund_mask.release(); e->ref_keep.release(); e->ref_in.release(); e->ref_out.release();
@@ -664,7 +685,12 @@ void mh_destroy(mh_engine* e)
     if (e->h_sel) (void)hipHostFree(e->h_sel);
     for (int b = 0; b < 2; ++b) { e->sel_orig[b].release(); e->sel_cand_H[b].release(); }
     e->sel_counts.release(); e->sel_rec.release(); e->sel_scores.release(); e->sel_gathered.release(); e->sel_out_H.release();
-    e->sel_my_H.release(); e->sel_all_H.release(); e->sel_counter.release(); e->sel_keys.release();
+    e->sel_records.release(); e->sel_counter.release(); e->sel_keys.release();
+    e->H_next.release(); e->samples_next.release(); e->best_key.release();
+    if (e->h_best) (void)hipHostFree(e->h_best);
+    if (e->ev_side) (void)hipEventDestroy(e->ev_side);
+    if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+    if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1348,6 +1374,27 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     });
 }
 
+int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
+{
+    return guarded([&]() -> int {
+    int rc = require_models(e);
+    if (rc) return rc;
+    e->ldc = cost_ld(e->n);
+    HIPCHK(e->C.reserve((size_t)e->m * (size_t)e->ldc));
+    HIPCHK(e->counts.reserve(e->m));
+    {
+        ScopedTimer t(e, MH_K_COSTMATRIX);
+        HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, e->thr_H * e->thr_H, e->C.p, e->ldc, e->counts.p, e->stream));
+    }
+    if (C_host)
+        HIPCHK(hipMemcpy2DAsync(C_host, sizeof(int) * e->n, e->C.p, sizeof(int) * e->ldc, sizeof(int) * e->n, e->m,
+                                hipMemcpyDeviceToHost, e->stream));
+    if (counts) HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
+    if (C_host || counts) HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+    });
+}
+
 int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
 {
     return guarded([&]() -> int {
@@ -1364,20 +1411,57 @@ int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
     });
 }
 
+// all-gather on the engine's stream through whichever transport is set; the host-synchronised hook sees an idle stream
+static int exchange(mh_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank)
+{
+    if (e->t_stream_fn) {
+        if (e->t_stream_fn(e->t_ctx, send_dev, recv_dev, (unsigned long long)bytes_per_rank, (void*)e->stream) != 0)
+            return fail(MH_ERR_INVALID, "all-gather failed (stream-ordered transport)");
+        return MH_OK;
+    }
+    if (!e->t_host_fn) return fail(MH_ERR_NOT_SET, "no transport set (mh_set_transport)");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->t_host_fn(e->t_ctx, send_dev, recv_dev, (unsigned long long)bytes_per_rank) != 0)
+        return fail(MH_ERR_INVALID, "all-gather failed (host-synchronised transport)");
+    return MH_OK;
+}
+
+int mh_set_transport(mh_engine* e, int rank, int world, mh_allgather_stream_fn stream_fn, mh_allgather_dev_fn host_fn, void* ctx)
+{
+    return guarded([&]() -> int {
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (world < 1 || rank < 0 || rank >= world) return fail(MH_ERR_INVALID, "bad rank / world");
+    if (stream_fn && host_fn) return fail(MH_ERR_INVALID, "give ONE transport: stream-ordered or host-synchronised");
+    if (world > 1 && !stream_fn && !host_fn) return fail(MH_ERR_INVALID, "world > 1 needs a transport");
+    e->t_rank = rank; e->t_world = world; e->t_stream_fn = stream_fn; e->t_host_fn = host_fn; e->t_ctx = ctx;
+    return MH_OK;
+    });
+}
+
 int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsigned char* point_mask,
-                     double* H_out, long long* counters_out, int* counts_out, int* selected_out,
-                     int rank, int world, int shard_longest, mh_allgather_dev_fn exchange, void* ctx)
+                     double* H_out, long long* counters_out, int* counts_out, int* selected_out, long long total_m)
 {
     return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (!H_out || !selected_out || max_models <= 0 || need < 1) return fail(MH_ERR_INVALID, "bad argument");
-    if (world < 1 || rank < 0 || rank >= world) return fail(MH_ERR_INVALID, "bad rank / world");
-    if (world > 1 && (!exchange || shard_longest <= 0 || e->m > shard_longest))
-        return fail(MH_ERR_INVALID, "a sharded selection needs the exchange callback and the longest shard's size");
-    const int n = e->n, M = e->m;                     // M may be 0 on a rank without hypotheses (world > shard count)
-    if (world == 1 && M <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
-    const int longest = world > 1 ? shard_longest : 0;
+    if (e->residual_mode == MH_RESIDUAL_SYMMETRIC)
+        return fail(MH_ERR_INVALID, "the greedy selection scores and claims with the forward transfer error (the reference's); "
+                                    "switch back to MH_RESIDUAL_FORWARD for it");
+    const int n = e->n, M = e->m;                     // M may be 0 on a rank without hypotheses (more ranks than hypotheses)
+    // The transport is used whenever one is set — also with world == 1, where a one-rank communicator runs the whole
+    // protocol (how the RCCL path is tested on a box with one GPU).
+    const bool sharded = e->t_stream_fn || e->t_host_fn;
+    const int world = sharded ? e->t_world : 1, rank = sharded ? e->t_rank : 0;
+    if (!sharded && M <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
+    if (total_m <= 0) total_m = M;
+    if (total_m > 0xfffffffell) return fail(MH_ERR_INVALID, "more than 2^32 - 2 hypotheses in a batch");
+    // contiguous shards of the whole batch, the first `rem` one hypothesis longer
+    const int base = (int)(total_m / world), rem = (int)(total_m % world);
+    const int longest = base + (rem ? 1 : 0);
+    const int mine = base + (rank < rem ? 1 : 0);
+    const unsigned int my_off = (unsigned int)((long long)rank * base + std::min(rank, rem));
+    if (M != mine) return fail(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
     const size_t cap = (size_t)std::max(M, 1);
     for (int b = 0; b < 2; ++b) { HIPCHK(e->sel_orig[b].reserve(cap)); HIPCHK(e->sel_cand_H[b].reserve(cap * 9)); }
     HIPCHK(e->sel_counts.reserve(cap));
@@ -1385,12 +1469,11 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     HIPCHK(e->sel_keys.reserve(2));
     HIPCHK(e->sel_out_H.reserve((size_t)max_models * 9));
     HIPCHK(e->sel_counter.reserve(max_models));
-    HIPCHK(e->sel_my_H.reserve(16));
+    HIPCHK(e->sel_records.reserve((size_t)world + 1));
     HIPCHK(e->mask.reserve((size_t)n + 2));
-    if (world > 1) {
-        HIPCHK(e->sel_scores.reserve(longest));
-        HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
-        HIPCHK(e->sel_all_H.reserve((size_t)world * 9));
+    if (sharded) {
+        HIPCHK(e->sel_scores.reserve((size_t)std::max(longest, 1)));
+        HIPCHK(e->sel_gathered.reserve((size_t)world * std::max(longest, 1)));
     }
     if (!e->h_sel) {
         HIPCHK(hipHostMalloc((void**)&e->h_sel, sizeof(int) * 8, hipHostMallocMapped));
@@ -1401,10 +1484,12 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     else HIPCHK(hipMemsetAsync(e->mask.p, 1, n, s));
     HIPCHK(hipMemsetAsync(e->sel_rec.p, 0, sizeof(int) * 8, s));
     HIPCHK(hipMemsetAsync(e->sel_keys.p, 0, sizeof(unsigned long long) * 2, s));
-    HIPCHK(hipMemsetAsync(e->sel_my_H.p, 0, sizeof(double) * 16, s));
-    if (world > 1) HIPCHK(hipMemsetAsync(e->sel_scores.p, 0xff, sizeof(int) * longest, s));       // -1: padding / pruned
+    HIPCHK(hipMemsetAsync(e->sel_records.p, 0, sizeof(SelRecord) * ((size_t)world + 1), s));
+    if (sharded && longest > 0) HIPCHK(hipMemsetAsync(e->sel_scores.p, 0xff, sizeof(int) * (size_t)longest, s));   // -1: padding
     unsigned long long* key_local = e->sel_keys.p;
-    unsigned long long* key_global = world > 1 ? e->sel_keys.p + 1 : e->sel_keys.p;
+    unsigned long long* key_check = e->sel_keys.p + 1;     // the first round's winner as the gathered score vector gives it
+    SelRecord* my_record = e->sel_records.p;
+    SelRecord* records = sharded ? e->sel_records.p + 1 : e->sel_records.p;
 
     // The support set only shrinks (the inliers of every selected model leave it), and the score kernel pays per point
     // it sweeps: every round scores the PACKED active points.  Their number is known on the host without a copy — the
@@ -1414,7 +1499,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     for (int c = 0; c < 4; ++c) HIPCHK(e->sel_pts[c].reserve((size_t)n + 2));
     HIPCHK(e->sel_pack_count.reserve(1));
 
-    int Mc = M, cur = 0, selected = 0, packed_as = -1;
+    int Mc = M, cur = 0, selected = 0, packed_as = -1, local_err = 0;
     bool first = true;
     for (int round = 0; round < max_models; ++round) {
         const double* Hs = first ? e->H.p : e->sel_cand_H[cur].p;
@@ -1435,28 +1520,27 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
                 HIPCHK(hipMemsetAsync(e->sel_counts.p, 0, sizeof(int) * (size_t)Mc, s));
             }
         }
-        HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, key_local, world > 1 ? e->sel_scores.p : nullptr, s));
-        if (world > 1) {
-            // north_star's exchange: the per-model int32 scores of every rank, device buffers on both sides
-            HIPCHK(hipStreamSynchronize(s));
-            if (exchange(ctx, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest) != 0)
-                return fail(MH_ERR_INVALID, "score all-gather failed");
-            HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world * longest, key_global, s));
+        const bool gather_scores = sharded && first && longest > 0;      // north_star's exchange, once per batch
+        HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, my_off, key_local, gather_scores ? e->sel_scores.p : nullptr, s));
+        HIPCHK(launch_sel_record(e->sel_counts.p, orig, Hs, Mc, my_off, key_local, local_err, my_record, s));
+        if (sharded) {
+            if (gather_scores) {
+                rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest);
+                if (rc) return rc;
+                HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, key_check, s));
+            }
+            rc = exchange(e, my_record, records, sizeof(SelRecord));     // 88 bytes per rank
+            if (rc) return rc;
         }
-        HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, key_local, key_global,
-                                  world > 1 ? (unsigned int)rank * (unsigned int)longest : 0u, e->sel_orig[cur ^ 1].p,
-                                  e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, e->sel_my_H.p, world > 1 ? e->sel_scores.p : nullptr, s));
-        const double* offers = e->sel_my_H.p;
-        if (world > 1) {
-            HIPCHK(hipStreamSynchronize(s));
-            if (exchange(ctx, e->sel_my_H.p, e->sel_all_H.p, sizeof(double) * 9) != 0)
-                return fail(MH_ERR_INVALID, "model all-gather failed");
-            offers = e->sel_all_H.p;
-        }
-        HIPCHK(launch_sel_claim(e->pts(), offers, longest, key_global, thr2, need, e->mask.p, e->sel_rec.p, e->sel_out_H.p,
-                                e->sel_counter.p, max_models, s));
-        HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, need, e->h_sel_dev, s));
-        HIPCHK(hipStreamSynchronize(s));                 // three control words through mapped memory: no copy
+        HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, records, world, my_off, e->sel_orig[cur ^ 1].p,
+                                  e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, s));
+        HIPCHK(launch_sel_claim(e->pts(), records, world, gather_scores ? key_check : nullptr, thr2, need, e->mask.p, e->sel_rec.p,
+                                e->sel_out_H.p, e->sel_counter.p, max_models, s));
+        HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, my_record, need, e->h_sel_dev, s));
+        HIPCHK(hipStreamSynchronize(s));                 // five control words through mapped memory: no copy
+        if (e->h_sel[4] != 0)                            // every rank sees the same word, so every rank leaves here
+            return fail(MH_ERR_HIP, e->h_sel[4] == 2 ? "greedy selection: the gathered score vector and the ranks' records disagree about the winner"
+                                                      : "greedy selection: a rank reported an error");
         const int best = e->h_sel[0];
         if (best < need) break;
         if (counts_out) counts_out[selected] = best;
@@ -1481,6 +1565,106 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     HIPCHK(hipStreamSynchronize(s));
     if (packed_n != packed_as)                           // the host's bookkeeping of the support set against the device's own count
         return fail(MH_ERR_HIP, "greedy selection: the packed support set does not have the expected size");
+    return MH_OK;
+    });
+}
+
+// ---- pipelined propose -------------------------------------------------------------------------
+static int ensure_side_stream(mh_engine* e)
+{
+    if (!e->side_stream) HIPCHK(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    if (!e->ev_side) HIPCHK(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+    if (!e->ev_main) HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+    return MH_OK;
+}
+
+int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int m)
+{
+    return guarded([&]() -> int {
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (m <= 0) return fail(MH_ERR_INVALID, "m must be positive");
+    if (e->n < 4) return fail(MH_ERR_INVALID, "need at least 4 correspondences");
+    rc = ensure_side_stream(e);
+    if (rc) return rc;
+    if (e->H_next.cap < (size_t)m * 9 || e->samples_next.cap < (size_t)m * 4) {
+        // (re)allocation: nothing may still be reading the spare buffers
+        HIPCHK(hipStreamSynchronize(e->side_stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(e->H_next.reserve((size_t)m * 9));
+        HIPCHK(e->samples_next.reserve((size_t)m * 4));
+    }
+    // The spare buffers held the batch that was current before the last adoption; kernels of the main stream enqueued
+    // up to now may still read them.
+    HIPCHK(hipEventRecord(e->ev_main, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_main, 0));
+    {
+        ScopedTimer t(e, MH_K_DLT4, e->side_stream);           // (the kernel's span on the second stream, beside whatever the main one runs)
+        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples_next.p, e->H_next.p, e->side_stream));
+    }
+    HIPCHK(hipEventRecord(e->ev_side, e->side_stream));
+    e->m_next = m;
+    e->next_valid = true;
+    return MH_OK;
+    });
+}
+
+int mh_adopt_prefetched(mh_engine* e)
+{
+    return guarded([&]() -> int {
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (!e->next_valid) return fail(MH_ERR_NOT_SET, "no prefetched batch (mh_prefetch_dlt4)");
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_side, 0));        // main-stream work behind this point sees the new batch
+    std::swap(e->H, e->H_next);
+    std::swap(e->samples, e->samples_next);
+    HIPCHK(e->counts.reserve(e->m_next));
+    e->m = e->m_next;
+    e->have_samples = true;
+    e->next_valid = false;
+    e->cost_L = 0;
+    return MH_OK;
+    });
+}
+
+// ---- best model of the scored batch --------------------------------------------------------------
+int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* best_count)
+{
+    return guarded([&]() -> int {
+    int rc = require_models(e);
+    if (rc) return rc;
+    const bool sharded = (e->t_stream_fn || e->t_host_fn) && e->t_world > 1;
+    const int world = sharded ? e->t_world : 1, rank = sharded ? e->t_rank : 0;
+    if (total_m <= 0) total_m = e->m;
+    const int base = (int)(total_m / world), rem = (int)(total_m % world);
+    const int longest = base + (rem ? 1 : 0);
+    if (e->m != base + (rank < rem ? 1 : 0)) return fail(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
+    HIPCHK(e->best_key.reserve(1));
+    if (!e->h_best) {
+        HIPCHK(hipHostMalloc((void**)&e->h_best, sizeof(int) * 4, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_best_dev, e->h_best, 0));
+        e->h_best[0] = e->h_best[1] = e->h_best[2] = 0;
+        HIPCHK(hipMemsetAsync(e->best_key.p, 0, sizeof(unsigned long long), e->stream));
+    }
+    hipStream_t s = e->stream;
+    if (sharded) {
+        HIPCHK(e->sel_scores.reserve((size_t)longest));
+        HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
+        HIPCHK(launch_pad_scores(e->counts.p, e->m, longest, e->sel_scores.p, s));
+        rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest);     // north_star's all-gather
+        if (rc) return rc;
+        HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, e->best_key.p, s));
+    } else {
+        HIPCHK(launch_sel_argmax(e->counts.p, nullptr, e->m, 0u, e->best_key.p, nullptr, s));
+    }
+    HIPCHK(launch_best_publish(e->best_key.p, e->h_best_dev, s));
+    ++e->best_seq;
+    if (best_index || best_count) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (e->h_best[2] != e->best_seq) return fail(MH_ERR_HIP, "best-model result is stale");
+        if (best_index) *best_index = e->h_best[1];
+        if (best_count) *best_count = e->h_best[0];
+    }
     return MH_OK;
     });
 }
@@ -1704,6 +1888,7 @@ int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned long long
     case MH_BUF_RESIDUALS: *ptr_dev = (e->ldr > 0 && e->m > 0) ? e->R.p : nullptr; *bytes = sizeof(double) * (size_t)e->m * (size_t)e->ldr; break;
     case MH_BUF_LABELS: *ptr_dev = e->ew_label.p; *bytes = sizeof(int) * (size_t)e->n; break;
     case MH_BUF_COST: *ptr_dev = e->cost.p; *bytes = sizeof(int) * (size_t)e->n * e->cost_L; break;
+    case MH_BUF_GATHERED_SCORES: *ptr_dev = e->sel_gathered.p; *bytes = sizeof(int) * e->sel_gathered.cap; break;
     default: return fail(MH_ERR_INVALID, "unknown buffer id");
     }
     if (!*ptr_dev) return fail(MH_ERR_NOT_SET, "buffer has not been produced yet");

@@ -59,6 +59,10 @@ hipError_t launch_fund_refit(const Points& p, const double* F_in, double thr2, d
                              unsigned char* mask_out, int* count_out, hipStream_t s);
 
 // --- datacost.hip -----------------------------------------------------------
+// the data cost of every model against every point, int32, model-major with pitch ldc (datacost.hip)
+inline long long cost_ld(int n) { return ((long long)n + 31) & ~31ll; }
+hipError_t launch_cost_matrix(const Points& p, const double* H, int M, double lambda, double thr2, int* C, long long ldc,
+                              int* counts, hipStream_t s);
 hipError_t launch_data_cost(const Points& p, const double* H, int Nh, double lambda, double thr2,
                             int* cost, hipStream_t s);
 
@@ -174,15 +178,23 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 // packs the points with mask != 0 into cx1.. (any order); *count = their number
 hipError_t launch_sel_pack_points(const Points& p, const unsigned char* mask, double* cx1, double* cy1, double* cx2, double* cy2,
                                   int* count, hipStream_t s);
-hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned long long* key, int* scores_full, hipStream_t s);
-hipError_t launch_sel_argmax_gathered(const int* gathered, int total, unsigned long long* key, hipStream_t s);
-hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need,
-                              const unsigned long long* key_local, const unsigned long long* key_global, unsigned int my_pos0,
-                              int* next_orig, double* next_H, int* rec, double* my_best_H, int* scores_full, hipStream_t s);
-hipError_t launch_sel_claim(const Points& p, const double* all_H, int longest, const unsigned long long* key_global, double thr2,
+// one rank's offer in a round of the greedy selection: 88 bytes, the unit of the sharded exchange
+struct SelRecord { unsigned long long key; double H[9]; int err; int pad; };
+static_assert(sizeof(SelRecord) == 88, "the exchanged record is 88 bytes");
+hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned int my_off, unsigned long long* key,
+                             int* scores_full, hipStream_t s);
+hipError_t launch_sel_argmax_gathered(const int* gathered, int world, int longest, int base, int rem, unsigned long long* key,
+                                      hipStream_t s);
+hipError_t launch_sel_record(const int* counts, const int* orig, const double* Hs, int Mc, unsigned int my_off,
+                             const unsigned long long* key_local, int err, SelRecord* record, hipStream_t s);
+hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need, const SelRecord* records,
+                              int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, hipStream_t s);
+hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
                             hipStream_t s);
-hipError_t launch_sel_publish(int* rec, unsigned long long* keys, int need, int* h_rec_dev, hipStream_t s);
+hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_record, int need, int* h_rec_dev, hipStream_t s);
+hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s);
+hipError_t launch_pad_scores(const int* counts, int m, int longest, int* scores, hipStream_t s);
 
 // --- knn.hip ----------------------------------------------------------------
 constexpr int KNN_MAX_SPLITS = 16;      // slices of the candidate range (knn.hip)

@@ -40,7 +40,7 @@ namespace mh {
 // TILED (tuning): R stored tile-major — [model block][point tile][MC][TILE] — so that a workgroup writes one contiguous
 // 128-KiB block per tile instead of MC row segments.
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -233,7 +233,14 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                         const double d1 = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1], py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
                         if (WRITE_R) {
                             double* dstp = row_ptr(wbase + c * 128 + lane * 2);
-                            if (NT) {
+                            if (SF != 0) {          // measurement builds: cache-policy bits of the store spelt out
+                                typedef double d2v __attribute__((ext_vector_type(2)));
+                                const d2v val = { d0, d1 };
+                                if (SF == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(val) : "memory");
+                                else if (SF == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dstp), "v"(val) : "memory");
+                                else if (SF == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dstp), "v"(val) : "memory");
+                                else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dstp), "v"(val) : "memory");
+                            } else if (NT) {
                                 __builtin_nontemporal_store(d0, dstp);
                                 __builtin_nontemporal_store(d1, dstp + 1);
                             } else {
@@ -264,7 +271,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0, int swapxy = 0)
@@ -293,7 +300,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     }
     dim3 grid(gx, psplit);
     if (swapxy) grid = dim3(psplit, gx);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy,
                        p.xmin, p.xmax, p.ymin, p.ymax);
     return hipGetLastError();
@@ -306,7 +313,8 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s)
 {
-    if (variant == 0) return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // PPL 4, MC 16, plain 16-B stores
+    // PPL 4, MC 16, plain 16-B stores, the lean sweep wherever a tile and a model allow it (r03)
+    if (variant == 0) return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
@@ -328,13 +336,18 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 8: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 8
     case 9: return launch_rs<6, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 6
     case 10: return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // fused multiply-adds: NOT bit-exact
-    case 20: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean sweep on clean tiles
+    case 20: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean sweep on clean tiles (= the product since r03)
+    case 32: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                                                 // the r02 product kernel: checked sweep everywhere
     case 21: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // lean + tile-major R
     case 22: return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);          // lean + nt stores
     case 23: return launch_rs<4, 16, true, false, false, true, false, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // tile-major R alone
     case 24: return launch_rs<4, 16, true, false, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration, tile-major R
     case 25: return launch_rs<6, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 6
     case 26: return launch_rs<8, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 8
+    case 28: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 2>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc1 stores
+    case 29: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 3>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 stores
+    case 30: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 4>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc1 nt stores
+    case 31: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 5>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 nt stores
     case 27: return launch_rs<2, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 2
     default: break;
     }
@@ -349,10 +362,11 @@ hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
         if (mask) return launch_rs<4, 16, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
         return launch_rs<4, 16, false, false, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
     }
-    if (mask) return launch_rs<4, 16, false, true, false>(p, H, M, thr2, nullptr, 0, counts, mask, s);
-    if (variant == 0) return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    if (mask) return launch_rs<4, 16, false, true, false, true, false, false, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
+    if (variant == 0) return launch_rs<4, 16, false, false, false, true, false, false, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == 1) return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);           // PPL 2
+    if (variant == 32) return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);          // the r02 score kernel
     if (variant == 3) return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);    // compiler IEEE division
 #endif
     return hipErrorInvalidValue;

@@ -4,16 +4,22 @@
 // take its inliers out of the support set, score again) as the engine runs it behind MultiH::ProposeModels:
 // per round
 //   launch_score     inlier counts of the candidate hypotheses over the points still in the support mask
-//   k_sel_argmax     best candidate: highest count, lowest hypothesis counter on ties (one 64-bit atomicMax per
-//                    workgroup on key = count << 32 | ~counter)
-//   k_sel_compact    the winner's H goes to the output list; the candidates that can still win — count >= need,
-//                    counts only fall as points leave the mask — are copied to the next round's list
-//   k_sel_claim      the winner's inliers leave the mask
-//   k_sel_publish    three control words for the host (mapped pinned memory): the round's best count decides whether
+//   k_sel_argmax     this rank's best candidate: highest count, lowest GLOBAL hypothesis counter on ties (one 64-bit
+//                    atomicMax per workgroup on key = count << 32 | ~counter)
+//   k_sel_record     the rank's OFFER: an 88-byte record {key, H[9], error word}
+//   (exchange)       sharded batches only: the ranks all-gather their records — 88 bytes per rank — on the engine's
+//                    stream (RCCL); in the FIRST round also their whole int32 score vectors (north_star's exchange:
+//                    every rank then holds every hypothesis' score; the winner it implies is cross-checked against
+//                    the records')
+//   k_sel_compact    the candidates that can still win — count >= need, counts only fall as points leave the mask —
+//                    are copied to the next round's list (the round's winner is not one of them)
+//   k_sel_claim      the winner (largest key over the records, identical on every rank) joins the output list and its
+//                    inliers leave the mask
+//   k_sel_publish    five control words for the host (mapped pinned memory): the round's best count decides whether
 //                    there is another round; nothing else crosses the bus
-// After the first round the candidate list is a small fraction of the batch, so later rounds are short.
-// Sharded batches (one process per GPU): between argmax and compact the ranks all-gather their int32 score vectors
-// (device pointers; RCCL on a real node) and the 72-byte H of their local best, and every rank picks the same winner.
+// After the first round the candidate list is a small fraction of the batch, so later rounds are short.  Keys carry the
+// hypothesis' position in the WHOLE batch (shard offset + local index), so the order of selection — and with it every
+// output, the counters included — is the single-GPU one for any number of ranks.
 #include "mh_device.hpp"
 #include "mh_kernels.hpp"
 
@@ -24,74 +30,95 @@ __device__ __forceinline__ unsigned long long sel_key(int count, unsigned int co
     return ((unsigned long long)(unsigned int)count << 32) | (unsigned long long)(0xffffffffu - counter);
 }
 
-// counts[c] of candidate c whose hypothesis counter (position in its rank's batch) is orig[c] (identity when null).
-// counter_base: added to the counter (sharded: the rank's offset is NOT added here; see k_sel_argmax_gathered).
+__device__ __forceinline__ unsigned long long wg_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(k, m, 64); k = o > k ? o : k; }
+    __shared__ unsigned long long s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = k;
+    __syncthreads();
+    unsigned long long b = s[0];
+    for (int w = 1; w < 4; ++w) b = s[w] > b ? s[w] : b;
+    return b;
+}
+
+// counts[c] of candidate c whose position in this rank's batch is orig[c] (identity when null); my_off = position of this
+// rank's hypothesis 0 in the whole batch.  scores_full (nullable): scores_full[orig] = count (the vector that is
+// all-gathered in the first round; entries never written stay -1).
 __global__ void __launch_bounds__(256)
-k_sel_argmax(const int* __restrict__ counts, const int* __restrict__ orig, int Mc, unsigned long long* __restrict__ key,
-             int* __restrict__ scores_full /* nullable: scores_full[orig] = count */)
+k_sel_argmax(const int* __restrict__ counts, const int* __restrict__ orig, int Mc, unsigned int my_off,
+             unsigned long long* __restrict__ key, int* __restrict__ scores_full)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     unsigned long long k = 0;
     if (c < Mc) {
         const int o = orig ? orig[c] : c;
         const int cnt = counts[c];
-        if (cnt >= 0) k = sel_key(cnt, (unsigned int)o);
+        if (cnt >= 0) k = sel_key(cnt, my_off + (unsigned int)o);
         if (scores_full) scores_full[o] = cnt;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(k, m, 64); k = o > k ? o : k; }
-    __shared__ unsigned long long s[4];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = k;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long b = s[0];
-        for (int w = 1; w < 4; ++w) b = s[w] > b ? s[w] : b;
-        if (b) atomicMax(key, b);
-    }
+    const unsigned long long b = wg_max_u64(k);
+    if (threadIdx.x == 0 && b) atomicMax(key, b);
 }
 
-// gathered: world x longest scores in rank order (-1 = padding or pruned); counter of entry (r, j) = r * longest + j,
-// which orders entries like the single-rank batch orders its hypotheses (the ranks own contiguous ascending ranges).
+// gathered: world x longest scores in rank order (-1 = padding); entry (r, j) is hypothesis r * base + min(r, rem) + j of
+// the whole batch (contiguous shards, the first `rem` one longer).
 __global__ void __launch_bounds__(256)
-k_sel_argmax_gathered(const int* __restrict__ gathered, int total, unsigned long long* __restrict__ key)
+k_sel_argmax_gathered(const int* __restrict__ gathered, int world, int longest, int base, int rem,
+                      unsigned long long* __restrict__ key)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     unsigned long long k = 0;
-    if (c < total && gathered[c] >= 0) k = sel_key(gathered[c], (unsigned int)c);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(k, m, 64); k = o > k ? o : k; }
-    __shared__ unsigned long long s[4];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = k;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long b = s[0];
-        for (int w = 1; w < 4; ++w) b = s[w] > b ? s[w] : b;
-        if (b) atomicMax(key, b);
+    if (c < world * longest && gathered[c] >= 0) {
+        const int r = c / longest, j = c - r * longest;
+        k = sel_key(gathered[c], (unsigned int)(r * base + (r < rem ? r : rem) + j));
     }
+    const unsigned long long b = wg_max_u64(k);
+    if (threadIdx.x == 0 && b) atomicMax(key, b);
 }
 
-// rec: [0] best count of the round (global), [1] its counter, [2] next candidate count, [3] models selected so far.
-// key_local: this rank's best; key_global: the round's winner (== key_local on one rank).  my_pos0: counter of this
-// rank's hypothesis 0 in the gathered numbering (rank * longest), or 0.
+// This rank's offer: the candidate whose key is the rank's best.  `record` must have been cleared (key 0 = no offer).
 __global__ void __launch_bounds__(256)
-k_sel_compact(const int* __restrict__ counts, const int* __restrict__ orig, const double* __restrict__ Hs, int Mc, int need,
-              const unsigned long long* __restrict__ key_local, const unsigned long long* __restrict__ key_global,
-              unsigned int my_pos0, int* __restrict__ next_orig, double* __restrict__ next_H, int* __restrict__ rec,
-              double* __restrict__ my_best_H, int* __restrict__ scores_full)
+k_sel_record(const int* __restrict__ counts, const int* __restrict__ orig, const double* __restrict__ Hs, int Mc,
+             unsigned int my_off, const unsigned long long* __restrict__ key_local, int err, SelRecord* __restrict__ record)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long kl = *key_local, kg = *key_global;
+    const unsigned long long kl = *key_local;
+    if (c == 0) record->err = err;
+    if (c >= Mc || !kl) return;
+    const int o = orig ? orig[c] : c;
+    if (sel_key(counts[c], my_off + (unsigned int)o) != kl) return;
+    record->key = kl;
+    const double* h = Hs + 9 * (size_t)c;
+    for (int q = 0; q < 9; ++q) record->H[q] = h[q];
+}
+
+// the round's winner: the largest key over the ranks' records (every rank computes the same)
+__device__ __forceinline__ unsigned long long sel_winner(const SelRecord* __restrict__ records, int world, int* rank_out)
+{
+    unsigned long long kg = 0;
+    int wr = 0;
+    for (int r = 0; r < world; ++r) { const unsigned long long k = records[r].key; if (k > kg) { kg = k; wr = r; } }
+    if (rank_out) *rank_out = wr;
+    return kg;
+}
+
+// rec: [0] best count of the round, [1] its global counter, [2] next candidate count, [3] models selected so far,
+// [4] sticky error (a rank reported one, or the two ways of finding the first round's winner disagree).
+__global__ void __launch_bounds__(256)
+k_sel_compact(const int* __restrict__ counts, const int* __restrict__ orig, const double* __restrict__ Hs, int Mc, int need,
+              const SelRecord* __restrict__ records, int world, unsigned int my_off, int* __restrict__ next_orig,
+              double* __restrict__ next_H, int* __restrict__ rec)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long kg = sel_winner(records, world, nullptr);
     bool keep = false;
     int o = 0;
     if (c < Mc) {
         o = orig ? orig[c] : c;
         const int cnt = counts[c];
-        const double* h = Hs + 9 * (size_t)c;
-        if (kl && sel_key(cnt, (unsigned int)o) == kl)
-            for (int q = 0; q < 9; ++q) my_best_H[q] = h[q];                    // what this rank offers
-        const bool is_winner = kg && cnt >= 0 && sel_key(cnt, my_pos0 + (unsigned int)o) == kg;
+        const bool is_winner = kg && cnt >= 0 && sel_key(cnt, my_off + (unsigned int)o) == kg;
         keep = cnt >= need && !is_winner;
-        if (!keep && scores_full) scores_full[o] = -1;                           // can never win again
     }
     __shared__ int s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -109,23 +136,31 @@ k_sel_compact(const int* __restrict__ counts, const int* __restrict__ orig, cons
     }
 }
 
-// The winner's inliers leave the support mask; its H joins the output list (one thread).  all_H: world x 9 (the ranks'
-// offers, rank order) or this rank's own offer when world == 1.
+// The winner's inliers leave the support mask; its H joins the output list (one thread).  key_check (nullable): the
+// winner as the all-gathered score vector of the first round gives it — must equal the records' winner.
 __global__ void __launch_bounds__(256)
 k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
-            const double* __restrict__ y2, int N, const double* __restrict__ all_H, int longest,
-            const unsigned long long* __restrict__ key_global, double thr2, int need, unsigned char* __restrict__ mask,
+            const double* __restrict__ y2, int N, const SelRecord* __restrict__ records, int world,
+            const unsigned long long* __restrict__ key_check, double thr2, int need, unsigned char* __restrict__ mask,
             int* __restrict__ rec, double* __restrict__ sel_H, long long* __restrict__ sel_counter, int max_models)
 {
-    const unsigned long long kg = *key_global;
+    int wr = 0;
+    const unsigned long long kg = sel_winner(records, world, &wr);
     const int best = (int)(kg >> 32);
     const unsigned int pos = 0xffffffffu - (unsigned int)(kg & 0xffffffffull);
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n == 0) { rec[0] = kg ? best : -1; rec[1] = (int)pos; }
+    if (n == 0) {
+        rec[0] = kg ? best : -1;
+        rec[1] = (int)pos;
+        int err = 0;
+        for (int r = 0; r < world; ++r) if (records[r].err) err = records[r].err;
+        if (key_check && *key_check != kg) err = 2;
+        if (err) rec[4] = err;
+    }
     if (!kg || best < need) return;
     const int sel = rec[3];
     if (sel >= max_models) return;
-    const double* h = all_H + 9 * (size_t)(longest > 0 ? pos / (unsigned int)longest : 0u);
+    const double* h = records[wr].H;
     if (n == 0) {
         for (int q = 0; q < 9; ++q) sel_H[9 * (size_t)sel + q] = h[q];
         sel_counter[sel] = (long long)pos;
@@ -135,14 +170,36 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
     if (d2 < thr2) mask[n] = 0;
 }
 
-__global__ void k_sel_publish(int* __restrict__ rec, unsigned long long* __restrict__ keys, int need, int* __restrict__ h_rec)
+__global__ void k_sel_publish(int* __restrict__ rec, unsigned long long* __restrict__ keys, SelRecord* __restrict__ my_record,
+                              int need, int* __restrict__ h_rec)
 {
     if (threadIdx.x != 0) return;
-    h_rec[0] = rec[0]; h_rec[1] = rec[1]; h_rec[2] = rec[2];
+    h_rec[0] = rec[0]; h_rec[1] = rec[1]; h_rec[2] = rec[2]; h_rec[4] = rec[4];
     if (rec[0] >= need) rec[3] += 1;
     h_rec[3] = rec[3];
     rec[2] = 0;
     keys[0] = 0; keys[1] = 0;
+    my_record->key = 0;
+}
+
+// Best model of a scored batch (the step bench.py times): arg-max of the resident counts — or of the all-gathered
+// vector — then one word pair for the host.
+__global__ void k_best_publish(unsigned long long* __restrict__ key, int* __restrict__ h_best)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long k = *key;
+    h_best[0] = k ? (int)(k >> 32) : -1;
+    h_best[1] = (int)(0xffffffffu - (unsigned int)(k & 0xffffffffull));
+    h_best[2] += 1;                                   // sequence number: the host can tell a fresh result from an old one
+    *key = 0;
+}
+
+// scores[0, m) <- counts, scores[m, longest) <- -1: the send buffer of the score all-gather
+__global__ void __launch_bounds__(256)
+k_pad_scores(const int* __restrict__ counts, int m, int longest, int* __restrict__ scores)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < longest) scores[c] = c < m ? counts[c] : -1;
 }
 
 // The points that are still in the support set, packed: the re-scoring of a round then sweeps only them (the score
@@ -175,42 +232,65 @@ hipError_t launch_sel_pack_points(const Points& p, const unsigned char* mask, do
     return hipGetLastError();
 }
 
-hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned long long* key, int* scores_full, hipStream_t s)
+hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned int my_off, unsigned long long* key,
+                             int* scores_full, hipStream_t s)
 {
     if (Mc <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sel_argmax, dim3((Mc + 255) / 256), dim3(256), 0, s, counts, orig, Mc, key, scores_full);
+    hipLaunchKernelGGL(k_sel_argmax, dim3((Mc + 255) / 256), dim3(256), 0, s, counts, orig, Mc, my_off, key, scores_full);
     return hipGetLastError();
 }
 
-hipError_t launch_sel_argmax_gathered(const int* gathered, int total, unsigned long long* key, hipStream_t s)
+hipError_t launch_sel_argmax_gathered(const int* gathered, int world, int longest, int base, int rem, unsigned long long* key,
+                                      hipStream_t s)
 {
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sel_argmax_gathered, dim3((total + 255) / 256), dim3(256), 0, s, gathered, total, key);
+    if (world * longest <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sel_argmax_gathered, dim3((world * longest + 255) / 256), dim3(256), 0, s, gathered, world, longest,
+                       base, rem, key);
     return hipGetLastError();
 }
 
-hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need,
-                              const unsigned long long* key_local, const unsigned long long* key_global, unsigned int my_pos0,
-                              int* next_orig, double* next_H, int* rec, double* my_best_H, int* scores_full, hipStream_t s)
+hipError_t launch_sel_record(const int* counts, const int* orig, const double* Hs, int Mc, unsigned int my_off,
+                             const unsigned long long* key_local, int err, SelRecord* record, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sel_record, dim3(Mc > 0 ? (Mc + 255) / 256 : 1), dim3(256), 0, s, counts, orig, Hs, Mc, my_off, key_local,
+                       err, record);
+    return hipGetLastError();
+}
+
+hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need, const SelRecord* records,
+                              int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, hipStream_t s)
 {
     if (Mc <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sel_compact, dim3((Mc + 255) / 256), dim3(256), 0, s, counts, orig, Hs, Mc, need, key_local,
-                       key_global, my_pos0, next_orig, next_H, rec, my_best_H, scores_full);
+    hipLaunchKernelGGL(k_sel_compact, dim3((Mc + 255) / 256), dim3(256), 0, s, counts, orig, Hs, Mc, need, records, world, my_off,
+                       next_orig, next_H, rec);
     return hipGetLastError();
 }
 
-hipError_t launch_sel_claim(const Points& p, const double* all_H, int longest, const unsigned long long* key_global, double thr2,
+hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
                             hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sel_claim, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, all_H, longest,
-                       key_global, thr2, need, mask, rec, sel_H, sel_counter, max_models);
+    hipLaunchKernelGGL(k_sel_claim, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, records, world,
+                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models);
     return hipGetLastError();
 }
 
-hipError_t launch_sel_publish(int* rec, unsigned long long* keys, int need, int* h_rec_dev, hipStream_t s)
+hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_record, int need, int* h_rec_dev, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sel_publish, dim3(1), dim3(64), 0, s, rec, keys, need, h_rec_dev);
+    hipLaunchKernelGGL(k_sel_publish, dim3(1), dim3(64), 0, s, rec, keys, my_record, need, h_rec_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_best_publish, dim3(1), dim3(64), 0, s, key, h_best_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad_scores(const int* counts, int m, int longest, int* scores, hipStream_t s)
+{
+    if (longest <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pad_scores, dim3((longest + 255) / 256), dim3(256), 0, s, counts, m, longest, scores);
     return hipGetLastError();
 }
 

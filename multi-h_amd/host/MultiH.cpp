@@ -100,6 +100,9 @@ bool MultiH::EnsureEngine()
         for (const auto& kv : engine_tuning)
             if (!Check(mh_set_tuning(engine, kv.first, kv.second), "mh_set_tuning")) return false;
     }
+    if (!Check(mh_set_transport(engine, shard_rank, std::max(shard_world, 1), shard_stream_allgather, shard_allgather, shard_ctx),
+               "mh_set_transport"))
+        return false;
     return Check(mh_set_params(engine, threshold_fundamental_matrix, threshold_homography,
                                locality_lambda, energy_lambda, minimum_inlier_number),
                  "mh_set_params");
@@ -380,7 +383,6 @@ bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models
     const int need = std::max(minimum_inlier_number, 8);
     if (M <= 0 || max_models <= 0) return true;
     const int W = std::max(shard_world, 1), base = M / W, rem = M % W;
-    const int longest = base + (rem ? 1 : 0);
     const int mine = base + (shard_rank < rem ? 1 : 0);
     const long long off = (long long)shard_rank * base + std::min(shard_rank, rem);
     if (mine > 0) {
@@ -391,7 +393,7 @@ bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models
     std::vector<double> H(9 * (size_t)max_models);
     int selected = 0;
     if (!Check(mh_select_greedy(engine, sqr_threshold_homography, need, max_models, mask.data(), H.data(), nullptr, nullptr,
-                                &selected, shard_rank, W, longest, W > 1 ? shard_allgather : nullptr, shard_ctx),
+                                &selected, (long long)M),
                "mh_select_greedy"))
         return false;
     for (int i = 0; i < selected; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
@@ -400,11 +402,22 @@ bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models
 
 void MultiH::SetSharding(int rank, int world, AllGatherFn fn, void* ctx)
 {
+    shard_stream_allgather = nullptr;
     if (world <= 1 || !fn || rank < 0 || rank >= world) {
         shard_rank = 0; shard_world = 1; shard_allgather = nullptr; shard_ctx = nullptr;
         return;
     }
     shard_rank = rank; shard_world = world; shard_allgather = fn; shard_ctx = ctx;
+}
+
+void MultiH::SetShardingStream(int rank, int world, StreamAllGatherFn fn, void* ctx)
+{
+    shard_allgather = nullptr;
+    if (world < 1 || !fn || rank < 0 || rank >= world) {
+        shard_rank = 0; shard_world = 1; shard_stream_allgather = nullptr; shard_ctx = nullptr;
+        return;
+    }
+    shard_rank = rank; shard_world = world; shard_stream_allgather = fn; shard_ctx = ctx;      // world == 1: a one-rank communicator
 }
 
 void MultiH::ClusterMergingAndLabeling()
@@ -616,11 +629,20 @@ void MultiH::HandleDegenerateCase()
 // Sharding for the next mhh_run_process call of this process (one process per GPU).
 static int g_shard_rank = 0, g_shard_world = 1;
 static MultiH::AllGatherFn g_shard_fn = nullptr;
+static MultiH::StreamAllGatherFn g_shard_stream_fn = nullptr;
 static void* g_shard_ctx = nullptr;
 extern "C" __attribute__((visibility("default")))
 void mhh_set_sharding(int rank, int world, MultiH::AllGatherFn fn, void* ctx)
 {
-    g_shard_rank = rank; g_shard_world = world; g_shard_fn = fn; g_shard_ctx = ctx;
+    g_shard_rank = rank; g_shard_world = world; g_shard_fn = fn; g_shard_stream_fn = nullptr; g_shard_ctx = ctx;
+}
+
+// Stream-ordered transport (RCCL: host/rccl_transport.cpp) for the next mhh_run_process calls; fn = NULL returns to
+// whatever mhh_set_sharding set.  world == 1 is allowed: the whole sharded protocol on a one-rank communicator.
+extern "C" __attribute__((visibility("default")))
+void mhh_set_sharding_stream(int rank, int world, MultiH::StreamAllGatherFn fn, void* ctx)
+{
+    g_shard_rank = rank; g_shard_world = world; g_shard_stream_fn = fn; g_shard_fn = nullptr; g_shard_ctx = ctx;
 }
 
 static int g_device = 0;
@@ -661,7 +683,8 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetProposal(seed, hypotheses, max_models);
     mh.SetFixedIterations(fixed_iterations);
     mh.SetIterativeProposal(iter_hypotheses, iter_max_new < 0 ? 4 : iter_max_new);
-    mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
+    if (g_shard_stream_fn) mh.SetShardingStream(g_shard_rank, g_shard_world, g_shard_stream_fn, g_shard_ctx);
+    else mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
     mh.SetDevice(g_device);
     mh.SetCompatibilityCheck(g_post_filter != 0);
     for (const auto& kv : g_tuning) mh.SetEngineTuning(kv.first, kv.second);

@@ -104,15 +104,22 @@ public:
     void SetIterativeProposal(int hypotheses, int max_new) { iter_hypotheses = hypotheses; iter_max_new = max_new; }
     // Multi-GPU propose stage (BASELINE configs[3] and [4]): one process per GPU, every rank holds all
     // correspondences and owns a contiguous shard of each hypothesis batch (the hypotheses are a pure function of
-    // (seed, counter), so the union over ranks is the single-GPU batch).  Per greedy round the ranks all-gather their
-    // int32 inlier scores — north_star's exchange — and the 72-byte H each offers, and run the same first-maximum
-    // selection on the device.  Labeling and re-estimation run replicated and deterministic, so the ranks stay
+    // (seed, counter), so the union over ranks is the single-GPU batch).  In the first greedy round the ranks all-gather
+    // their int32 inlier scores — north_star's exchange —, in every round one 88-byte record each (best score and its
+    // position in the batch, that hypothesis' H), and run the same first-maximum selection on the device.  Labeling and re-estimation run replicated and deterministic, so the ranks stay
     // identical without a broadcast.  `fn` is the transport: it receives DEVICE pointers (the engine's resident score
     // buffer on the send side), so RCCL (`ncclAllGather`, or torch.distributed's all_gather_into_tensor as in
     // multi-h_amd/sharding.py) works on them in place: send `bytes_per_rank` bytes, receive world * bytes_per_rank in
     // rank order, return 0 once the result is complete in `recv_dev`.  The engine's stream is idle during the call.
     typedef int (*AllGatherFn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank);
     void SetSharding(int rank, int world, AllGatherFn fn, void* ctx);
+    // The same with a STREAM-ORDERED transport: `fn` enqueues the all-gather on `hip_stream` (the engine's) and returns at
+    // once — RCCL's ncclAllGather; include/multih_rccl.h + host/rccl_transport.cpp provide it (mhr_allgather) together with the communicator
+    // bootstrap.  No host synchronisation and no Python in the exchange.  world == 1 with a transport runs the whole
+    // sharded protocol on a one-rank communicator.
+    typedef int (*StreamAllGatherFn)(void* ctx, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank,
+                                     void* hip_stream);
+    void SetShardingStream(int rank, int world, StreamAllGatherFn fn, void* ctx);
     // Number of 8-point hypotheses of the GPU F estimation used when SetEpipolarGeometry was not called.
     void SetFundamentalHypotheses(int n) { fundamental_hypotheses = n; }
     // The post-filter of Process() (HomographyCompatibilityCheck, M/MultiH.cpp:78-86) can be switched off to look at
@@ -166,6 +173,7 @@ protected:
     std::vector<cv::Mat> initial_homographies;
     int shard_rank = 0, shard_world = 1;
     AllGatherFn shard_allgather = nullptr;
+    StreamAllGatherFn shard_stream_allgather = nullptr;
     void* shard_ctx = nullptr;
 
     bool EnsureEngine();

@@ -8,6 +8,11 @@
 //                  [--thrF 2.6] [--thrH 2.2] [--locality 0.005] [--lambda 0.5] [--min-inliers 20]
 //                  [--hypotheses 10000] [--max-models 32] [--seed 1234] [--iterations 0]
 //                  [--neighbourhood knn|radius]   (knn, the default: the 16 nearest hits within 1/locality pixels; radius: every hit within it)
+//                  [--ranks N]   one process per GPU (rank r on device r), the hypothesis batches sharded over the ranks and
+//                                exchanged by RCCL (host/rccl_transport.cpp: ncclAllGather on the engine's stream); this
+//                                process becomes rank 0 and starts the others before anything touches the GPU.  Every rank
+//                                computes the same result; rank 0 writes <out_result.txt>, rank r > 0 <out_result.txt>.rank<r>.
+//                                N = 1 runs the same protocol on a one-rank communicator.
 // Defaults are the harness defaults of the reference (M/main.cpp:55-59).
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +22,12 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "MultiH.h"
+#include "multih_rccl.h"
 
 static bool LoadPointsFromFile(std::vector<cv::Point2d>& srcPoints, std::vector<cv::Point2d>& dstPoints,
                                std::vector<cv::Mat>& affines, const char* file)
@@ -55,12 +65,13 @@ int main(int argc, char** argv)
     if (argc < 3) {
         std::cerr << "usage: multih_harness <in_corr.txt> <out_result.txt> [--epipolar file] [--thrF v] [--thrH v] "
                      "[--locality v] [--lambda v] [--min-inliers n] [--hypotheses n] [--max-models n] [--seed n] "
-                     "[--iterations n] [--neighbourhood knn|radius]\n";
+                     "[--iterations n] [--neighbourhood knn|radius] [--ranks n]\n";
         return 2;
     }
     double thrF = 2.6, thrH = 2.2, locality = 0.005, lambda = 0.5;     // M/main.cpp:55-59
     int min_inliers = 20, hypotheses = 10000, max_models = 32, iterations = 0;
     unsigned long long seed = 1234;
+    int ranks = 0;
     std::string epi, neighbourhood = "knn";
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
@@ -76,14 +87,64 @@ int main(int argc, char** argv)
         else if (k == "--seed") seed = strtoull(v, nullptr, 10);
         else if (k == "--iterations") iterations = atoi(v);
         else if (k == "--neighbourhood") neighbourhood = v;
+        else if (k == "--ranks") ranks = atoi(v);
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
+    }
+
+    // --ranks N: fork ranks 1..N-1 now — no HIP call has been made yet — then every rank joins the communicator
+    int rank = 0;
+    std::vector<pid_t> kids;
+    if (ranks > 1) {
+        const std::string idfile = "/tmp/multih_rccl_id_" + std::to_string((long long)getpid());
+        setenv("MULTIH_RCCL_ID_FILE", idfile.c_str(), 1);
+        for (int r = 1; r < ranks; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) { perror("fork"); return 1; }
+            if (pid == 0) { rank = r; kids.clear(); break; }
+            kids.push_back(pid);
+        }
+    }
+    auto finish = [&](int rc) {
+        for (pid_t pid : kids) {
+            int st = 0;
+            if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                std::cerr << "[Multi-H] a rank failed\n";
+                if (rc == 0) rc = 1;
+            }
+        }
+        if (rank == 0 && ranks > 1) unlink(getenv("MULTIH_RCCL_ID_FILE"));
+        return rc;
+    };
+    mhr_comm* comm = nullptr;
+    int (*allgather)(void*, const void*, void*, unsigned long long, void*) = nullptr;
+    void (*comm_destroy)(mhr_comm*) = nullptr;
+    if (ranks >= 1) {
+        void* lib = dlopen("libmultih_rccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { std::cerr << "cannot load libmultih_rccl.so: " << dlerror() << "\n"; return finish(1); }
+        auto init_file = (int (*)(mhr_comm**, int, int, const char*, int, int))dlsym(lib, "mhr_init_from_file");
+        auto init_id = (int (*)(mhr_comm**, int, int, const unsigned char*, int))dlsym(lib, "mhr_init");
+        auto make_id = (int (*)(unsigned char*))dlsym(lib, "mhr_unique_id");
+        auto last_error = (const char* (*)())dlsym(lib, "mhr_last_error");
+        allgather = (int (*)(void*, const void*, void*, unsigned long long, void*))dlsym(lib, "mhr_allgather");
+        comm_destroy = (void (*)(mhr_comm*))dlsym(lib, "mhr_destroy");
+        if (!init_file || !init_id || !make_id || !allgather || !comm_destroy || !last_error) { std::cerr << "libmultih_rccl.so lacks a symbol\n"; return finish(1); }
+        int rc;
+        if (ranks == 1) {
+            unsigned char id[MHR_ID_BYTES];
+            rc = make_id(id);
+            if (rc == 0) rc = init_id(&comm, 0, 1, id, 0);
+        } else {
+            rc = init_file(&comm, rank, ranks, getenv("MULTIH_RCCL_ID_FILE"), rank, 120);
+        }
+        if (rc != 0) { std::cerr << "[Multi-H] rank " << rank << ": RCCL communicator: " << last_error() << "\n"; return finish(1); }
+        printf("[Multi-H] rank %d of %d joined the RCCL communicator (device %d)\n", rank, ranks, rank);
     }
 
     std::vector<cv::Point2d> srcPointsOrig, dstPointsOrig;
     std::vector<cv::Mat> origAffines;
     if (!LoadPointsFromFile(srcPointsOrig, dstPointsOrig, origAffines, argv[1])) {
         std::cerr << "cannot read " << argv[1] << "\n";
-        return 1;
+        return finish(1);
     }
     printf("Found %d matches.\n", (int)srcPointsOrig.size());
 
@@ -94,13 +155,18 @@ int main(int argc, char** argv)
         bool ok = true;
         for (double& x : F) ok = ok && static_cast<bool>(f >> x);
         for (double& x : e2) ok = ok && static_cast<bool>(f >> x);
-        if (!ok) { std::cerr << "cannot read epipolar geometry from " << epi << "\n"; return 1; }
+        if (!ok) { std::cerr << "cannot read epipolar geometry from " << epi << "\n"; return finish(1); }
         multiH->SetEpipolarGeometry(F, e2);
     }
     multiH->SetProposal(seed, hypotheses, max_models);
     multiH->SetFixedIterations(iterations);
+    if (comm) {
+        multiH->SetDevice(rank);
+        multiH->SetShardingStream(rank, ranks, allgather, comm);
+    }
     if (neighbourhood == "radius") multiH->SetNeighbourRadius(1.0 / locality);        // the complete list of M/MultiH.cpp:252-253 (see MultiH.h)
-    if (!multiH->Process(srcPointsOrig, dstPointsOrig, origAffines)) { delete multiH; return 1; }
+    if (!multiH->Process(srcPointsOrig, dstPointsOrig, origAffines)) { delete multiH; return finish(1); }
+    const std::string out_path = rank == 0 ? std::string(argv[2]) : std::string(argv[2]) + ".rank" + std::to_string(rank);
 
     std::vector<int> labeling;
     multiH->GetLabels(labeling);
@@ -109,7 +175,7 @@ int main(int argc, char** argv)
         multiH->Release();
         std::cerr << "No homographies were found!\n";
         delete multiH;
-        return 1;
+        return finish(1);
     }
     printf("[Multi-H] %d clusters, %d iterations, energy %.0f\n", multiH->GetClusterNumber(), iterationNum,
            multiH->GetEnergy());
@@ -120,14 +186,15 @@ int main(int argc, char** argv)
     multiH->GetLabels(labels);
     bool saved;
     if (labels.size() == srcPointsOrig.size()) {                        // M/main.cpp:287-297
-        saved = SavePointsToFile(srcPointsOrig, dstPointsOrig, origAffines, labels, argv[2]);
+        saved = SavePointsToFile(srcPointsOrig, dstPointsOrig, origAffines, labels, out_path.c_str());
     } else {
         multiH->GetSourcePoints(src_points);
         multiH->GetDestinationPoints(dst_points);
         multiH->GetAffinities(affinities);
-        saved = SavePointsToFile(src_points, dst_points, affinities, labels, argv[2]);
+        saved = SavePointsToFile(src_points, dst_points, affinities, labels, out_path.c_str());
     }
     multiH->Release();
     delete multiH;
-    return saved ? 0 : 1;
+    if (comm) comm_destroy(comm);
+    return finish(saved ? 0 : 1);
 }

@@ -120,8 +120,9 @@ int mh_labeling_step(mh_engine* e, int, int* labeling, double* energy, int* cycl
 }
 }
 extern "C" int mh_build_neighbors_knn_radius(mh_engine*, int, double) { return MH_OK; }
+extern "C" int mh_set_transport(mh_engine*, int, int, mh_allgather_stream_fn, mh_allgather_dev_fn, void*) { return MH_OK; }
 extern "C" int mh_select_greedy(mh_engine* e, double, int, int max_models, unsigned char* mask, double* H_out, long long* counters,
-                                int* counts, int* selected, int, int, int, mh_allgather_dev_fn, void*)
+                                int* counts, int* selected, long long)
 {
     // model `j` is the j-th pick with 30 inliers (every other point); two picks, or one in mode 1
     int k = e->mode == 1 ? 1 : 2;

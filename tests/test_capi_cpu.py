@@ -28,7 +28,7 @@ def test_header_symbols_match_binding_and_library(mh, engine_lib):
 
 
 def test_abi_version_and_error_string(engine_lib):
-    assert engine_lib.mh_abi_version() == 1
+    assert engine_lib.mh_abi_version() == 2
     assert isinstance(engine_lib.mh_last_error(), (bytes, type(None)))
     assert engine_lib.mh_device_count() >= 0
 
@@ -49,12 +49,29 @@ def test_host_library_exports_class_hooks(mh, engine_lib):
     assert os.path.exists(host), "host layer not built"
     lib = ctypes.CDLL(host)
     for s in ("mhh_run_process", "mhh_mean_shift", "mhh_homography_3pt", "mhh_homography_3pt_refined",
-              "mhh_compatibility_check", "mhh_homography_features", "mhh_set_sharding", "mhh_set_device",
+              "mhh_compatibility_check", "mhh_homography_features", "mhh_set_sharding", "mhh_set_sharding_stream", "mhh_set_device",
               "mhh_set_neighbourhood", "mhh_set_post_filter", "mhh_set_engine_tuning"):
         assert hasattr(lib, s)
     out = subprocess.run(["nm", "-DC", "--defined-only", host], capture_output=True, text=True).stdout
     for method in ("MultiH::Process(", "MultiH::MultiH(", "MultiH::Release()"):
         assert method in out
+
+
+def test_rccl_transport_library_exports_its_header(mh, engine_lib):
+    """libmultih_rccl.so (the native multi-GPU transport) exports exactly what include/multih_rccl.h declares and links
+    RCCL; the engine and the host class do not depend on it (they take the transport as a function pointer)."""
+    text = open(os.path.join(ROOT, "include", "multih_rccl.h")).read()
+    declared = set(re.findall(r"\b(mhr_\w+)\s*\(", text))
+    lib_path = os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so")
+    assert os.path.exists(lib_path), "RCCL transport not built"
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (mhr_\w+)", out))
+    assert exported == declared and "mhr_allgather" in exported
+    needed = subprocess.run(["readelf", "-d", lib_path], capture_output=True, text=True).stdout
+    assert "librccl" in needed
+    for other in ("libmultih_hip.so", "libmultih_host.so"):
+        d = subprocess.run(["readelf", "-d", os.path.join(os.path.dirname(mh.LIB_PATH), other)], capture_output=True, text=True).stdout
+        assert "librccl" not in d and "libmultih_rccl" not in d
 
 
 def test_product_tree_never_touches_the_oracle():

@@ -1,0 +1,138 @@
+"""GPU tests of what r03 added around the bench step: the pipelined propose (second stream), the engine's own best-model
+arg-max, the materialised int32 cost matrix (the s = 4 variant of SURVEY 8(d)), and the native RCCL transport
+(libmultih_rccl.so) on a one-rank communicator — the whole sharded protocol, RCCL's ncclAllGather on the engine's
+stream, without Python in the exchange."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+THR2 = 2.2 * 2.2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(engine, sc):
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.set_epipolar(sc.F, sc.e2)
+
+
+def test_prefetched_batches_equal_proposed_batches(engine, synth, oracle):
+    """mh_prefetch_dlt4 + mh_adopt_prefetched: the batch is prepared on the engine's second stream while the main stream
+    sweeps the previous one; tuples, homographies and the counts of the sweep that follows are those of mh_propose_dlt4,
+    bit for bit, over several rounds of the double buffer and with different batch sizes."""
+    sc = synth.make_scene(3000, 3, seed=8, with_neighbours=False)
+    _load(engine, sc)
+    want = []
+    for i, m in enumerate((700, 700, 333, 1024)):
+        engine.propose_dlt4(21, 1000 * i, m)
+        R, cnt = engine.residual_matrix(THR2)
+        want.append((engine.get_samples(), engine.get_models(), cnt, R))
+    engine.prefetch_dlt4(21, 0, 700)
+    for i, m in enumerate((700, 700, 333, 1024)):
+        engine.adopt_prefetched()
+        if i < 3:
+            engine.prefetch_dlt4(21, 1000 * (i + 1), (700, 333, 1024)[i])      # runs beside the sweep below
+        R, cnt = engine.residual_matrix(THR2)
+        idx, H = engine.get_samples(), engine.get_models()
+        assert np.array_equal(idx, want[i][0]) and np.array_equal(H.view(np.uint64), want[i][1].view(np.uint64)), i
+        assert np.array_equal(cnt, want[i][2]) and np.array_equal(R.view(np.uint64), want[i][3].view(np.uint64)), i
+    assert np.array_equal(want[0][0], oracle.sample4(21, 0, 700, sc.n))
+    with pytest.raises(Exception):
+        engine.adopt_prefetched()                          # nothing prefetched any more
+
+
+def test_select_best_is_the_first_maximum(engine, synth):
+    sc = synth.make_scene(2000, 3, seed=4, with_neighbours=False)
+    _load(engine, sc)
+    engine.propose_dlt4(3, 0, 5000)
+    H = engine.get_models()
+    H[4000:] = H[:1000]                                    # duplicates: ties between a hypothesis and its copy
+    engine.set_models(H)
+    cnt = engine.score(THR2)
+    best, count = engine.select_best()
+    assert count == int(cnt.max()) and best == int(np.argmax(cnt))
+    assert int(np.flatnonzero(cnt == cnt.max()).size) >= 2, "the case should contain a tie"
+    engine.residual_matrix(THR2, fetch_R=False, fetch_counts=False)
+    assert engine.select_best() == (best, count)
+    assert engine.select_best(fetch=False) is None and engine.select_best() == (best, count)
+
+
+@pytest.mark.parametrize("n,k,seed", [(129, 2, 1), (1000, 3, 2), (4099, 4, 7)])
+def test_cost_matrix_bit_exact(engine, synth, oracle, n, k, seed):
+    """mh_cost_matrix against the oracle's dataEnergy (M/MultiH.cpp:473-504) for every (point, model), and its fused
+    counts against the score; includes degenerate models (non-finite d2 takes the `beyond` branch like the reference)."""
+    sc = synth.make_scene(n, k, seed=seed, with_neighbours=False)
+    rng = np.random.default_rng(seed)
+    H = np.concatenate([sc.H_true, sc.H_true[rng.integers(0, k, 20)] * (1 + rng.normal(0, 2e-4, (20, 9))),
+                        np.array([[1, 0, 0, 0, 1, 0, 0, 0, 0], [1, 0, 0, 0, 1, 0, 1e-3, -1e-3, 0.0]])])
+    _load(engine, sc)
+    engine.set_models(H)
+    Cm, cnt = engine.cost_matrix()
+    with np.errstate(all="ignore"):
+        ref = oracle.data_cost(sc.src, sc.dst, H, 0.5, THR2)           # site-major, label 0 = outlier
+        assert np.array_equal(Cm, ref[:, 1:].T)
+        assert np.array_equal(cnt, oracle.score(sc.src, sc.dst, H, THR2))
+    assert set(np.unique(Cm)).issubset(set(range(0, 201)) | {9802})
+
+
+def _rccl(mh):
+    lib = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so"))
+    lib.mhr_last_error.restype = C.c_char_p
+    lib.mhr_calls.restype = C.c_longlong
+    return lib
+
+
+def test_native_rccl_transport_on_a_one_rank_communicator(mh, engine, synth, oracle):
+    """mh_set_transport with RCCL's ncclAllGather (libmultih_rccl.so, include/multih_rccl.h) as the stream-ordered
+    transport.  One rank is all this box has, but the communicator, the collective on the engine's stream, the
+    88-byte records and the first round's score all-gather are the real ones: the selection must be the unsharded one
+    (which is compared with the oracle's), and the collective must actually have been used."""
+    rl = _rccl(mh)
+    uid = (C.c_ubyte * 128)()
+    assert rl.mhr_unique_id(uid) == 0, rl.mhr_last_error()
+    comm = C.c_void_p()
+    assert rl.mhr_init(C.byref(comm), 0, 1, uid, 0) == 0, rl.mhr_last_error()
+    try:
+        sc = synth.make_scene(4000, 4, seed=31, with_neighbours=False)
+        _load(engine, sc)
+        engine.propose_dlt4(77, 0, 3001)
+        plain = engine.select_greedy(THR2, 20, 8, np.ones(sc.n, np.uint8))
+        engine.set_transport(0, 1, stream_fn=rl.mhr_allgather, ctx=comm)
+        before = rl.mhr_calls(comm)
+        via = engine.select_greedy(THR2, 20, 8, np.ones(sc.n, np.uint8), total_m=3001)
+        used = rl.mhr_calls(comm) - before
+        for a, b in zip(plain, via):
+            assert np.array_equal(a, b)
+        assert len(plain[1]) >= 4
+        assert used == len(via[1]) + 1 + 1, "one score all-gather, then one 88-byte record all-gather per round"
+        H_all, _, _ = oracle.dlt4(sc.src, sc.dst, oracle.sample4(77, 0, 3001, sc.n))
+        _, idx_o, cnt_o, mask_o = oracle.select_greedy(sc.src, sc.dst, H_all, THR2, 20, 8)
+        assert idx_o.tolist() == via[1].tolist() and cnt_o.tolist() == via[2].tolist() and np.array_equal(mask_o, via[3])
+    finally:
+        engine.set_transport(0, 1)
+        rl.mhr_destroy(comm)
+
+
+def test_harness_with_rccl_ranks_equals_the_plain_run(mh, synth, tmp_path):
+    """multih_harness --ranks 1: the C++ path end to end — fork-free one-rank communicator, MultiH::SetShardingStream,
+    every propose batch through the sharded protocol — writes the result file of the plain run."""
+    sc = synth.make_scene(3000, 3, seed=12, with_neighbours=False)
+    corr = tmp_path / "corr.txt"
+    np.savetxt(corr, np.concatenate([sc.src, sc.dst, sc.aff], axis=1), fmt="%.17g")
+    epi = tmp_path / "epi.txt"
+    np.savetxt(epi, np.concatenate([sc.F, sc.e2])[None], fmt="%.17g")
+    harness = os.path.join(os.path.dirname(mh.LIB_PATH), "multih_harness")
+    outs = []
+    for extra in ([], ["--ranks", "1"]):
+        out = tmp_path / f"res{len(outs)}.txt"
+        r = subprocess.run([harness, str(corr), str(out), "--epipolar", str(epi), "--hypotheses", "3000"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        if extra:
+            assert "joined the RCCL communicator" in r.stdout
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == sc.n
+    assert len(set(int(l.split()[-1]) for l in outs[0].splitlines())) >= 3

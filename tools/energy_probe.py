@@ -18,14 +18,35 @@ SECONDS = float(os.environ.get("SECONDS", 3.0))
 VARIANTS = os.environ.get("RV", "0,20,2,22,3,10,7").split(",")
 
 
+def pci_dir():
+    """sysfs directory of the GPU that HIP device 0 is (a box may expose the sensors of every GPU of its node)."""
+    import ctypes
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = ctypes.CDLL(name)
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+                d = "/sys/bus/pci/devices/" + buf.value.decode().lower()
+                if os.path.isdir(d):
+                    return d
+        except OSError:
+            continue
+    return None
+
+
+PCI = pci_dir()
+
+
 def find_sensor():
-    for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
-        for f in sorted(glob.glob(pat)):
-            try:
-                if int(open(f).read()) > 0:
-                    return f
-            except Exception:
-                pass
+    roots = [PCI] if PCI else sorted(glob.glob("/sys/class/drm/card*/device"))
+    for root in roots:
+        for leaf in ("power1_average", "power1_input"):
+            for f in sorted(glob.glob(os.path.join(root, "hwmon", "hwmon*", leaf))):
+                try:
+                    if int(open(f).read()) > 0:
+                        return f
+                except Exception:
+                    pass
     return None
 
 
@@ -33,11 +54,24 @@ SENSOR = find_sensor()
 
 
 def sclk_file():
-    f = glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")
-    return f[0] if f else None
+    roots = [PCI] if PCI else sorted(glob.glob("/sys/class/drm/card*/device"))
+    for root in roots:
+        f = os.path.join(root, "pp_dpm_sclk")
+        if os.path.exists(f):
+            return f
+    return None
 
 
 SCLK = sclk_file()
+
+
+def power_cap():
+    if SENSOR:
+        try:
+            return int(open(os.path.join(os.path.dirname(SENSOR), "power1_cap")).read()) * 1e-6
+        except Exception:
+            return None
+    return None
 
 
 def read_power():
@@ -92,8 +126,9 @@ e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff)
 e.propose_dlt4(1234, 0, M)
 thr2 = 2.2 ** 2
-out = {"points": N, "models": M, "seconds_per_variant": SECONDS, "power_sensor": SENSOR or "rocm-smi --showpower",
-       "idle_power_W": read_power(), "variants": []}
+out = {"points": N, "models": M, "seconds_per_variant": SECONDS, "power_sensor": SENSOR or "rocm-smi --showpower", "pci_device": PCI,
+       "power_cap_W": power_cap(), "idle_power_W": read_power(), "variants": []}
+print(json.dumps({k: v for k, v in out.items() if k != "variants"}), flush=True)
 
 
 def measure(name, launch, kid, pairs_bytes):
@@ -125,7 +160,8 @@ def measure(name, launch, kid, pairs_bytes):
 names = {"0": "product (PPL 4, MC 16, checked sweep)", "20": "lean sweep on clean tiles", "2": "nt stores", "22": "lean + nt stores",
          "3": "compiler IEEE division (41 VALU/pair)", "10": "fused multiply-adds (20 FP64 ops/pair, NOT bit-exact)",
          "7": "store-only calibration (no arithmetic)", "21": "lean + tile-major R", "23": "tile-major R", "24": "store-only, tile-major R",
-         "25": "lean PPL 6", "26": "lean PPL 8", "27": "lean PPL 2"}
+         "25": "lean PPL 6", "26": "lean PPL 8", "27": "lean PPL 2", "28": "lean, sc1 stores", "29": "lean, sc0 sc1 stores",
+         "30": "lean, sc1 nt stores", "31": "lean, sc0 sc1 nt stores"}
 for v in VARIANTS:
     v = v.strip()
     if not v:
