@@ -313,8 +313,10 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s)
 {
-    // PPL 4, MC 16, plain 16-B stores, the lean sweep wherever a tile and a model allow it (r03)
-    if (variant == 0) return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    // PPL 4, MC 16, the lean sweep wherever a tile and a model allow it, non-temporal 16-B stores (r03: the kernel runs at
+    // the board's power cap, its time is its energy; nt stores — nothing of R is ever re-read — cost 2.7 % less energy
+    // per launch than plain ones, profiles/r03_energy.json)
+    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
@@ -336,10 +338,10 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 8: return launch_rs<8, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 8
     case 9: return launch_rs<6, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 6
     case 10: return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // fused multiply-adds: NOT bit-exact
-    case 20: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean sweep on clean tiles (= the product since r03)
+    case 20: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean sweep on clean tiles, plain stores
     case 32: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                                                 // the r02 product kernel: checked sweep everywhere
     case 21: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // lean + tile-major R
-    case 22: return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);          // lean + nt stores
+    case 22: return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);          // lean + nt stores (= the product since r03)
     case 23: return launch_rs<4, 16, true, false, false, true, false, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // tile-major R alone
     case 24: return launch_rs<4, 16, true, false, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration, tile-major R
     case 25: return launch_rs<6, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 6
@@ -348,6 +350,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 29: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 3>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 stores
     case 30: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 4>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc1 nt stores
     case 31: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 5>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 nt stores
+    case 33: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);           // lean + nt, coefficients through the scalar unit
     case 27: return launch_rs<2, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 2
     default: break;
     }
