@@ -246,8 +246,11 @@ MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int*
  * device as provably idempotent), 10 moves whose undecided core was not empty, 11 sum and 12 maximum of the
  * core sizes, 13 grid barriers, 14 global relabels, 15 microseconds spent inside the solver launches, of which
  * 16 inside grid barriers, 17 in global relabels and 18 in push phases (both including their barriers), 19 in
- * relabel/push rounds that began with fewer than 64 solver rows still holding excess (the tail of a move)}. */
-MH_API int mh_get_expand_stats(mh_engine* e, long long stats[20]);
+ * relabel/push rounds that began with fewer than 64 solver rows still holding excess (the tail of a move), 20 restarts of
+ * the expansion after a grid-barrier timeout (a GPU shared with other persistent launches: each restart halves the
+ * solver's workgroups; results never depend on their number), 21 workgroups of the solver launch in the attempt that
+ * completed, 22 moves solved inside one XCD (small cores), 23 reserved}. */
+MH_API int mh_get_expand_stats(mh_engine* e, long long stats[24]);
 /* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid
  * barriers, 100 MHz ticks inside the launch, of which inside barriers}; all zero for moves that were skipped or had an empty core. */
@@ -279,7 +282,8 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * rounds per launch (0 = off), 7 mean-shift iterations per host round trip, 8 moves logged by mh_get_expand_trace
  * (0 = off), 9 move whose relabels are logged one by one, 10 push cycles per phase as a multiple of the last
  * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow), 12
- * dominance-reduction launches per move (1 or 2).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * dominance-reduction launches per move (1 or 2), 14 test hook: the first attempts of the next n expansions count as
+ * barrier time-outs (exercises the restart with fewer workgroups).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

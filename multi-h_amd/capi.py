@@ -366,11 +366,12 @@ class Engine:
         return labels, energy.value, cycles.value
 
     def expand_stats(self):
-        st = (C.c_longlong * 20)()
+        st = (C.c_longlong * 24)()
         self._check(self.lib.mh_get_expand_stats(self._h, st))
         return dict(zip(("cycles", "moves", "accepted", "push_phases", "relax_intervals", "host_syncs",
                          "reduce_launches", "flow_moves", "launches", "moves_run", "moves_solved",
-                         "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us", "tail_us"),
+                         "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us", "tail_us",
+                         "barrier_timeout_retries", "solver_workgroups", "xcd_local_moves", "reserved"),
                         list(st)))
 
     def expand_trace(self, moves: int):

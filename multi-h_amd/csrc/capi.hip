@@ -133,6 +133,10 @@ struct mh_engine {
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
     int cu_count = 256;
+    int solve_grid_max = 0;                  // workgroups of the solver launch that can be resident at once (0 = not queried yet)
+    int last_expand_retries = 0;             // restarts of the last expansion after a barrier timeout (shared GPU)
+    int last_solve_grid = 0;                 // workgroups of the solver launch in the attempt that completed
+    int inject_barrier_timeouts = 0;         // test hook: the next n expansions' first attempts count as timed out
     DevBuf<long long> ew_acc;
     int* h_flags = nullptr;
     MeanShiftResultBlock* h_ms = nullptr;      // mapped pinned result block of the mean-shift climbs
@@ -510,6 +514,18 @@ int do_data_cost(mh_engine* e)
     return MH_OK;
 }
 
+// How many workgroups of the solver launch the device holds at once: the occupancy query's answer for k_solve at its
+// default dynamic LDS, times the CUs — and never more than one per CU (the kernel is written for that).
+int solve_grid_limit(mh_engine* e)
+{
+    if (e->solve_grid_max > 0) return MH_OK;
+    int per_cu = 0;
+    HIPCHK(solver_blocks_per_cu(&per_cu));
+    if (per_cu < 1) return fail(MH_ERR_HIP, "the alpha-expansion solver kernel does not fit a compute unit");
+    e->solve_grid_max = e->cu_count * 1;
+    return MH_OK;
+}
+
 // init_dev: device pointer to initial labels (GCO numbering) or null.
 int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
 {
@@ -518,9 +534,15 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     int rc = ensure_expand_work(e);
     if (rc) return rc;
     Graph g{ e->d_rowptr.p, e->d_col.p, e->d_w.p, e->d_rev.p, e->n, e->g_nnz, e->d_order.p, e->d_wsum.p };
-    // the solver launch must be resident as a whole (it synchronises through a grid barrier): at most half
-    // the CUs, so that engines of other processes sharing the GPU can never starve each other's launches
-    const int solve_grid = std::max(1, std::min(e->tune_expand[3], e->cu_count));
+    // The solver launch synchronises through a grid barrier, so it must be resident as a whole: one 512-thread workgroup
+    // per CU at most (what the occupancy query admits for this kernel is checked once per engine, solve_grid_limit).
+    // One process per GPU — the deployment — always is.  Engines of several processes that share a GPU can keep each
+    // other's workgroups off the chip; a launch whose barrier then gives up (3 s) is not an error any more: the
+    // expansion is restarted from its initial labeling with half the workgroups (results never depend on that number),
+    // up to four times — a shared GPU degrades instead of failing.  `mh_set_tuning` key 5 sets the starting number.
+    rc = solve_grid_limit(e);
+    if (rc) return rc;
+    int solve_grid = std::max(1, std::min(e->tune_expand[3], e->solve_grid_max));
     ExpandWork w{ e->ew_label.p, e->ew_cur.p, e->ew_cap.p, e->ew_sent.p, e->ew_excess.p, e->ew_sink.p,
                   e->ew_height.p, e->ew_decided.p, e->ew_took.p, e->ew_core.p, e->ew_flags.p, e->ew_acc.p,
                   e->h_flags, e->h_acc, e->h_flags_dev, e->h_acc_dev,
@@ -547,15 +569,32 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
     ExpandStats st{};
     {
         ScopedTimer t(e, MH_K_EXPAND);
-        HIPCHK(launch_init_labeling(e->cost.p, e->cost_L, e->n, init_dev, w.label, w.cur_cost, e->stream));
-        hipError_t he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
+        hipError_t he = hipSuccess;
+        e->last_expand_retries = 0;
+        for (int attempt = 0; attempt < 5; ++attempt) {
+            w.solve_grid = solve_grid;
+            if (w.saved_flow) HIPCHK(hipMemsetAsync(e->ew_saved.p, 0, sizeof(int) * recycle_words, e->stream));
+            HIPCHK(launch_init_labeling(e->cost.p, e->cost_L, e->n, init_dev, w.label, w.cur_cost, e->stream));
+            he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
+            bool timed_out = he == hipErrorLaunchTimeOut && st.energy == -2;
+            if (he == hipSuccess && e->inject_barrier_timeouts > 0) {           // test hook (mh_set_tuning key 14)
+                --e->inject_barrier_timeouts;
+                timed_out = true;
+                he = hipErrorLaunchTimeOut;
+                st.energy = -2;
+            }
+            e->last_solve_grid = solve_grid;
+            if (!timed_out || solve_grid == 1 || attempt == 4) break;
+            solve_grid = std::max(1, solve_grid / 2);
+            ++e->last_expand_retries;
+        }
         if (he == hipErrorOutOfMemory)
             return fail(MH_ERR_INVALID, "alpha-expansion: more sites than the solver's per-row state holds (about 1.3 million at 256 workgroups)");
         if (he == hipErrorInvalidValue && st.energy == -1)
             return fail(MH_ERR_OVERFLOW, "int32 energy term overflow in alpha-expansion");
         if (he == hipErrorLaunchTimeOut && st.energy == -2)
-            return fail(MH_ERR_HIP, "alpha-expansion: the solver's grid barrier timed out (its workgroups were not all resident; "
-                                    "is the GPU shared with other persistent launches?)");
+            return fail(MH_ERR_HIP, "alpha-expansion: the solver's grid barrier timed out even with the launch cut down to a few workgroups "
+                                    "(its workgroups were not all resident; is the GPU shared with other persistent launches?)");
         if (he == hipErrorLaunchTimeOut && st.energy == -3)
             return fail(MH_ERR_HIP, "alpha-expansion: push-relabel did not converge within its iteration bound");
         HIPCHK(he);
@@ -1770,7 +1809,7 @@ int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int* energy
     });
 }
 
-int mh_get_expand_stats(mh_engine* e, long long stats[20])
+int mh_get_expand_stats(mh_engine* e, long long stats[24])
 {
     return guarded([&]() -> int {
     if (!e || !stats) return fail(MH_ERR_INVALID, "null argument");
@@ -1795,6 +1834,10 @@ int mh_get_expand_stats(mh_engine* e, long long stats[20])
     stats[17] = (long long)(x.relax_ms * 1000.0);
     stats[18] = (long long)(x.push_ms * 1000.0);
     stats[19] = (long long)(x.tail_ms * 1000.0);
+    stats[20] = e->last_expand_retries;
+    stats[21] = e->last_solve_grid;
+    stats[22] = 0;
+    stats[23] = 0;
     return MH_OK;
     });
 }
@@ -1807,7 +1850,8 @@ int mh_get_expand_trace(mh_engine* e, int* trace, int moves)
     if (!trace || moves <= 0) return fail(MH_ERR_INVALID, "null trace or moves <= 0");
     if (e->trace_moves <= 0 || !e->ew_trace.p) return fail(MH_ERR_NOT_SET, "tracing is off (mh_set_tuning key 8) or no expansion has run");
     // rows [0, trace_moves): the moves; rows behind them: the relabel log of the detail move (key 9), two relabels per row
-    const int m = std::min(moves, e->trace_moves + 1024);
+    // (the buffer was sized by the trace_moves in force at the last expansion: never read past it)
+    const int m = std::min(moves, (int)std::min<size_t>((size_t)e->trace_moves + 1024, e->ew_trace.cap / 8));
     HIPCHK(hipMemcpyAsync(trace, e->ew_trace.p, sizeof(int) * 8 * (size_t)m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
@@ -1952,6 +1996,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }
     if (key == 11 && (value == 0 || value == 1)) { e->tune_recycle = value; return MH_OK; }
     if (key == 12 && (value == 1 || value == 2)) { e->tune_reduce_launches = value; return MH_OK; }
+    if (key == 14 && value >= 0 && value <= 8) { e->inject_barrier_timeouts = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -1222,6 +1222,11 @@ static hipError_t fetch(ExpandWork& w, ExpandStats& st, hipStream_t s)
     return hipStreamSynchronize(s);
 }
 
+hipError_t solver_blocks_per_cu(int* blocks)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, (const void*)k_solve, SOLVE_THREADS, sizeof(int) * F_FIELDS * SOLVE_ROWS);
+}
+
 hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, ExpandWork& w,
                          int max_cycles, ExpandStats* st, hipStream_t s)
 {

@@ -167,6 +167,8 @@ struct ExpandStats {
     long long tail_rounds;
 };
 
+// resident workgroups of the solver launch per CU, as the occupancy query sees k_solve
+hipError_t solver_blocks_per_cu(int* blocks);
 hipError_t run_expansion(const Graph& g, const int* cost /* n x L */, int L, int potts,
                          ExpandWork& w, int max_cycles, ExpandStats* st, hipStream_t s);
 hipError_t launch_init_labeling(const int* cost, int L, int n, const int* init_or_null_dev,

@@ -154,8 +154,8 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
         for (int mi = 0; mi < MC; ++mi) {
             const int m = m0 + mi;
             if (m < M) {                                   // wave-uniform
-                // HSGPR: coefficients through the scalar unit (uniform address -> s_load), so the
-                // twelve linear-form operations read one operand from SGPRs instead of VGPRs.
+                // HSGPR (the product): coefficients through the scalar unit (uniform address -> s_load_dwordx16 + x2 per
+                // model), so the twelve linear-form operations read one operand from SGPRs instead of VGPRs.
                 const double* h = HSGPR ? (H + 9 * (size_t)m) : (s_h + 9 * mi);
                 const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5],
                              h6 = h[6], h7 = h[7], h8 = h[8];
@@ -316,7 +316,9 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     // PPL 4, MC 16, the lean sweep wherever a tile and a model allow it, non-temporal 16-B stores (r03: the kernel runs at
     // the board's power cap, its time is its energy; nt stores — nothing of R is ever re-read — cost 2.7 % less energy
     // per launch than plain ones, profiles/r03_energy.json)
-    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    // ... and the nine coefficients of the current model through the scalar unit (s_load from H, uniform address) instead
+    // of LDS broadcasts into VGPRs: the twelve linear-form operations then read one operand from SGPRs; 2.5 % less energy.
+    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
     if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
@@ -341,7 +343,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 20: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean sweep on clean tiles, plain stores
     case 32: return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                                                 // the r02 product kernel: checked sweep everywhere
     case 21: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // lean + tile-major R
-    case 22: return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);          // lean + nt stores (= the product since r03)
+    case 22: return launch_rs<4, 16, true, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);          // lean + nt stores, coefficients from LDS
     case 23: return launch_rs<4, 16, true, false, false, true, false, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // tile-major R alone
     case 24: return launch_rs<4, 16, true, false, false, true, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // store-only calibration, tile-major R
     case 25: return launch_rs<6, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 6
@@ -350,7 +352,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 29: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 3>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 stores
     case 30: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 4>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc1 nt stores
     case 31: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 5>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 nt stores
-    case 33: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);           // lean + nt, coefficients through the scalar unit
+    case 33: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);           // lean + nt, coefficients through the scalar unit (= the product since r03)
     case 27: return launch_rs<2, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 2
     default: break;
     }
@@ -365,11 +367,12 @@ hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
         if (mask) return launch_rs<4, 16, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
         return launch_rs<4, 16, false, false, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
     }
-    if (mask) return launch_rs<4, 16, false, true, false, true, false, false, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
-    if (variant == 0) return launch_rs<4, 16, false, false, false, true, false, false, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
+    if (mask) return launch_rs<4, 16, false, true, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, mask, s);
+    if (variant == 0) return launch_rs<4, 16, false, false, false, true, false, true, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == 1) return launch_rs<2, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);           // PPL 2
     if (variant == 32) return launch_rs<4, 16, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);          // the r02 score kernel
+    if (variant == 20) return launch_rs<4, 16, false, false, false, true, false, false, false, false, true>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);   // lean, coefficients from LDS
     if (variant == 3) return launch_rs<4, 16, false, false, false, false>(p, H, M, thr2, nullptr, 0, counts, nullptr, s);    // compiler IEEE division
 #endif
     return hipErrorInvalidValue;

@@ -497,7 +497,7 @@ void MultiH::ClusterMergingAndLabeling()
         const bool labelled = LabelingStep(energy, changed);
         label_s += seconds_since(t_label);
         if (timing) {
-            long long st[20] = {};
+            long long st[24] = {};
             (void)mh_get_expand_stats(engine, st);
             printf("[Multi-H] iteration %d: %d clusters, changed %d, merging %.1f ms so far, labeling %.1f ms so far (this step %.1f ms: "
                    "%lld cycles, %lld moves solved, core %lld / max %lld, %lld relabels, %lld barriers, solver %.1f ms of which tail rounds %.1f ms)\n",
@@ -657,6 +657,10 @@ extern "C" __attribute__((visibility("default")))
 void mhh_set_post_filter(int on) { g_post_filter = on; }
 extern "C" __attribute__((visibility("default")))
 void mhh_set_neighbourhood(int knn_k, double radius) { g_knn = knn_k; g_radius = radius; }
+// bound on the hits of the complete radius list (MultiH::SetNeighbourRadius' max_hits); <= 0 restores the default
+static long long g_max_hits = 0;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_neighbour_max_hits(long long max_hits) { g_max_hits = max_hits; }
 // schedule knobs (mh_set_tuning) for the engines of the next mhh_run_process calls; key < 0 clears the list
 static std::vector<std::pair<int, int>> g_tuning;
 extern "C" __attribute__((visibility("default")))
@@ -688,7 +692,8 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetDevice(g_device);
     mh.SetCompatibilityCheck(g_post_filter != 0);
     for (const auto& kv : g_tuning) mh.SetEngineTuning(kv.first, kv.second);
-    if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
+    if (g_radius > 0.0 && g_max_hits > 0) { mh.SetNeighbourRadius(g_radius, g_max_hits); if (g_knn > 0) mh.SetFallbackK(g_knn); }
+    else if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
     else if (g_knn > 0) mh.SetNeighbourK(g_knn);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init
     if (init_H && n_init > 0) {

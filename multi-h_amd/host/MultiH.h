@@ -81,6 +81,8 @@ public:
     // The complete radius list instead (every hit within `radius`, exact), bounded by `max_hits` because it grows like
     // N^2: beyond the bound the k nearest hits within the radius are used and a line says so.
     void SetNeighbourRadius(double radius, long long max_hits = 1ll << 28) { neighbour_mode = NEIGHBOURS_RADIUS; neighbour_radius = radius; neighbour_max_hits = max_hits; }
+    // k of that fallback (default 16) without leaving the radius mode
+    void SetFallbackK(int k) { knn = k; }
     // Initial cluster_homographies (what EstablishStablePointSets hands to the loop).
     void SetInitialHomographies(const std::vector<cv::Mat>& Hs);
     // How the initial models are made when SetInitialHomographies was not called:

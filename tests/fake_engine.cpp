@@ -84,7 +84,7 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long, long long, int m)
 }
 int mh_set_models(mh_engine* e, const double* H, int m) { e->m = m; e->H.assign(H, H + 9 * (size_t)m); return MH_OK; }
 int mh_set_tuning(mh_engine*, int, int) { return MH_OK; }
-int mh_get_expand_stats(mh_engine*, long long stats[20]) { for (int i = 0; i < 20; ++i) stats[i] = 0; return MH_OK; }
+int mh_get_expand_stats(mh_engine*, long long stats[24]) { for (int i = 0; i < 24; ++i) stats[i] = 0; return MH_OK; }
 int mh_get_expand_trace(mh_engine*, int*, int) { return MH_ERR_NOT_SET; }
 int mh_get_models(mh_engine* e, double* H) { std::memcpy(H, e->H.data(), sizeof(double) * 9 * (size_t)e->m); return MH_OK; }
 int mh_score(mh_engine* e, double, const unsigned char*, int* counts)

@@ -165,3 +165,30 @@ def test_process_from_stable_point_sets_equals_the_oracle(mh, engine_lib, synth,
     got = _run_process(mh, sc, seed, stable_sets=True)
     _assert_same_result(got, want)
     assert got[0] >= 2
+
+
+def test_radius_list_beyond_its_bound_falls_back_to_the_nearest_hits(mh, engine_lib, synth, capfd):
+    """MultiH::SetNeighbourRadius(radius, max_hits): when the complete radius list would exceed max_hits the engine
+    refuses it (MH_ERR_OVERFLOW) and the class says so and continues with the k nearest hits inside the same radius —
+    the result must be the one of asking for those directly."""
+    sc = synth.make_scene(2000, 3, seed=14, with_neighbours=False)
+    H0 = _initial_models(sc, 14, 1, 0)
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    host.mhh_set_neighbour_max_hits.argtypes = [C.c_longlong]
+    radius = 1.0 / LOCALITY
+    try:
+        host.mhh_set_neighbourhood(12, C.c_double(0.0))               # the 12 nearest hits within 1/locality
+        want = _run_process(mh, sc, 14, H0=H0)
+        C.CDLL(None).fflush(None)
+        capfd.readouterr()
+        host.mhh_set_neighbourhood(12, C.c_double(radius))            # the complete list, bounded far below its size
+        host.mhh_set_neighbour_max_hits(1000)
+        got = _run_process(mh, sc, 14, H0=H0)
+        C.CDLL(None).fflush(None)
+        out = capfd.readouterr().out
+    finally:
+        host.mhh_set_neighbourhood(0, C.c_double(0.0))
+        host.mhh_set_neighbour_max_hits(0)
+    assert "exceed the limit" in out and "nearest hits instead" in out
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[3] == want[3] and got[4] == want[4]
+    assert np.array_equal(got[2], want[2])

@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,3 +76,46 @@ def test_process_survives(case):
         assert k == -1 and "Features are not set" in out.stderr          # M/MultiH.cpp:44-50
     if case in ("pure_noise", "identical_points"):
         assert k <= 2
+
+
+def test_expansion_restarts_with_fewer_workgroups_after_a_barrier_timeout(engine, synth, oracle):
+    """A GPU shared with another process' persistent launch can keep workgroups of the solver off the chip until its grid
+    barrier gives up.  That is not an error any more: the expansion starts over from its initial labeling with half the
+    workgroups (results never depend on their number).  mh_set_tuning key 14 makes the first attempts count as timed
+    out, which exercises exactly that path; labels, energy and cycle count stay the oracle's."""
+    sc = synth.make_scene(3000, 4, seed=9)
+    rng = np.random.default_rng(9)
+    H = np.concatenate([sc.H_true, sc.H_true[rng.integers(0, 4, 3)] * (1 + rng.normal(0, 2e-4, (3, 9)))])
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.set_epipolar(sc.F, sc.e2)
+    engine.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
+    engine.set_models(H)
+    cost = engine.data_cost()
+    lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(0.5))
+    init = (sc.gt_label + 1).astype(np.int32)
+    lab_w_ref, e_w_ref, _, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(0.5), init_labels=init)
+    engine.set_tuning(14, 2)
+    labels, energy, cycles = engine.expand()
+    st = engine.expand_stats()
+    assert st["barrier_timeout_retries"] == 2 and st["solver_workgroups"] == 256 // 4
+    assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref)
+    engine.set_tuning(14, 1)
+    labels, energy, _ = engine.expand(init)                      # the restart begins from the caller's labeling again
+    assert engine.expand_stats()["barrier_timeout_retries"] == 1
+    assert energy == e_w_ref and np.array_equal(labels, lab_w_ref)
+    labels, energy, cycles = engine.expand()
+    assert engine.expand_stats()["barrier_timeout_retries"] == 0 and energy == e_ref
+
+
+def test_greedy_selection_refuses_the_symmetric_residual_mode(mh, engine, synth):
+    sc = synth.make_scene(500, 2, seed=1, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.propose_dlt4(1, 0, 64)
+    engine.set_residual_mode(True)
+    try:
+        with pytest.raises(mh.MultiHError) as ei:
+            engine.select_greedy(2.2 ** 2, 8, 4)
+        assert ei.value.code == -2 and "forward" in str(ei.value)
+    finally:
+        engine.set_residual_mode(False)
+    assert len(engine.select_greedy(2.2 ** 2, 8, 4)[1]) >= 1
