@@ -1611,7 +1611,13 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
 // ---- pipelined propose -------------------------------------------------------------------------
 static int ensure_side_stream(mh_engine* e)
 {
-    if (!e->side_stream) HIPCHK(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    if (!e->side_stream) {
+        // highest priority: the short DLT kernel gets its compute units as soon as the sweep on the main stream frees
+        // some, so it is done early in the sweep instead of trickling in behind it and delaying the next one
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, hi));
+    }
     if (!e->ev_side) HIPCHK(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
     if (!e->ev_main) HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
     return MH_OK;

@@ -126,10 +126,13 @@ __device__ __forceinline__ double fwd_d2_fast(double h0, double h1, double h2, d
 // The fast path of fwd_d2_fast alone, for callers that have proved ALL its preconditions beforehand for every lane
 // (model_pre and model_far for the model, point_pre for every point of the wave's tile): the same rounded operations in
 // the same order, so the same bits as `/`, and nothing else.
+// s_out: the denominator, for the caller's |s| >= 2^-255 test where the model is not provably `far`.
 __device__ __forceinline__ double fwd_d2_lean(double h0, double h1, double h2, double h3, double h4, double h5,
-                                              double h6, double h7, double h8, double x, double y, double x2, double y2)
+                                              double h6, double h7, double h8, double x, double y, double x2, double y2,
+                                              double& s_out)
 {
     const double s = h6 * x + h7 * y + h8;
+    s_out = s;
     const double nx = h0 * x + h1 * y + h2;
     const double ny = h3 * x + h4 * y + h5;
     double r = __builtin_amdgcn_rcp(s);

@@ -40,7 +40,7 @@ namespace mh {
 // TILED (tuning): R stored tile-major — [model block][point tile][MC][TILE] — so that a workgroup writes one contiguous
 // 128-KiB block per tile instead of MC row segments.
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true>
 __global__ void __launch_bounds__(256)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -226,31 +226,48 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
                     if (TILED) return R + ((size_t)bx * ntiles_all + tile_idx) * ((size_t)MC * TILE) + (size_t)mi * TILE + (n - base);
                     return R + (size_t)m * ldr + n;
                 };
-                if (LEAN && FAST && !SYM && !CONTRACT && !CALIB && tile_lean && hok && far) {
+                // The lean sweep: all PPL residuals first, then the stores and the counts.  `far` models (the horizon provably
+                // clear of every point) need no check at all; for the others ONE wave-wide test per model — did any of the
+                // PPL x 64 denominators leave the fast division's range? — replaces the per-pair branch, and the rare wave
+                // that says yes redoes this model through the checked sweep (nothing has been stored or counted yet).
+                bool lean_done = false;
+                if (LEAN && FAST && !SYM && !CONTRACT && !CALIB && tile_lean && hok && (SEMI || far)) {
+                    double dl[PPL];
+                    unsigned long long bad = 0ull;          // lanes whose denominator is out of range (or NaN), any of the PPL pairs
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const double d0 = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c], py[2 * c], qx[2 * c], qy[2 * c]);
-                        const double d1 = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[2 * c + 1], py[2 * c + 1], qx[2 * c + 1], qy[2 * c + 1]);
-                        if (WRITE_R) {
-                            double* dstp = row_ptr(wbase + c * 128 + lane * 2);
-                            if (SF != 0) {          // measurement builds: cache-policy bits of the store spelt out
-                                typedef double d2v __attribute__((ext_vector_type(2)));
-                                const d2v val = { d0, d1 };
-                                if (SF == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(val) : "memory");
-                                else if (SF == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dstp), "v"(val) : "memory");
-                                else if (SF == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dstp), "v"(val) : "memory");
-                                else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dstp), "v"(val) : "memory");
-                            } else if (NT) {
-                                __builtin_nontemporal_store(d0, dstp);
-                                __builtin_nontemporal_store(d1, dstp + 1);
-                            } else {
-                                *reinterpret_cast<double2*>(dstp) = make_double2(d0, d1);
-                            }
-                        }
-                        c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 < thr2));
-                        c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1 < thr2));
+                    for (int q = 0; q < PPL; ++q) {
+                        double sq;
+                        dl[q] = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[q], py[q], qx[q], qy[q], sq);
+                        if (!far) bad |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sq) >= 0x1p-255));
                     }
-                } else if (far) sweep(std::false_type{});
+                    if (bad == 0ull) {
+                        lean_done = true;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            const double d0 = dl[2 * c], d1 = dl[2 * c + 1];
+                            if (WRITE_R) {
+                                double* dstp = row_ptr(wbase + c * 128 + lane * 2);
+                                if (SF != 0) {          // measurement builds: cache-policy bits of the store spelt out
+                                    typedef double d2v __attribute__((ext_vector_type(2)));
+                                    const d2v val = { d0, d1 };
+                                    if (SF == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(val) : "memory");
+                                    else if (SF == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dstp), "v"(val) : "memory");
+                                    else if (SF == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dstp), "v"(val) : "memory");
+                                    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dstp), "v"(val) : "memory");
+                                } else if (NT) {
+                                    __builtin_nontemporal_store(d0, dstp);
+                                    __builtin_nontemporal_store(d1, dstp + 1);
+                                } else {
+                                    *reinterpret_cast<double2*>(dstp) = make_double2(d0, d1);
+                                }
+                            }
+                            c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 < thr2));
+                            c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1 < thr2));
+                        }
+                    }
+                }
+                if (lean_done) {}
+                else if (far) sweep(std::false_type{});
                 else sweep(std::true_type{});
                 // lane mi accumulates model mi: read-modify-write of that one lane through the scalar unit
                 const int c_new = __builtin_amdgcn_readlane(cnt, mi) + c_m;
@@ -271,7 +288,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0, int swapxy = 0)
@@ -300,7 +317,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     }
     dim3 grid(gx, psplit);
     if (swapxy) grid = dim3(psplit, gx);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy,
                        p.xmin, p.xmax, p.ymin, p.ymax);
     return hipGetLastError();
@@ -353,6 +370,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 30: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 4>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc1 nt stores
     case 31: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 5>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 nt stores
     case 33: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);           // lean + nt, coefficients through the scalar unit (= the product since r03)
+    case 34: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true, false, 0, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // as the product, but models that are not `far` take the checked sweep
     case 27: return launch_rs<2, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 2
     default: break;
     }

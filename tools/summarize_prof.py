@@ -20,7 +20,7 @@ for f in find("trace", "*kernel_stats.csv"):
         for i, row in enumerate(csv.reader(fh)):
             if i < ROWS: print("  ", ",".join(row))
 # Per-dispatch durations of the residual kernel from the kernel trace, in launch order: bench.py runs WARMUP untimed steps,
-# then STEPS timed ones (the headline), then the same again for the pipelined form.  The average over the headline's timed
+# then STEPS timed ones (the headline, pipelined), then the same again for the sequential form.  The average over the headline's timed
 # launches is what bench.py's own event timing reports as kernel_ms.k_residual; warm-up launches are left out.
 for f in find("trace", "*kernel_trace.csv"):
     durs = []
@@ -37,7 +37,7 @@ for f in find("trace", "*kernel_trace.csv"):
         print(f"   -> {alg / (sum(head) / len(head) * 1e-3) / 1e9:.1f} GB/s = {alg / (sum(head) / len(head) * 1e-3) / 8e12:.4f} of the 8 TB/s peak (algorithmic {alg / 1e9:.4f} GB per launch)")
         rest = durs[2 * WARMUP + STEPS: 2 * WARMUP + 2 * STEPS]
         if len(rest) == STEPS:
-            print(f"   pipelined form (the DLT of the next batch beside it), its timed launches: avg {sum(rest) / len(rest):.4f} ms")
+            print(f"   sequential form (no kernel beside it), its timed launches: avg {sum(rest) / len(rest):.4f} ms = {alg / (sum(rest) / len(rest) * 1e-3) / 8e12:.4f} of the peak")
 traffic = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_label"):
     for f in find(sub, "*counter_collection.csv"):
