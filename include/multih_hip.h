@@ -225,6 +225,10 @@ MH_API int mh_adopt_prefetched(mh_engine* e);
  * rank finds the same winner.  best_index / best_count both NULL: enqueue only (no host synchronisation; a later call
  * with outputs, or mh_synchronize, completes it). */
 MH_API int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* best_count);
+/* mh_score and mh_select_greedy decide most (point, model) pairs in FP32 with a rigorous error bound and only the pairs
+ * within that bound of the threshold in FP64 (csrc/score32.hip; the counts are the FP64 formula's, bit for bit).  pairs:
+ * pairs scored that way since the last reset; pairs_fp64: how many of them needed the FP64 formula. */
+MH_API int mh_get_score_stats(mh_engine* e, long long* pairs, long long* pairs_fp64, int reset);
 /* Number of explicit host<->device copies mh_select_greedy has issued since the last reset. */
 MH_API int mh_get_copy_stats(mh_engine* e, long long* h2d, long long* d2h, int reset);
 /* Per-model inlier moments {n, Sx, Sy, Sxx, Sxy, Syy} and smallest eigenvalue of the 3x3
@@ -283,7 +287,8 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * (0 = off), 9 move whose relabels are logged one by one, 10 push cycles per phase as a multiple of the last
  * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow), 12
  * dominance-reduction launches per move (1 or 2), 14 test hook: the first attempts of the next n expansions count as
- * barrier time-outs (exercises the restart with fewer workgroups).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * barrier time-outs (exercises the restart with fewer workgroups), 15 the FP32 pre-test of the score kernels (1 on, 0 the
+ * FP64 sweep for every pair; the counts are equal by construction).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

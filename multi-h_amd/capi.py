@@ -27,7 +27,7 @@ SYMBOLS = [
     "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
-    "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_get_score_stats", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_get_expand_trace", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
@@ -323,6 +323,12 @@ class Engine:
         idx, cnt = C.c_longlong(0), C.c_int(0)
         self._check(self.lib.mh_select_best(self._h, C.c_longlong(int(total_m)), C.byref(idx), C.byref(cnt)))
         return int(idx.value), int(cnt.value)
+
+    def score_stats(self, reset=False):
+        """(pairs scored through the FP32 pre-test, pairs among them that needed the FP64 formula)"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._check(self.lib.mh_get_score_stats(self._h, C.byref(a), C.byref(b), int(bool(reset))))
+        return int(a.value), int(b.value)
 
     def copy_stats(self, reset=False):
         a, b = C.c_longlong(0), C.c_longlong(0)

@@ -165,6 +165,13 @@ struct mh_engine {
     ExpandStats last_expand{};
 
     double bbox[4] = { NAN, NAN, NAN, NAN };   // xmin xmax ymin ymax of the source points
+    // FP32 pre-test of the score kernels (score32.hip): usable when every coordinate is finite and below 2^20
+    bool coords32_ok = false;
+    double absmax_x = NAN, absmax_y = NAN;
+    int tune_score32 = 1;                      // mh_set_tuning key 15: 0 = always the FP64 sweep (A/B; counts are equal by construction)
+    DevBuf<float> H32;
+    DevBuf<unsigned long long> fb_pairs;
+    long long score_pairs = 0;                 // pairs scored through the pre-test since the last reset (mh_get_score_stats)
     Points pts() const { return Points{ x1.p, y1.p, x2.p, y2.p, n, bbox[0], bbox[1], bbox[2], bbox[3] }; }
 };
 
@@ -634,6 +641,24 @@ void host_jacobi3(double* a, double* v, double* d)
     for (int i = 0; i < n; ++i) d[i] = a[i * n + i];
 }
 
+// Inlier counts of `m` models (device array Hs) over the points `p`: the FP32 pre-test kernel where its preconditions
+// hold (forward residual, bounded coordinates), the FP64 sweep otherwise.  Same counts either way.
+int score_models(mh_engine* e, const Points& p, const double* Hs, int m, double thr2, const unsigned char* dmask, int* counts_dev)
+{
+    const bool fwd = e->residual_mode != MH_RESIDUAL_SYMMETRIC;
+    if (fwd && e->tune_score32 && e->tune_score_variant == 0 && e->coords32_ok && m > 0) {
+        HIPCHK(e->H32.reserve((size_t)m * 16));
+        HIPCHK(e->fb_pairs.reserve(1));
+        if (e->score_pairs == 0) HIPCHK(hipMemsetAsync(e->fb_pairs.p, 0, sizeof(unsigned long long), e->stream));
+        HIPCHK(launch_model32(Hs, m, e->absmax_x, e->absmax_y, e->H32.p, e->stream));
+        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, dmask, counts_dev, e->fb_pairs.p, e->stream));
+        e->score_pairs += (long long)m * p.n;
+        return MH_OK;
+    }
+    HIPCHK(launch_score(p, Hs, m, thr2, dmask, counts_dev, fwd ? e->tune_score_variant : -1, e->stream));
+    return MH_OK;
+}
+
 __global__ void k_shift_labels(int n, const int* in, int delta, int* out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -725,7 +750,7 @@ void mh_destroy(mh_engine* e)
     for (int b = 0; b < 2; ++b) { e->sel_orig[b].release(); e->sel_cand_H[b].release(); }
     e->sel_counts.release(); e->sel_rec.release(); e->sel_scores.release(); e->sel_gathered.release(); e->sel_out_H.release();
     e->sel_records.release(); e->sel_counter.release(); e->sel_keys.release();
-    e->H_next.release(); e->samples_next.release(); e->best_key.release();
+    e->H_next.release(); e->samples_next.release(); e->best_key.release(); e->H32.release(); e->fb_pairs.release();
     if (e->h_best) (void)hipHostFree(e->h_best);
     if (e->ev_side) (void)hipEventDestroy(e->ev_side);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
@@ -804,16 +829,22 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
         e->m = 0; e->ldr = 0; e->have_samples = false; e->fm = 0;
     }
     {
-        double xmin = src_xy[0], xmax = src_xy[0], ymin = src_xy[1], ymax = src_xy[1];
-        bool finite = true;
+        double xmin = src_xy[0], xmax = src_xy[0], ymin = src_xy[1], ymax = src_xy[1], dmax = 0.0;
+        bool finite = true, dfinite = true;
         for (int i = 0; i < n; ++i) {
             const double x = src_xy[2 * i], y = src_xy[2 * i + 1];
             finite = finite && std::isfinite(x) && std::isfinite(y);
             xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
             ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
+            const double a = std::fabs(dst_xy[2 * i]), b = std::fabs(dst_xy[2 * i + 1]);
+            dfinite = dfinite && std::isfinite(a) && std::isfinite(b);
+            dmax = a > dmax ? a : dmax; dmax = b > dmax ? b : dmax;
         }
         if (!finite) xmin = xmax = ymin = ymax = NAN;
         e->bbox[0] = xmin; e->bbox[1] = xmax; e->bbox[2] = ymin; e->bbox[3] = ymax;
+        e->absmax_x = std::max(std::fabs(xmin), std::fabs(xmax));
+        e->absmax_y = std::max(std::fabs(ymin), std::fabs(ymax));
+        e->coords32_ok = finite && dfinite && e->absmax_x < 0x1p20 && e->absmax_y < 0x1p20 && dmax < 0x1p20;
     }
     e->n = n;
     e->have_aff = affines != nullptr;
@@ -1372,8 +1403,8 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
     }
     {
         ScopedTimer t(e, MH_K_SCORE);
-        HIPCHK(launch_score(e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p,
-                            e->residual_mode == MH_RESIDUAL_SYMMETRIC ? -1 : e->tune_score_variant, e->stream));
+        rc = score_models(e, e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p);
+        if (rc) return rc;
     }
     if (counts) {
         HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
@@ -1546,7 +1577,8 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         if (Mc > 0) {
             ScopedTimer t(e, MH_K_SCORE);
             if (active == n) {
-                HIPCHK(launch_score(e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p, e->tune_score_variant, s));
+                rc = score_models(e, e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p);
+                if (rc) return rc;
             } else if (active > 0) {
                 HIPCHK(launch_sel_pack_points(e->pts(), e->mask.p, e->sel_pts[0].p, e->sel_pts[1].p, e->sel_pts[2].p, e->sel_pts[3].p,
                                               e->sel_pack_count.p, s));
@@ -1554,7 +1586,8 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
                 Points packed = e->pts();                     // (same bounding box: a superset's is valid)
                 packed.x1 = e->sel_pts[0].p; packed.y1 = e->sel_pts[1].p; packed.x2 = e->sel_pts[2].p; packed.y2 = e->sel_pts[3].p;
                 packed.n = active;
-                HIPCHK(launch_score(packed, Hs, Mc, thr2, nullptr, e->sel_counts.p, e->tune_score_variant, s));
+                rc = score_models(e, packed, Hs, Mc, thr2, nullptr, e->sel_counts.p);
+                if (rc) return rc;
             } else {
                 HIPCHK(hipMemsetAsync(e->sel_counts.p, 0, sizeof(int) * (size_t)Mc, s));
             }
@@ -1710,6 +1743,23 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
         if (best_index) *best_index = e->h_best[1];
         if (best_count) *best_count = e->h_best[0];
     }
+    return MH_OK;
+    });
+}
+
+int mh_get_score_stats(mh_engine* e, long long* pairs, long long* pairs_fp64, int reset)
+{
+    return guarded([&]() -> int {
+    int rc = enter(e);
+    if (rc) return rc;
+    unsigned long long fb = 0;
+    if (e->fb_pairs.p && e->score_pairs > 0) {
+        HIPCHK(hipMemcpyAsync(&fb, e->fb_pairs.p, sizeof(fb), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (pairs) *pairs = e->score_pairs;
+    if (pairs_fp64) *pairs_fp64 = (long long)fb;
+    if (reset) e->score_pairs = 0;                 // (the device counter is cleared by the next scoring call)
     return MH_OK;
     });
 }
@@ -2003,6 +2053,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 11 && (value == 0 || value == 1)) { e->tune_recycle = value; return MH_OK; }
     if (key == 12 && (value == 1 || value == 2)) { e->tune_reduce_launches = value; return MH_OK; }
     if (key == 14 && value >= 0 && value <= 8) { e->inject_barrier_timeouts = value; return MH_OK; }
+    if (key == 15 && (value == 0 || value == 1)) { e->tune_score32 = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -40,8 +40,8 @@ namespace mh {
 // TILED (tuning): R stored tile-major — [model block][point tile][MC][TILE] — so that a workgroup writes one contiguous
 // 128-KiB block per tile instead of MC row segments.
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true>
-__global__ void __launch_bounds__(256)
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
 k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
            const double* __restrict__ x2, const double* __restrict__ y2, int N,
            const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
@@ -288,7 +288,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true>
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0, int swapxy = 0)
@@ -317,7 +317,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     }
     dim3 grid(gx, psplit);
     if (swapxy) grid = dim3(psplit, gx);
-    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI>), grid, dim3(256), 0, s, p.x1, p.y1,
+    hipLaunchKernelGGL((k_residual<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI, MINW>), grid, dim3(256), 0, s, p.x1, p.y1,
                        p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, contiguous ? -psplit : psplit, swapxy,
                        p.xmin, p.xmax, p.ymin, p.ymax);
     return hipGetLastError();
@@ -371,6 +371,19 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     case 31: return launch_rs<4, 16, true, false, false, true, false, false, false, false, true, false, 5>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // lean, sc0 sc1 nt stores
     case 33: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);           // lean + nt, coefficients through the scalar unit (= the product since r03)
     case 34: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true, false, 0, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);  // as the product, but models that are not `far` take the checked sweep
+    case 35: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true, false, 0, true, 8>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // product, registers capped for 8 waves per SIMD
+    case 36: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true, false, 0, true, 7>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // ... 7 waves per SIMD
+    case 37: return launch_rs<6, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                     // product at PPL 6
+    case 38: return launch_rs<2, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                     // product at PPL 2
+    case 39: return launch_rs<4, 32, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                     // product at MC 32
+    case 40: return launch_rs<4, 8, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                      // product at MC 8
+    case 41: return launch_rs<4, 32, true, false, true, true, false, true, false, false, true, false, 0, true, 7>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // MC 32, 7 waves per SIMD
+    case 42: return launch_rs<4, 64, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                      // MC 64
+    case 43: return launch_rs<6, 32, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                      // MC 32, PPL 6
+    case 44: return launch_rs<4, 64, true, false, true, true, false, true, false, false, true, false, 0, true, 7>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // MC 64, 7 waves per SIMD
+    case 45: return launch_rs<4, 32, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, 8);                   // MC 32, 8 point slices
+    case 46: return launch_rs<4, 32, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, 2);                   // MC 32, 2 point slices
+    case 47: return launch_rs<4, 64, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, 8);                   // MC 64, 8 point slices
     case 27: return launch_rs<2, 16, true, false, false, true, false, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // lean, PPL 2
     default: break;
     }

@@ -1718,6 +1718,11 @@ typedef int (*mho_expand_hook)(int N, int L, const int* cost, const int* hit_row
 // seed_of_step(c) = seed ^ 0x4d53 ^ (c << 20) for the c-th MergingStep, the product's convention.
 // Returns the number of models; *iterations = final_iteration_number (:311), *energy = final_energy (0 unless the
 // loop converged, :297).
+// The product's SetFixedIterations (north_star configs[4]: "20 propose-expand iterations" instead of the convergence
+// test): with n > 0 the loop below also stops after its n-th LabelingStep.  0 = the reference's stop rule alone.
+static int g_fixed_iterations = 0;
+MHO_API void mho_set_fixed_iterations(int n) { g_fixed_iterations = n; }
+
 MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1, const double* x2, const double* y2,
                                              const double* aff, int N, double* H, int Nh, int max_models,
                                              const double* F, const double* e2, double lambda, double thr_h,
@@ -1765,7 +1770,8 @@ MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1,
         for (int i = 0; i < N; ++i) labeling[i] = lab[i] - 1;                                 // :547-568
         mho_haf_reestimate(x1, y1, x2, y2, aff, N, labeling, nh, F, e2, models.data(), nullptr);
         const double energy = (double)energy_i;
-        if ((!changed && fabs(last_energy - energy) < 1e-5) || not_changed > 10) {            // :295
+        if ((!changed && fabs(last_energy - energy) < 1e-5) || not_changed > 10 ||            // :295
+            (g_fixed_iterations > 0 && iteration >= g_fixed_iterations)) {
             final_energy = energy;
             break;
         }

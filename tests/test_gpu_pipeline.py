@@ -136,3 +136,58 @@ def test_harness_with_rccl_ranks_equals_the_plain_run(mh, synth, tmp_path):
         outs.append(open(out).read())
     assert outs[0] == outs[1] and len(outs[0].splitlines()) == sc.n
     assert len(set(int(l.split()[-1]) for l in outs[0].splitlines())) >= 3
+
+
+def test_fp32_pretest_score_equals_the_fp64_formula(engine, synth, oracle):
+    """mh_score decides most pairs in FP32 behind a rigorous error bound and only the doubtful ones in FP64
+    (csrc/score32.hip): the counts must be the oracle's for good models, near-miss models, models whose horizon crosses
+    the data and degenerate ones, with and without a point mask — and the pre-test must really carry the load."""
+    sc = synth.make_scene(5000, 4, seed=17, with_neighbours=False)
+    rng = np.random.default_rng(17)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.propose_dlt4(17, 0, 3000)
+    H = np.concatenate([engine.get_models(), sc.H_true, sc.H_true[rng.integers(0, 4, 50)] * (1 + rng.normal(0, 3e-4, (50, 9))),
+                        np.array([[1, 0, 0, 0, 1, 0, 1e-3, -1e-3, 0.0],            # horizon through the image
+                                  [1, 0, 0, 0, 1, 0, 0, 0, 0.0],                   # s == 0 everywhere
+                                  [1e150, 0, 0, 0, 1e150, 0, 0, 0, 1e150],         # outside the FP32 range: all pairs in FP64
+                                  [1e-300, 0, 0, 0, 1e-300, 0, 0, 0, 1e-300],
+                                  [np.nan, 0, 0, 0, 1, 0, 0, 0, 1.0]])])
+    engine.set_models(H)
+    engine.score_stats(reset=True)
+    cnt = engine.score(THR2)
+    pairs, pairs64 = engine.score_stats(reset=True)
+    with np.errstate(all="ignore"):
+        ref = oracle.score(sc.src, sc.dst, H, THR2)
+    assert np.array_equal(cnt, ref), f"{int((cnt != ref).sum())} counts differ"
+    assert pairs == H.shape[0] * sc.n and 0 < pairs64 < 0.02 * pairs, (pairs, pairs64)
+    mask = (rng.random(sc.n) < 0.6).astype(np.uint8)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(engine.score(THR2, mask), oracle.score(sc.src, sc.dst, H, THR2, mask))
+    engine.set_tuning(15, 0)                                  # the FP64 sweep for every pair
+    try:
+        assert np.array_equal(engine.score(THR2), ref)
+        assert engine.score_stats()[0] == 0
+    finally:
+        engine.set_tuning(15, 1)
+
+
+def test_fp32_pretest_with_thresholds_exactly_on_residual_values(engine, synth, oracle):
+    """The strict comparison d2 < thr^2 at its sharpest: thresholds set to a pair's own FP64 residual (that pair is NOT an
+    inlier) and to the next double above it (now it is).  The FP32 pre-test cannot tell such pairs apart — its bound
+    must make it hand them to the FP64 formula."""
+    sc = synth.make_scene(2000, 3, seed=23, noise=1.0, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    H = np.concatenate([sc.H_true, sc.H_true * (1 + np.random.default_rng(1).normal(0, 1e-4, sc.H_true.shape))])
+    engine.set_models(H)
+    R, _ = engine.residual_matrix(THR2)
+    rng = np.random.default_rng(2)
+    tried = 0
+    for m in range(H.shape[0]):
+        near = np.flatnonzero((R[m] > 0.5) & (R[m] < 50.0))
+        for i in rng.choice(near, size=min(6, near.size), replace=False):
+            for thr2 in (R[m, i], np.nextafter(R[m, i], np.inf), np.nextafter(R[m, i], -np.inf)):
+                cnt = engine.score(float(thr2))
+                want = (R < thr2).sum(axis=1)
+                assert np.array_equal(cnt, want), (m, int(i), float(thr2))
+                tried += 1
+    assert tried >= 60
