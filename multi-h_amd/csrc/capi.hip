@@ -167,7 +167,8 @@ struct mh_engine {
     double bbox[4] = { NAN, NAN, NAN, NAN };   // xmin xmax ymin ymax of the source points
     // FP32 pre-test of the score kernels (score32.hip): usable when every coordinate is finite and below 2^20
     bool coords32_ok = false;
-    double absmax_x = NAN, absmax_y = NAN;
+    double absmax_x = NAN, absmax_y = NAN, absmax_dst = NAN;
+    int tune_score32_tiling = 0;               // key 16: points per lane / models per workgroup of the pre-test kernel (schedule only)
     int tune_score32 = 1;                      // mh_set_tuning key 15: 0 = always the FP64 sweep (A/B; counts are equal by construction)
     DevBuf<float> H32;
     DevBuf<unsigned long long> fb_pairs;
@@ -650,8 +651,8 @@ int score_models(mh_engine* e, const Points& p, const double* Hs, int m, double 
         HIPCHK(e->H32.reserve((size_t)m * 16));
         HIPCHK(e->fb_pairs.reserve(1));
         if (e->score_pairs == 0) HIPCHK(hipMemsetAsync(e->fb_pairs.p, 0, sizeof(unsigned long long), e->stream));
-        HIPCHK(launch_model32(Hs, m, e->absmax_x, e->absmax_y, e->H32.p, e->stream));
-        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, dmask, counts_dev, e->fb_pairs.p, e->stream));
+        HIPCHK(launch_model32(Hs, m, e->absmax_x, e->absmax_y, e->absmax_dst, e->H32.p, e->stream));
+        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, dmask, counts_dev, e->fb_pairs.p, e->tune_score32_tiling, e->stream));
         e->score_pairs += (long long)m * p.n;
         return MH_OK;
     }
@@ -844,6 +845,7 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
         e->bbox[0] = xmin; e->bbox[1] = xmax; e->bbox[2] = ymin; e->bbox[3] = ymax;
         e->absmax_x = std::max(std::fabs(xmin), std::fabs(xmax));
         e->absmax_y = std::max(std::fabs(ymin), std::fabs(ymax));
+        e->absmax_dst = dmax;
         e->coords32_ok = finite && dfinite && e->absmax_x < 0x1p20 && e->absmax_y < 0x1p20 && dmax < 0x1p20;
     }
     e->n = n;
@@ -2054,6 +2056,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 12 && (value == 1 || value == 2)) { e->tune_reduce_launches = value; return MH_OK; }
     if (key == 14 && value >= 0 && value <= 8) { e->inject_barrier_timeouts = value; return MH_OK; }
     if (key == 15 && (value == 0 || value == 1)) { e->tune_score32 = value; return MH_OK; }
+    if (key == 16 && value >= 0 && value <= 7) { e->tune_score32_tiling = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -5,6 +5,7 @@
 // multiply-adds, hardware reciprocal: about a third of the FP64 sweep's issue cycles per pair) together with a RIGOROUS
 // bound B on |d2_fp32 - d2_fp64|, decides the pairs for which the bound leaves no doubt
 //         d2_fp32 + B <  thr^2   ->  inlier            d2_fp32 - B >= thr^2   ->  not an inlier
+// (evaluated as |d2_fp32 - thr^2| > B with the sign of the difference telling which)
 // and recomputes the others — pairs within B of the threshold, pairs near a model's horizon, anything that produced a
 // NaN or an infinity on the way — with the FP64 formula in the reference's own operation order.  The result is the count
 // the FP64 kernel (residual.hip) gives; the tests compare the two and put thresholds exactly ON residual values.
@@ -28,18 +29,32 @@
 // only when every coordinate is finite and below 2^20 in magnitude.  A NaN anywhere makes both comparisons false, which
 // also sends the pair to FP64.
 //
+// Most pairs are nowhere near the threshold — a random hypothesis maps a point hundreds of pixels from its match — and
+// for them a much cheaper sufficient test decides "not an inlier" before d2 is even formed.  With w = max(|dx|, |dy|) and
+// Cmax = max |x2|, |y2| over all points: |u| <= Cmax + 1.01 w, so E <= E'|r| + 6.1u Cmax + 0.0177 w with the per-model
+// constant E' = 1.1 (E_n + Cmax E_s) (the term 1.12 w E_s |r| is at most 0.0176 w once sigma >= 64 E_s).  If
+//         sigma >= 64 E_s,     w >= 2.5 thr,     E'|r| + 6.1u Cmax <= 0.08 w
+// then E <= 0.1 w, the true max(|dx|, |dy|) is at least 0.9 w >= 2.25 thr and the true d2 at least 5 thr^2.  When all 64
+// lanes of a wave pass this for a pair, the wave moves on (a wave-uniform branch); otherwise the pair takes the full bound.
+//
+// An FP32 instruction with a scalar-register operand issues in 4 cycles, with vector operands only in 2
+// (tools/ubench/valu_cost.hip), so the per-model constants are staged in LDS once per workgroup and broadcast into
+// VGPRs per model (LDS instructions do not take VALU issue slots).
+//
 // Work split as k_residual: a 256-thread workgroup owns MC = 16 models and sweeps a slice of the points, a lane holds
-// PPL = 4 points; the per-model constants come through the scalar unit (one s_load_dwordx16 per model).
+// PPL = 4 points.
 #include "mh_kernels.hpp"
 #include "mh_device.hpp"
+
+#include <cmath>
 
 namespace mh {
 
 constexpr float U32 = 5.9604644775390625e-08f;       // 2^-24
 
-// per model: 9 coefficients in FP32, then 1.1 E_s, 1.1 E_n, tau = 64 E_s (or +inf: not eligible), 4 pad
+// per model: 9 coefficients in FP32, then 1.1 E_s, 1.1 E_n, tau = 64 E_s (or +inf: not eligible), 12.6 E', 12.6 x 6.1u Cmax, 2 pad
 __global__ void __launch_bounds__(256)
-k_model32(const double* __restrict__ H, int M, double X, double Y, float* __restrict__ out)
+k_model32(const double* __restrict__ H, int M, double X, double Y, double Cmax, float* __restrict__ out)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
@@ -59,74 +74,115 @@ k_model32(const double* __restrict__ H, int M, double X, double Y, float* __rest
     o[9] = (float)(1.1 * es * up);
     o[10] = (float)(1.1 * en * up);
     o[11] = ok ? (float)(64.0 * es * up) : INFINITY;
-    o[12] = o[13] = o[14] = o[15] = 0.f;
+    o[12] = (float)(12.6 * 1.1 * (en + Cmax * es) * up);       // 12.6 E' (12.5 = 1 / 0.08, the rest covers the test's own rounding)
+    o[13] = (float)(12.6 * 6.1 * u * Cmax * up);
+    o[14] = o[15] = 0.f;
 }
 
 template <int PPL, int MC, bool MASK>
 __global__ void __launch_bounds__(256)
 k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
           const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
-          double thr2, float thr2_lo, float thr2_hi, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+          double thr2, float thr2_f, float c_thr, float w_min, int* __restrict__ counts, const unsigned char* __restrict__ mask,
           int psplit, unsigned long long* __restrict__ fallback_pairs)
 {
     constexpr int WAVE_PTS = 64 * PPL, TILE = 4 * WAVE_PTS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * MC;
+    __shared__ float4 s_m[MC * 4];               // this workgroup's rows of the model table
+    for (int i = threadIdx.x; i < MC * 4; i += 256) {
+        const size_t g = (size_t)m0 * 4 + i;
+        s_m[i] = g < (size_t)M * 4 ? reinterpret_cast<const float4*>(H32)[g] : make_float4(0.f, 0.f, 0.f, INFINITY);
+    }
+    __syncthreads();
+    // kernel-argument constants that enter FP32 instructions: VGPR copies, made once
+    float vthr2, vc_thr, vw_min;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vthr2) : "s"(thr2_f));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vc_thr) : "s"(c_thr));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vw_min) : "s"(w_min));
     int cnt = 0;                                 // lane mi of each wave counts model m0 + mi
     unsigned long long fb = 0;                   // pairs this lane sent to FP64 (diagnostic)
     for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
         const int n0 = base + wave * WAVE_PTS + lane * PPL;
-        double px[PPL], py[PPL], qx[PPL], qy[PPL];
+        // only the FP32 copies of the points stay in registers; the rare FP64 decision reloads its point (L2-resident)
         float fx[PPL], fy[PPL], gx[PPL], gy[PPL], cx[PPL];
         unsigned long long okm[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             const int n = n0 + q;
             bool ok = n < N;
-            px[q] = ok ? x1[n] : 1.0; py[q] = ok ? y1[n] : 1.0; qx[q] = ok ? x2[n] : 1.0; qy[q] = ok ? y2[n] : 1.0;
+            const double px = ok ? x1[n] : 1.0, py = ok ? y1[n] : 1.0, qx = ok ? x2[n] : 1.0, qy = ok ? y2[n] : 1.0;
             if (MASK && ok) ok = mask[n] != 0;
             okm[q] = __builtin_amdgcn_ballot_w64(ok);
-            fx[q] = (float)px[q]; fy[q] = (float)py[q]; gx[q] = (float)qx[q]; gy[q] = (float)qy[q];
+            fx[q] = (float)px; fy[q] = (float)py; gx[q] = (float)qx; gy[q] = (float)qy;
             cx[q] = U32 * fmaxf(fabsf(gx[q]), fabsf(gy[q])) * 1.0000002f;
         }
 #pragma unroll 1
         for (int mi = 0; mi < MC; ++mi) {
             const int m = m0 + mi;
             if (m >= M) break;
-            const float* hf = H32 + 16 * (size_t)m;          // uniform address: scalar loads
-            const float h0 = hf[0], h1 = hf[1], h2 = hf[2], h3 = hf[3], h4 = hf[4], h5 = hf[5], h6 = hf[6], h7 = hf[7], h8 = hf[8];
-            const float es = hf[9], en = hf[10], tau = hf[11];
-            int c_m = 0;
+            // broadcast LDS reads: every lane gets the model's constants in VGPRs
+            const float4 ma = s_m[4 * mi], mb = s_m[4 * mi + 1], mc = s_m[4 * mi + 2], md = s_m[4 * mi + 3];
+            const float h0 = ma.x, h1 = ma.y, h2 = ma.z, h3 = ma.w, h4 = mb.x, h5 = mb.y, h6 = mb.z, h7 = mb.w, h8 = mc.x;
+            const float es = mc.y, en = mc.z, tau = mc.w, ebar = md.x, c6 = md.y;
+            // Pass one, all PPL pairs: the cheap test.  Nothing but the PPL lane masks survives it, so it needs few registers.
+            unsigned long long farq[PPL], all_far = ~0ull;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
                 const float s = __builtin_fmaf(h6, fx[q], __builtin_fmaf(h7, fy[q], h8));
                 const float nx = __builtin_fmaf(h0, fx[q], __builtin_fmaf(h1, fy[q], h2));
                 const float ny = __builtin_fmaf(h3, fx[q], __builtin_fmaf(h4, fy[q], h5));
                 const float r = __builtin_amdgcn_rcpf(s);
-                const float uu = nx * r, vv = ny * r;
-                const float dx = gx[q] - uu, dy = gy[q] - vv;
-                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                // the bound (every term >= 0)
-                const float mm = fmaxf(fabsf(uu), fabsf(vv));
-                const float eq = __builtin_fmaf(__builtin_fmaf(mm, es, en), fabsf(r), (5.0f * U32) * mm);
+                const float dx = gx[q] - nx * r, dy = gy[q] - ny * r;
                 const float w = fmaxf(fabsf(dx), fabsf(dy));
-                const float E = __builtin_fmaf(1.01f * U32, w, eq + cx[q]);
-                const float B = __builtin_fmaf(2.2f * U32, d2, (2.02f * E) * __builtin_fmaf(2.0f, w, E));
-                const bool trust = fabsf(s) >= tau;
-                const bool in32 = trust && (d2 + B < thr2_lo);          // thr2_lo <= thr^2 <= thr2_hi: the threshold rounded down / up
-                const bool out32 = trust && (d2 - B >= thr2_hi);
-                bool inl = in32;
-                const bool need = !(in32 || out32);
-                if (__builtin_amdgcn_ballot_w64(need) != 0ull) {          // rare: some lane's pair is too close to call
-                    if (need) {
-                        const double* h = H + 9 * (size_t)m;
-                        const double e2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], px[q], py[q], qx[q], qy[q]);
-                        inl = e2 < thr2;
-                        ++fb;
+                farq[q] = __builtin_amdgcn_ballot_w64(fabsf(s) >= tau) &
+                          __builtin_amdgcn_ballot_w64(w >= fmaxf(__builtin_fmaf(ebar, fabsf(r), c6), vw_min));
+                all_far &= farq[q];
+            }
+            int c_m = 0;
+            if (all_far != ~0ull) {
+                // Pass two, only for the pairs in which some lane is not provably far out: the full bound (the few FP32
+                // operations of pass one are simply done again; this is the rare path)
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if (farq[q] == ~0ull) continue;
+                    asm volatile("; score32: full bound");           // (keeps the two passes' arithmetic apart)
+                    const float s = __builtin_fmaf(h6, fx[q], __builtin_fmaf(h7, fy[q], h8));
+                    const float nx = __builtin_fmaf(h0, fx[q], __builtin_fmaf(h1, fy[q], h2));
+                    const float ny = __builtin_fmaf(h3, fx[q], __builtin_fmaf(h4, fy[q], h5));
+                    const float r = __builtin_amdgcn_rcpf(s);
+                    const float uu = nx * r, vv = ny * r;
+                    const float dx = gx[q] - uu, dy = gy[q] - vv;
+                    const float w = fmaxf(fabsf(dx), fabsf(dy));
+                    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                    // the bound (every term >= 0); B0 = everything but the 2.2u d2 term, which the constant c_thr absorbs: a pair
+                    // decided as inlier has d2 < thr^2, and "d2 - B0 >= thr^2 (1 + 3u)" implies "d2 (1 - 2.2u) - B0 >= thr^2"
+                    const float mm = fmaxf(fabsf(uu), fabsf(vv));
+                    const float eq = __builtin_fmaf(__builtin_fmaf(mm, es, en), fabsf(r), (5.0f * U32) * mm);
+                    const float E = __builtin_fmaf(1.01f * U32, w, eq + cx[q]);
+                    const float B0 = __builtin_fmaf(2.02f * E, __builtin_fmaf(2.0f, w, E), vc_thr);
+                    const float t = d2 - vthr2;
+                    // lane masks straight from the compares; the logic on them is scalar
+                    const unsigned long long trust = __builtin_amdgcn_ballot_w64(fabsf(s) >= tau);
+                    const unsigned long long clear = __builtin_amdgcn_ballot_w64(fabsf(t) > B0);       // (false for NaN)
+                    const unsigned long long below = __builtin_amdgcn_ballot_w64(t < 0.0f);
+                    const unsigned long long decided = (trust & clear) | farq[q];
+                    unsigned long long inl = trust & clear & below;
+                    if (decided != ~0ull) {                               // rarer still: some lane's pair is too close to call
+                        const bool need = ((decided >> lane) & 1ull) == 0ull;
+                        bool in64 = false;
+                        if (need) {
+                            const double* h = H + 9 * (size_t)m;
+                            const int n = n0 + q < N ? n0 + q : N - 1;      // (a padding lane: its result is masked out by okm)
+                            const double e2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
+                            in64 = e2 < thr2;
+                            ++fb;
+                        }
+                        inl |= __builtin_amdgcn_ballot_w64(in64);
                     }
+                    c_m += __builtin_popcountll(inl & okm[q]);
                 }
-                c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(inl) & okm[q]);
             }
             const int c_new = __builtin_amdgcn_readlane(cnt, mi) + c_m;
             asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(c_new), "s"(mi) : "m0");
@@ -148,34 +204,51 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
     }
 }
 
-hipError_t launch_model32(const double* H, int M, double X, double Y, float* H32, hipStream_t s)
+hipError_t launch_model32(const double* H, int M, double X, double Y, double Cmax, float* H32, hipStream_t s)
 {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_model32, dim3((M + 255) / 256), dim3(256), 0, s, H, M, X, Y, H32);
+    hipLaunchKernelGGL(k_model32, dim3((M + 255) / 256), dim3(256), 0, s, H, M, X, Y, Cmax, H32);
     return hipGetLastError();
 }
 
-// H32: the table launch_model32 made for these M models.  fallback_pairs (nullable): device counter of the pairs decided in FP64.
-hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, const unsigned char* mask,
-                          int* counts, unsigned long long* fallback_pairs, hipStream_t s)
+template <int PPL, int MC>
+static hipError_t launch_score32_t(const Points& p, const double* H, const float* H32, int M, double thr2, const unsigned char* mask,
+                                   int* counts, unsigned long long* fallback_pairs, hipStream_t s)
 {
-    if (M <= 0 || p.n <= 0) return hipSuccess;
-    constexpr int PPL = 4, MC = 16;
     const int gx = (M + MC - 1) / MC, ntiles = (p.n + 256 * PPL - 1) / (256 * PPL);
-    int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 32 ? 4 : 1);
+    int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 16 ? 4 : 1);
     if (psplit > ntiles) psplit = ntiles;
     if (psplit < 1) psplit = 1;
     if (psplit > 1) {
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
         if (e != hipSuccess) return e;
     }
-    // the threshold in FP32, rounded towards the side that keeps each test conservative
-    float lo = (float)thr2, hi = lo;
-    if ((double)lo > thr2) lo = nextafterf(lo, -INFINITY);
-    if ((double)hi < thr2) hi = nextafterf(hi, INFINITY);
-    if (mask) hipLaunchKernelGGL((k_score32<PPL, MC, true>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, lo, hi, counts, mask, psplit, fallback_pairs);
-    else hipLaunchKernelGGL((k_score32<PPL, MC, false>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, lo, hi, counts, mask, psplit, fallback_pairs);
+    // the threshold in FP32 and the constant part of the bound: the rounding of the threshold itself (one ulp covers it
+    // either way) plus the 2.2u d2 term for d2 up to thr^2 (1 + 3u) (see the kernel)
+    const float tf = (float)thr2;
+    const float c_thr = (float)(std::fabs((double)tf - thr2) * 1.01 + 3.5 * 5.9604644775390625e-08 * std::fabs(thr2) * 1.01) + 1e-45f;
+    const float w_min = (float)(2.5 * std::sqrt(std::fabs(thr2)) * (1.0 + 1e-6)) + 1e-30f;      // the cheap test's "far from the threshold"
+    if (mask) hipLaunchKernelGGL((k_score32<PPL, MC, true>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, w_min, counts, mask, psplit, fallback_pairs);
+    else hipLaunchKernelGGL((k_score32<PPL, MC, false>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, w_min, counts, mask, psplit, fallback_pairs);
     return hipGetLastError();
+}
+
+// H32: the table launch_model32 made for these M models.  fallback_pairs (nullable): device counter of the pairs decided in
+// FP64.  tiling: points per lane / models per workgroup (a schedule choice; the counts do not depend on it).
+hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, const unsigned char* mask,
+                          int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s)
+{
+    if (M <= 0 || p.n <= 0) return hipSuccess;
+    switch (tiling) {
+    case 1: return launch_score32_t<4, 16>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 2: return launch_score32_t<8, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 3: return launch_score32_t<4, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 4: return launch_score32_t<8, 64>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 5: return launch_score32_t<6, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 6: return launch_score32_t<8, 16>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 7: return launch_score32_t<4, 64>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    default: return launch_score32_t<4, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    }
 }
 
 } // namespace mh

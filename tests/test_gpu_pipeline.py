@@ -163,6 +163,7 @@ def test_fp32_pretest_score_equals_the_fp64_formula(engine, synth, oracle):
     mask = (rng.random(sc.n) < 0.6).astype(np.uint8)
     with np.errstate(all="ignore"):
         assert np.array_equal(engine.score(THR2, mask), oracle.score(sc.src, sc.dst, H, THR2, mask))
+    engine.score_stats(reset=True)
     engine.set_tuning(15, 0)                                  # the FP64 sweep for every pair
     try:
         assert np.array_equal(engine.score(THR2), ref)

@@ -15,8 +15,7 @@ budget = float(os.environ.get("SECONDS", 300))
 rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
 host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
 dp = C.POINTER(C.c_double)
-host.mhh_set_post_filter(0)
-t0 = time.time(); runs = 0; skipped = 0; used_ref_all = True
+t0 = time.time(); runs = 0; tails = 0; removed = 0; dlt_runs = 0; used_ref_all = True
 while time.time() - t0 < budget:
     n = int(rng.integers(600, 4000)); planes = int(rng.integers(2, 6)); seed = int(rng.integers(0, 1 << 30))
     dup, strays = int(rng.integers(0, 5)), int(rng.integers(0, 3))
@@ -24,25 +23,33 @@ while time.time() - t0 < budget:
                              outlier_frac=float(rng.uniform(0.05, 0.5)))
     H0 = _initial_models(sc, seed, dup, strays)
     rowptr, col = _knn_hits(sc, 16)
-    lab_o, H_o, it_o, en_o, used_ref = O.cluster_merging_and_labeling(sc.src, sc.dst, sc.aff, H0, sc.F, sc.e2, LAM, THR, rowptr, col, seed)
-    used_ref_all = used_ref_all and used_ref
-    if H_o.shape[0] <= 1:           # Process() then goes on to the reference's degenerate-case tail (:88-94), which is not part of the loop
-        skipped += 1
-        continue
-    labels = np.full(n, -7, dtype=np.int32); Hout = np.zeros((64, 9)); it, en = C.c_int(-1), C.c_double(-1)
+    # r03: the whole Process() — post-filter (HomographyCompatibilityCheck) on or off, the degenerate tail included, and
+    # either the given initial models or the default route (DLT proposals + greedy selection on the device)
+    post = bool(rng.integers(0, 2))
+    from_dlt = rng.integers(0, 4) == 0
+    hyp = int(rng.integers(500, 3000)) if from_dlt else 0
+    want = O.process(sc.src, sc.dst, sc.aff, sc.F, sc.e2, THR, LOCALITY, LAM, 20, seed, rowptr, col,
+                     init_H=None if from_dlt else H0, init_mode=2 if from_dlt else 0, hypotheses=hyp, max_propose=16, post_filter=post)
+    used_ref_all = used_ref_all and want["used_reference_gco"]
+    tails += int(want["degenerate_tail"]); removed += want["removed_by_filter"]; dlt_runs += int(from_dlt)
+    H_o, lab_o, it_o, en_o = want["H"], want["labels"], want["iterations"], want["energy"]
+    labels = np.full(n, -7, dtype=np.int32); Hout = np.zeros((256, 9)); it, en = C.c_int(-1), C.c_double(-1)
     src, dst, aff, F, e2 = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.aff, sc.F, sc.e2))
+    host.mhh_set_post_filter(1 if post else 0)
     k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n, F.ctypes.data_as(dp),
                              e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(THR), C.c_double(LOCALITY), C.c_double(LAM), 20,
-                             C.c_ulonglong(seed), 0, 0, 0, H0.ctypes.data_as(dp), H0.shape[0],
-                             labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 64, C.byref(it), C.byref(en), None, 0, 4)
+                             C.c_ulonglong(seed), hyp, 16 if from_dlt else 0, 0, None if from_dlt else H0.ctypes.data_as(dp), 0 if from_dlt else H0.shape[0],
+                             labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256, C.byref(it), C.byref(en), None, 0, 4)
     ok = k == H_o.shape[0] and it.value == it_o and en.value == en_o and np.array_equal(labels, lab_o)
     if not ok:
-        print("MISMATCH", dict(n=n, planes=planes, seed=seed, dup=dup, strays=strays, k=k, k_o=H_o.shape[0], it=it.value, it_o=it_o,
-                               en=en.value, en_o=en_o, diff=int((labels != lab_o).sum())))
+        print("MISMATCH", dict(n=n, planes=planes, seed=seed, dup=dup, strays=strays, post=post, from_dlt=from_dlt, hyp=hyp, k=k, k_o=H_o.shape[0],
+                               it=it.value, it_o=it_o, en=en.value, en_o=en_o, diff=int((labels != lab_o).sum())))
         sys.exit(1)
     runs += 1
+host.mhh_set_post_filter(1)
 sys.stdout.flush()
-msg = (f"alternation stress ok: {runs} random scenes ({skipped} more ended with a single model and were skipped) in {time.time() - t0:.0f} s (expansions of the oracle side by the reference GCO: {used_ref_all})")
+msg = (f"Process() stress ok: {runs} random scenes in {time.time() - t0:.0f} s — {dlt_runs} from DLT proposals + greedy selection, {tails} ended in the degenerate tail, "
+       f"the post-filter removed {removed} clusters in all (expansions of the oracle side by the reference GCO: {used_ref_all})")
 print(msg, file=sys.stderr, flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "stress_alternation.txt"), "a").write(msg + "\n")

@@ -8,6 +8,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(double* out, double a
 {
     double x0 = a + threadIdx.x, x1 = a + 1, x2 = a + 2, x3 = a + 3, x4 = a + 4, x5 = a + 5, x6 = a + 6, x7 = a + 7;
     unsigned int u0 = threadIdx.x, u1 = 1, u2 = 2, u3 = 3;
+    float f0 = (float)a + threadIdx.x, f1 = (float)b, f2 = (float)a, f3 = 1.5f, f4 = 2.5f, f5 = 3.5f;
     for (int i = 0; i < iters; ++i) {
 #define REP8(S) S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7)
         if (OP == 0) {
@@ -49,9 +50,36 @@ template <int OP> __global__ void __launch_bounds__(256) k(double* out, double a
         } else if (OP == 12) {
 #define S12(v) asm volatile("v_sqrt_f64 %0, %0" : "+v"(v));
             REP8(S12)
+        } else if (OP == 13) {
+#define S13(v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(f1), "v"(f2));
+            S13(f0) S13(f3) S13(f4) S13(f5) S13(f0) S13(f3) S13(f4) S13(f5)
+        } else if (OP == 14) {
+#define S14(v) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v) : "v"(f1), "v"(f2));
+            S14(f0) S14(f3) S14(f4) S14(f5) S14(f0) S14(f3) S14(f4) S14(f5)
+        } else if (OP == 15) {
+#define S15(v) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(b), "v"(a));
+            REP8(S15)
+        } else if (OP == 16) {
+#define S16(v) asm volatile("v_rcp_f32 %0, %0" : "+v"(v));
+            S16(f0) S16(f3) S16(f4) S16(f5) S16(f0) S16(f3) S16(f4) S16(f5)
+        } else if (OP == 17) {
+#define S17(v) asm volatile("v_max_f32 %0, |%0|, |%1|" : "+v"(v) : "v"(f1));
+            S17(f0) S17(f3) S17(f4) S17(f5) S17(f0) S17(f3) S17(f4) S17(f5)
+        } else if (OP == 18) {
+#define S18(v) asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(v), "v"(f1) : "vcc");
+            S18(f0) S18(f3) S18(f4) S18(f5) S18(f0) S18(f3) S18(f4) S18(f5)
+        } else if (OP == 19) {
+#define S19(v) asm volatile("v_fma_f32 %0, %0, s4, %1" : "+v"(v) : "v"(f2) : "s4");
+            S19(f0) S19(f3) S19(f4) S19(f5) S19(f0) S19(f3) S19(f4) S19(f5)
+        } else if (OP == 20) {
+#define S20(v) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v) : "v"(f1));
+            S20(f0) S20(f3) S20(f4) S20(f5) S20(f0) S20(f3) S20(f4) S20(f5)
+        } else if (OP == 21) {
+#define S21(v) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v) : "v"(b));
+            REP8(S21)
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + u0 + u1 + u2;
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + u0 + u1 + u2 + f0 + f3 + f4 + f5;
 }
 
 template <int OP> int run(const char* name, double* out)
@@ -80,5 +108,8 @@ int main()
     run<4>("v_cmp_lt_f64", out); run<5>("v_div_scale_f64", out); run<6>("v_div_fixup_f64", out);
     run<7>("v_div_fmas_f64", out); run<8>("v_add_u32", out); run<9>("v_alignbit_b32", out);
     run<10>("v_cmp_lt_u32", out); run<11>("v_mov_b32", out); run<12>("v_sqrt_f64", out);
+    run<13>("v_fma_f32", out); run<14>("v_fmac_f32", out); run<15>("v_pk_fma_f32", out); run<16>("v_rcp_f32", out);
+    run<17>("v_max_f32 |a|,|b|", out); run<18>("v_cmp_gt_f32", out); run<19>("v_fma_f32 (sgpr)", out); run<20>("v_mul_f32", out);
+    run<21>("v_pk_mul_f32", out);
     return 0;
 }
