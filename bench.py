@@ -356,14 +356,23 @@ def main():
 
     # Outside the timed region: the store-free fused score kernel on the last batch (SURVEY §8(d)
     # "fused score kernel: not HBM-bound"), reported next to the headline for context.
-    eng.profile_reset()
-    eng.profile_enable(True)
-    for _ in range(5):
+    def time_score():
         eng.score(thr2, fetch=False)
-    eng.synchronize()
-    n_sc, ms_sc = eng.profile_get(2)         # MH_K_SCORE
-    eng.profile_enable(False)
-    fused_ms = ms_sc / max(n_sc, 1)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        for _ in range(5):
+            eng.score(thr2, fetch=False)
+        eng.synchronize()
+        n_sc, ms_sc = eng.profile_get(2)     # MH_K_SCORE
+        eng.profile_enable(False)
+        return ms_sc / max(n_sc, 1)
+
+    eng.set_tuning(15, 0)                    # the FP64 sweep for every pair (k_residual without the stores)
+    fused_ms = time_score()
+    eng.set_tuning(15, 1)                    # the product's score path: FP32 pre-test with a rigorous bound, FP64 for the doubtful pairs
+    eng.score_stats(reset=True)
+    pretest_ms = time_score()
+    pre_pairs, pre_fp64 = eng.score_stats(reset=True)
     # ... and the s = 4 variant of the matrix: the int32 data cost of every hypothesis against every point
     eng.profile_reset()
     eng.profile_enable(True)
@@ -418,7 +427,7 @@ def main():
             "step_ms": {"median": head["step_ms_median"], "min": head["step_ms_min"], "max": head["step_ms_max"],
                         "mean_wall": dt / a.steps * 1e3, "note": "HIP events on the engine's stream at every step boundary"},
             "kernel_ms": {"k_residual": avg_res_ms, "k_dlt4_span_on_the_second_stream": head["dlt_ms"], "k_dlt4_alone": seq["dlt_ms"],
-                          "k_score_fused": fused_ms, "k_cost_matrix_int32": cost_ms},
+                          "k_score_fused_fp64": fused_ms, "k_score_fp32_pretest": pretest_ms, "k_cost_matrix_int32": cost_ms},
             "step_minus_residual_ms": head["step_ms_median"] - avg_res_ms,
             "sequential_form": {"what": "the same steps with the four stages in sequence on one stream (no second stream)",
                                 "value": float(sum(seq["sizes"])) * a.steps / seq["dt"], "ms_per_step": seq["dt"] / a.steps * 1e3,
@@ -426,8 +435,11 @@ def main():
                                 "k_residual_frac_of_hbm_peak": alg_bytes / (seq["res_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "scores_identical": seq["scores_sha256"] == head["scores_sha256"]},
             "transport": transport_kind,
-            "fused_score_hypotheses_per_s_per_gpu": M / (fused_ms * 1e-3),
-            # fused score kernel: FP64-issue bound.  28 rounded FP64 operations per pair (M/MultiH.cpp:434-441 with two IEEE
+            "fused_score_hypotheses_per_s_per_gpu": M / (pretest_ms * 1e-3),
+            "fused_score": {"what": "mh_score on the same batch, no matrix written: FP32 pre-test with a rigorous error bound, FP64 formula only for the "
+                                    "pairs it cannot decide (csrc/score32.hip); counts identical to the FP64 sweep's",
+                            "ms": pretest_ms, "ms_fp64_sweep": fused_ms, "pairs_decided_in_fp64": pre_fp64 / max(pre_pairs, 1)},
+            # fused score kernel, FP64 sweep: FP64-issue bound.  28 rounded FP64 operations per pair (M/MultiH.cpp:434-441 with two IEEE
             # divisions sharing one refined reciprocal) against the chip's FP64 vector issue rate at its 2.4 GHz maximum
             # (256 CUs x 4 SIMDs x 16 lanes per clock = 39.3 T operations/s, i.e. the 78.6 TFLOP/s spec counting an FMA as two)
             "fused_score_fp64": {"ops_per_pair": 28, "ops_per_s": 28.0 * N * M / (fused_ms * 1e-3),
