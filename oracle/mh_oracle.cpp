@@ -26,6 +26,12 @@
 //       definition (Hartley-normalised DLT, one-sided Jacobi null space,
 //       splitmix64 counter RNG); cross-checked with numpy.linalg.svd in tests.
 //
+//   the merge <-> label alternation (section 11), the post-filter HomographyCompatibilityCheck, stable point
+//       sets, the sequential greedy selection and Process() end to end (section 12) : restated from the reference
+//       text; every alpha-expansion inside them can run through the reference's own GCoptimization (oracle/_ref);
+//       "parity unpinned" at rand() (splitmix64 counters instead) and at the OpenCV primitives under the 3-point
+//       solver, the mean shift's summation order (section 8b's engine-order variant) and cv::findHomography.
+//
 // Build:  g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared (oracle/Makefile)
 // -ffp-contract=off matters: the GPU side is compiled the same way so that
 // every FP64 operation rounds once, in the reference's association order.
