@@ -255,24 +255,48 @@ def main():
     keep = []
     if world > 1:
         import ctypes
-        if backend == "nccl":
-            rl = ctypes.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so"))
-            rl.mhr_last_error.restype = ctypes.c_char_p
+        native_ok = False
+        if backend == "nccl" and os.environ.get("MH_BENCH_TRANSPORT", "native") == "native":
+            # every rank takes part in every step of the bootstrap, and the ranks agree on its outcome before anyone
+            # depends on it: a rank that cannot load the library or create the communicator sends all of them to the hook
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            try:
+                rl = ctypes.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so"))
+                rl.mhr_last_error.restype = ctypes.c_char_p
+            except OSError as ex:
+                rl = None
+                status += 1
+                print(f"[bench] rank {rank}: libmultih_rccl.so: {ex}", file=sys.stderr, flush=True)
             uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
+            if rank == 0 and rl is not None:
                 buf = (ctypes.c_ubyte * 128)()
                 if rl.mhr_unique_id(buf) != 0:
-                    raise SystemExit("mhr_unique_id: " + rl.mhr_last_error().decode())
+                    status += 1
+                    print("[bench] mhr_unique_id: " + rl.mhr_last_error().decode(), file=sys.stderr, flush=True)
                 uid = torch.tensor(list(buf), dtype=torch.uint8)
             uid = uid.to(dev)
             dist.broadcast(uid, src=0)
-            raw = (ctypes.c_ubyte * 128)(*uid.cpu().tolist())
-            comm = ctypes.c_void_p()
-            if rl.mhr_init(ctypes.byref(comm), rank, world, raw, local_rank) != 0:
-                raise SystemExit("mhr_init: " + rl.mhr_last_error().decode())
-            eng.set_transport(rank, world, stream_fn=rl.mhr_allgather, ctx=comm)
-            keep += [rl, comm]
-            transport_kind = "native RCCL (ncclAllGather on the engine's stream, libmultih_rccl.so)"
+            dist.all_reduce(status, op=dist.ReduceOp.MAX)
+            if int(status.item()) == 0:
+                raw = (ctypes.c_ubyte * 128)(*uid.cpu().tolist())
+                comm = ctypes.c_void_p()
+                rc = rl.mhr_init(ctypes.byref(comm), rank, world, raw, local_rank)      # collective (ncclCommInitRank)
+                if rc != 0:
+                    print(f"[bench] rank {rank}: mhr_init: " + rl.mhr_last_error().decode(), file=sys.stderr, flush=True)
+                status += 1 if rc != 0 else 0
+                dist.all_reduce(status, op=dist.ReduceOp.MAX)
+                if int(status.item()) == 0:
+                    eng.set_transport(rank, world, stream_fn=rl.mhr_allgather, ctx=comm)
+                    keep += [rl, comm]
+                    transport_kind = "native RCCL (ncclAllGather on the engine's stream, libmultih_rccl.so)"
+                    native_ok = True
+        if native_ok:
+            pass
+        elif backend == "nccl":
+            hook = sharding.make_allgather_hook(world, dev)
+            eng.set_transport(rank, world, host_fn=hook)
+            keep.append(hook)
+            transport_kind = "torch.distributed all_gather_into_tensor over RCCL through the host-synchronised hook (native transport unavailable)"
         else:
             hook = sharding.make_allgather_hook(world, dev)
             eng.set_transport(rank, world, host_fn=hook)

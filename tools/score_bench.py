@@ -10,7 +10,7 @@ sc = mh.synth.make_scene(N, 10, seed=1234, with_neighbours=False)
 e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff)
 e.propose_dlt4(1234, 0, M)
-for tiling in [int(x) for x in os.environ.get("TILINGS", "0,1,2,3,4,5").split(",")]:
+for tiling in [int(x) for x in os.environ.get("TILINGS", "0,1,3,7,9,12,13").split(",")]:
     e.set_tuning(15, 1); e.set_tuning(16, tiling)
     e.score(2.2 ** 2, fetch=False); e.synchronize()
     e.profile_reset(); e.profile_enable(True)
