@@ -253,6 +253,7 @@ def main():
     # host-synchronised torch.distributed hook instead.
     transport_kind = None
     keep = []
+    native_comm = None
     if world > 1:
         import ctypes
         native_ok = False
@@ -288,6 +289,7 @@ def main():
                 if int(status.item()) == 0:
                     eng.set_transport(rank, world, stream_fn=rl.mhr_allgather, ctx=comm)
                     keep += [rl, comm]
+                    native_comm = (rl, comm)
                     transport_kind = "native RCCL (ncclAllGather on the engine's stream, libmultih_rccl.so)"
                     native_ok = True
         if native_ok:
@@ -505,6 +507,9 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     eng.close()
+    if native_comm is not None:
+        torch.cuda.synchronize()
+        native_comm[0].mhr_destroy(native_comm[1])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

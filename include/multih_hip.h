@@ -288,7 +288,8 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow), 12
  * dominance-reduction launches per move (1 or 2), 14 test hook: the first attempts of the next n expansions count as
  * barrier time-outs (exercises the restart with fewer workgroups), 15 the FP32 pre-test of the score kernels (1 on, 0 the
- * FP64 sweep for every pair; the counts are equal by construction).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * FP64 sweep for every pair; the counts are equal by construction), 16 tiling of that pre-test kernel, 17 passes of the
+ * dominance cascade inside the solver launch (0 = to its fixed point).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

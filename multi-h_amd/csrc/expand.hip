@@ -405,7 +405,7 @@ constexpr int SOLVE_THREADS = 512;
 constexpr int SOLVE_ROWS = SOLVE_THREADS / SLPN;
 constexpr int H_SHIFT = 24, H_MASK = (1 << H_SHIFT) - 1, H_EPOCHS = 126;   // height word = (H_EPOCHS - epoch) << 24 | height
 
-struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer; };
+struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer, cascade_iters; };
 
 // Grid barrier with reductions, two levels: the workgroups of one XCD meet on a line of their own, the last
 // arriver of each XCD carries the XCD's reductions to the top line and arrives there, everybody polls the top
@@ -438,7 +438,9 @@ __device__ __forceinline__ bool grid_sync_first(GridBarrier& b)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (b.P == 1) { b.xcds = 1; b.xcd_wgs = 1; return true; }   // a core of at most 64 sites: the workgroup's own barrier is the grid's
+    // a core of at most 64 sites: the workgroup's own barrier is the grid's.  Up to 32 workgroups: the barriers are flat (one
+    // counter, no per-XCD level), so nobody needs the census, and the first barrier of the cascade orders what this one would
+    if (b.P <= 32) { b.xcds = 1; b.xcd_wgs = 1; return true; }
     if (threadIdx.x == 0) {
         b.s_red[6] = 0;
         atomicAdd(&b.flags[C_XCD + b.xcd * C_LINE], 1);
@@ -651,7 +653,11 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
     if (!grid_sync_first(bar)) return;
 
     // ---- phase 0: the reduction cascade to its fixed point (k_reduce's body on the core) -------------
+    int cascade_pass = 0;
     for (;;) {
+        // (a capped cascade ends with a pass that only folds: every verdict taken before it is then folded into its
+        // undecided neighbours, which is what the flow phase relies on — decided sites are not part of its graph)
+        const bool fold_only = sp.cascade_iters > 0 && cascade_pass + 1 >= sp.cascade_iters;
         bool changed = false;
         FOR_MY_SLOTS(slot) {
             enter(slot);
@@ -673,6 +679,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
                 }
                 add = row_sum64<SLPN>(add); out = row_sum64<SLPN>(out); in = row_sum64<SLPN>(in);
                 if (add != 0) { net += add; dirty = true; changed = true; }
+                if (fold_only) break;                 // the capped cascade's last pass: no new verdicts, so none is left unfolded
                 if (net > out) verdict = 1;
                 else if (-net > in) verdict = 2;
                 if (verdict || add == 0) break;       // a round that folded nothing would repeat itself
@@ -690,6 +697,10 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
         int any, nact, hm;
         if (!grid_sync(bar, changed && sub == 0, false, 0, any, nact, hm)) return;
         if (!any || sp.reduce_rounds <= 0) break;
+        // The cascade is exact but optional: a site it would still decide stays in the flow problem, whose read-out gives it
+        // the same side.  A cap trades its barrier-separated passes against a slightly larger flow problem.
+        if (fold_only) break;
+        ++cascade_pass;
     }
 
     // ---- flow recycling: start from what the previous expansion on this label left in the arcs ----------
@@ -1252,7 +1263,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     stats.launches += 1;
     energy = w.h_acc[A_ENERGY];
 
-    SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20 };
+    SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20, w.cascade_iters };
     int solve_grid = w.solve_grid > 0 ? w.solve_grid : 128;
     // slots per solver row for a core of all n sites, and the LDS that holds their scalars
     const int mslots = std::max(1, (g.n + solve_grid * SOLVE_ROWS - 1) / (solve_grid * SOLVE_ROWS));

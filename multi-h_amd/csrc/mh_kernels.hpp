@@ -139,6 +139,7 @@ struct ExpandWork {         // scratch owned by the engine
     int relax_rounds, push_cycles, push_phases, solve_grid, push_mult;
     int reduce_rounds;      // dominance-reduction rounds per launch; 0 switches the reduction off (A/B)
     int reduce_launches;    // reduction launches per move in front of the solver: 2, or 1 (the compacting one alone)
+    int cascade_iters;      // barrier-separated passes of the dominance cascade inside the solver launch (0 = to its fixed point)
     int* trace;             // optional: 8 ints per move {core sites, workgroups, relabels, relax intervals, push phases,
     int trace_moves;        //   barriers, ticks (100 MHz), ticks inside barriers}; moves beyond trace_moves are not traced
     int detail_move;        // move whose global relabels are logged behind the trace (4 ints each, at most 2048): {active sites,

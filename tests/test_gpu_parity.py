@@ -252,6 +252,37 @@ def test_dominance_reduction_changes_nothing(engine, synth, oracle, lam):
         engine.set_params(2.6, THR, 0.005, LAM, 20)
 
 
+def test_capped_dominance_cascade_changes_nothing(engine, synth, oracle):
+    """Inside the solver launch the dominance cascade runs a bounded number of barrier-separated passes (default 2; r03) and
+    ends with a pass that only folds the verdicts taken so far.  The cascade is exact but optional — what it leaves
+    undecided the flow decides the same way — so labels, energy and cycles are the oracle's for every cap, on a k-NN
+    graph and on a dense radius graph, cold and warm."""
+    sc = synth.make_scene(4000, 4, seed=21, noise=1.0, outlier_frac=0.3)
+    H = _models(sc, np.random.default_rng(21), extra=4)
+    _load(engine, sc)
+    engine.set_models(H)
+    cost = engine.data_cost()
+    lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM))
+    init = (sc.gt_label + 1).astype(np.int32)
+    lab_w, e_w, cyc_w, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM), init_labels=init)
+    barriers = {}
+    try:
+        for cap in (0, 1, 2, 3, 7):
+            engine.set_tuning(17, cap)
+            for grid in (256, 3):
+                engine.set_tuning(5, grid)
+                labels, energy, cycles = engine.expand()
+                assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), (cap, grid)
+                if grid == 256:
+                    barriers[cap] = engine.expand_stats()["barriers"]
+                labels, energy, cycles = engine.expand(init)
+                assert energy == e_w and cycles == cyc_w and np.array_equal(labels, lab_w), (cap, grid, "warm")
+    finally:
+        engine.set_tuning(17, 2)
+        engine.set_tuning(5, 256)
+    assert barriers[2] < barriers[0], barriers
+
+
 @pytest.mark.parametrize("case", ["rows_walk_several_sites", "one_workgroup", "degree_above_register_slots", "no_reduction_large_core"])
 def test_expand_solver_paths(engine, synth, oracle, case):
     """The per-move solver launch (csrc/expand.hip k_solve) has several code paths that the default sizes never
@@ -333,6 +364,7 @@ def test_expand_on_a_dense_radius_graph(engine, synth, oracle, lam, grid):
             for reduce_rounds in (2, 0):
                 engine.set_tuning(11, recycle)
                 engine.set_tuning(6, reduce_rounds)
+                engine.set_tuning(17, 0 if recycle else 2)          # cascade to its fixed point / capped (the default)
                 labels, energy, cycles = engine.expand()
                 assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref), (recycle, reduce_rounds)
                 labels, energy, cycles = engine.expand(init)
@@ -342,6 +374,7 @@ def test_expand_on_a_dense_radius_graph(engine, synth, oracle, lam, grid):
         engine.set_tuning(5, 256)
         engine.set_tuning(6, 2)
         engine.set_tuning(11, 1)
+        engine.set_tuning(17, 2)
         engine.set_params(2.6, THR, 0.005, LAM, 20)
 
 

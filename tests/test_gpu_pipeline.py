@@ -108,6 +108,16 @@ def test_native_rccl_transport_on_a_one_rank_communicator(mh, engine, synth, ora
             assert np.array_equal(a, b)
         assert len(plain[1]) >= 4
         assert used == len(via[1]) + 1 + 1, "one score all-gather, then one 88-byte record all-gather per round"
+        # the bench step's exchange: score all-gather + arg-max over the gathered vector (mh_select_best)
+        engine.residual_matrix(THR2, fetch_R=False, fetch_counts=False)
+        before = rl.mhr_calls(comm)
+        best_via = engine.select_best(3001)
+        assert rl.mhr_calls(comm) - before == 1
+        engine.set_transport(0, 1)
+        assert engine.select_best() == best_via
+        cnt_all = engine.score(THR2)
+        assert best_via == (int(np.argmax(cnt_all)), int(cnt_all.max()))
+        engine.set_transport(0, 1, stream_fn=rl.mhr_allgather, ctx=comm)
         H_all, _, _ = oracle.dlt4(sc.src, sc.dst, oracle.sample4(77, 0, 3001, sc.n))
         _, idx_o, cnt_o, mask_o = oracle.select_greedy(sc.src, sc.dst, H_all, THR2, 20, 8)
         assert idx_o.tolist() == via[1].tolist() and cnt_o.tolist() == via[2].tolist() and np.array_equal(mask_o, via[3])

@@ -30,6 +30,7 @@ while time.time() - t0 < budget:
     e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2); e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
     e.set_tuning(5, int(rng.choice([256, 256, 32, 8, 2])))    # solver workgroups: few of them give every solver row several sites
     e.set_tuning(11, int(rng.integers(0, 2)))                 # flow recycling on / off
+    e.set_tuning(17, int(rng.choice([0, 1, 2, 2, 4])))        # passes of the dominance cascade inside the solver launch
     extra = int(rng.integers(0, 6))
     H = np.concatenate([sc.H_true] + [sc.H_true[rng.integers(0, k)][None] * (1 + rng.normal(0, 3e-4, (1, 9))) for _ in range(extra)])
     e.set_models(H)
