@@ -153,25 +153,56 @@ k_argmin_labels(const int* __restrict__ cost, int L, int n, int* __restrict__ la
 constexpr int LPN = 16;
 constexpr int SITES_PER_BLOCK = 256 / LPN;
 
+// Reductions over the W = 8 or 16 consecutive lanes of a site, as DPP moves inside the VALU (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror): a butterfly through ds_bpermute costs an LDS round trip per step, and the solver's push
+// cycle has four of them on its critical path.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ long long dpp_mov64(long long v)
+{
+    const int lo = dpp_mov<CTRL>((int)(unsigned)((unsigned long long)v & 0xffffffffull)), hi = dpp_mov<CTRL>((int)(v >> 32));
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
 template <int W>
 __device__ __forceinline__ int row_min(int v)
 {
-#pragma unroll
-    for (int m = W / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, W); v = o < v ? o : v; }
+    static_assert(W == 8 || W == 16, "a DPP row");
+    int o = dpp_mov<DPP_XOR1>(v); v = o < v ? o : v;
+    o = dpp_mov<DPP_XOR2>(v); v = o < v ? o : v;
+    o = dpp_mov<DPP_HALF_MIRROR>(v); v = o < v ? o : v;
+    if (W == 16) { o = dpp_mov<DPP_MIRROR>(v); v = o < v ? o : v; }
     return v;
 }
 template <int W>
 __device__ __forceinline__ long long row_min64(long long v)
 {
-#pragma unroll
-    for (int m = W / 2; m >= 1; m >>= 1) { const long long o = __shfl_xor(v, m, W); v = o < v ? o : v; }
+    static_assert(W == 8 || W == 16, "a DPP row");
+    long long o = dpp_mov64<DPP_XOR1>(v); v = o < v ? o : v;
+    o = dpp_mov64<DPP_XOR2>(v); v = o < v ? o : v;
+    o = dpp_mov64<DPP_HALF_MIRROR>(v); v = o < v ? o : v;
+    if (W == 16) { o = dpp_mov64<DPP_MIRROR>(v); v = o < v ? o : v; }
     return v;
 }
 template <int W>
 __device__ __forceinline__ long long row_sum64(long long v)
 {
-#pragma unroll
-    for (int m = W / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, W);
+    static_assert(W == 8 || W == 16, "a DPP row");
+    v += dpp_mov64<DPP_XOR1>(v);
+    v += dpp_mov64<DPP_XOR2>(v);
+    v += dpp_mov64<DPP_HALF_MIRROR>(v);
+    if (W == 16) v += dpp_mov64<DPP_MIRROR>(v);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ int row_sum(int v)
+{
+    static_assert(W == 8 || W == 16, "a DPP row");
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    if (W == 16) v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
 
@@ -912,10 +943,11 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
                             r[q] = nb[q] >= 0 ? c0[q] - so[q] + r[q] : 0;
                             if (r[q] > 0 && hq[q] < hu) D += r[q];
                         }
-                        int incl = D;
-#pragma unroll
-                        for (int o = 1; o < SLPN; o <<= 1) { const int y = __shfl_up(incl, o, SLPN); if (sub >= o) incl += y; }
-                        const int tot = __shfl(incl, SLPN - 1, SLPN);
+                        int incl = D;                               // prefix over the row's lanes: row_shr 1, 2, 4
+                        { const int y = dpp_mov<0x111>(incl); if (sub >= 1) incl += y; }
+                        { const int y = dpp_mov<0x112>(incl); if (sub >= 2) incl += y; }
+                        { const int y = dpp_mov<0x114>(incl); if (sub >= 4) incl += y; }
+                        const int tot = row_sum<SLPN>(D);
                         if (tot > 0) {
                             int budget = e - (incl - D);            // the lanes in front of me are served first
                             if (budget > D) budget = D;
