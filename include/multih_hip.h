@@ -182,6 +182,16 @@ MH_API int mh_inliers_of_model(mh_engine* e, int idx, double thr2, int label_val
  * model set is left untouched.  Used by the sharded propose stage, where the winning hypothesis
  * of a round may live on another rank. */
 MH_API int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int label_value, int* labels /* in/out n */);
+/* Trial statistics of HomographyCompatibilityCheck (M/MultiH.cpp:128-196; host/merge_step.cpp ClusterMedian) for
+ * `clusters` clusters of at least 19 points each.  pts_xyxy: the clusters' points back to back in cluster order, 4 doubles
+ * each (x1 y1 x2 y2); cluster_begin[c] .. cluster_begin[c+1] (cluster_begin[0] = 0); per (cluster, trial): tri = the
+ * positions inside the cluster of the 3 points the trial drew (:140-151), H = the trial's 3-point homography (:154,
+ * row-major 9), ok = 0 when that fit failed (all distances then count as NaN -> 1e300).  stats_out: 8 doubles per
+ * (cluster, trial): the order statistics of the N-3 squared transfer errors (:158-173) at ranks k-3 .. k+1, k = (N-3)/2,
+ * then their three largest values ascending — all a trial's "median" (:175-176) can depend on, bit-identical to sorting
+ * on the host.  Independent of the resident correspondences. */
+MH_API int mh_compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                                 const double* H, const unsigned char* ok, int trials, double* stats_out);
 /* ---- multi-GPU transport (one process per GPU, hypotheses sharded, correspondences replicated) ------
  * The reference is a single process; the one exchange north_star adds is an all-gather of per-model inlier scores.
  * The engine calls the transport with DEVICE pointers: send `bytes_per_rank` bytes, receive world * bytes_per_rank in

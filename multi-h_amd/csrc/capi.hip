@@ -86,6 +86,9 @@ struct mh_engine {
     long long ldc = 0;
     DevBuf<unsigned char> mask;
     DevBuf<double> moments, min_eig;
+    DevBuf<double> cp_pts, cp_H, cp_out;     // mh_compat_trial_stats staging
+    DevBuf<int> cp_begin, cp_tri;
+    DevBuf<unsigned char> cp_ok;
     // greedy selection (select.hip): two candidate lists, control words, exchange buffers
     DevBuf<int> sel_orig[2], sel_counts, sel_rec, sel_scores, sel_gathered;
     DevBuf<double> sel_cand_H[2], sel_out_H;
@@ -731,6 +734,7 @@ void mh_destroy(mh_engine* e)
     e->d_rowptr.release(); e->d_col.release(); e->d_w.release(); e->d_rev.release();
     e->H.release(); e->samples.release(); e->counts.release(); e->R.release(); e->C.release(); e->mask.release();
     e->moments.release(); e->min_eig.release();
+    e->cp_pts.release(); e->cp_H.release(); e->cp_out.release(); e->cp_begin.release(); e->cp_tri.release(); e->cp_ok.release();
     e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
     e->fund_inl.release(); e->fund_mask.release(); e->ref_keep.release(); e->ref_in.release(); e->ref_out.release();
     e->loc_H.release(); e->loc_feat.release(); e->ms_data.release(); e->ms_mean.release();
@@ -1805,6 +1809,40 @@ int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, int lab
     HIPCHK(hipMemcpyAsync(e->labels_pts.p, labels, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
     HIPCHK(launch_inliers_of_model(e->pts(), e->H_one.p, 0, thr2, label_value, e->labels_pts.p, e->stream));
     HIPCHK(hipMemcpyAsync(labels, e->labels_pts.p, sizeof(int) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+    });
+}
+
+int mh_compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                          const double* H, const unsigned char* ok, int trials, double* stats_out)
+{
+    return guarded([&]() -> int {
+    if (!e) return fail(MH_ERR_INVALID, "null engine");
+    if (clusters < 0 || trials < 0) return fail(MH_ERR_INVALID, "negative cluster or trial count");
+    if (clusters == 0 || trials == 0) return MH_OK;
+    if (!pts_xyxy || !cluster_begin || !tri || !H || !ok || !stats_out) return fail(MH_ERR_INVALID, "null argument");
+    if (cluster_begin[0] != 0) return fail(MH_ERR_INVALID, "cluster_begin[0] must be 0");
+    for (int c = 0; c < clusters; ++c)
+        if (cluster_begin[c + 1] - cluster_begin[c] < 19)
+            return fail(MH_ERR_INVALID, "a cluster of fewer than 19 points: the caller handles those itself (the three stale entries of the reference's buffer reach the median ranks)");
+    const size_t total = (size_t)cluster_begin[clusters], ct = (size_t)clusters * (size_t)trials;
+    if (ct > (size_t)0x7fffffff) return fail(MH_ERR_INVALID, "too many trials");
+    for (size_t i = 0; i < ct; ++i) {
+        const int nc = cluster_begin[i / trials + 1] - cluster_begin[i / trials];
+        for (int j = 0; j < 3; ++j)
+            if (tri[3 * i + j] < 0 || tri[3 * i + j] >= nc) return fail(MH_ERR_INVALID, "a trial draws a point outside its cluster");
+    }
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(e->cp_pts.reserve(4 * total)); HIPCHK(e->cp_begin.reserve(clusters + 1)); HIPCHK(e->cp_tri.reserve(3 * ct));
+    HIPCHK(e->cp_H.reserve(9 * ct)); HIPCHK(e->cp_ok.reserve(ct)); HIPCHK(e->cp_out.reserve(8 * ct));
+    HIPCHK(hipMemcpyAsync(e->cp_pts.p, pts_xyxy, sizeof(double) * 4 * total, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->cp_begin.p, cluster_begin, sizeof(int) * (clusters + 1), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->cp_tri.p, tri, sizeof(int) * 3 * ct, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->cp_H.p, H, sizeof(double) * 9 * ct, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->cp_ok.p, ok, ct, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(launch_compat_select(e->cp_pts.p, e->cp_begin.p, clusters, e->cp_tri.p, e->cp_H.p, e->cp_ok.p, trials, e->cp_out.p, e->stream));
+    HIPCHK(hipMemcpyAsync(stats_out, e->cp_out.p, sizeof(double) * 8 * ct, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
     });

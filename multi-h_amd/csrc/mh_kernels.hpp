@@ -48,6 +48,11 @@ hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, do
 hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,
                           double* min_eig, hipStream_t s);
 
+// --- compat.hip: order statistics of the post-filter's trials (HomographyCompatibilityCheck, M/MultiH.cpp:128-196)
+hipError_t launch_compat_select(const double* pts /* total x 4 */, const int* begin /* clusters + 1 */, int clusters,
+                                const int* tri /* clusters x trials x 3 */, const double* H /* clusters x trials x 9 */,
+                                const unsigned char* ok, int trials, double* out /* clusters x trials x 8 */, hipStream_t s);
+
 // --- dlt4.hip ---------------------------------------------------------------
 hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,
                        int* idx_out, double* H_out, hipStream_t s);

@@ -227,7 +227,9 @@ bool MultiH::Process()
     if (cluster_homographies.size() > 1 && run_compatibility_check) {        // :78-86
         const int before = static_cast<int>(cluster_homographies.size());
         auto t0 = std::chrono::system_clock::now();
+        post_filter_failed = false;
         HomographyCompatibilityCheck();
+        if (post_filter_failed) return false;                                // the engine refused: no host fallback
         std::chrono::duration<double> el = std::chrono::system_clock::now() - t0;
         printf("[Multi-H] Compatibility check time = %f secs (%d clusters removed from %d)\n", el.count(),
                before - (int)cluster_homographies.size(), before);
@@ -256,9 +258,20 @@ void MultiH::HomographyCompatibilityCheck()
         const double* p = reinterpret_cast<const double*>(cluster_homographies[i].data);
         for (int k = 0; k < 9; ++k) H[9 * (size_t)i + k] = p[k];
     }
+    // the trials' order statistics come from the engine (csrc/compat.hip); the fits, the replay of the draws and the
+    // reference's stale-buffer bookkeeping are host work (merge_step.cpp)
+    multih::CompatStatsFn on_engine;
+    if (engine)
+        on_engine = [this](const double* pts, const int* begin, int clusters, const int* tri, const double* Ht,
+                           const unsigned char* ok, int trials, double* out) {
+            return Check(mh_compat_trial_stats(engine, pts, begin, clusters, tri, Ht, ok, trials, out), "mh_compat_trial_stats");
+        };
+    bool failed = false;
     const int kept = multih::CompatibilityCheck(s.data(), d.data(), N, labeling.data(), H.data(), nh,
                                                 fundamental_matrix, sqr_threshold_homography,
-                                                minimum_inlier_number, proposal_seed ^ 0xc0117a7ull);
+                                                minimum_inlier_number, proposal_seed ^ 0xc0117a7ull, nullptr,
+                                                engine ? &on_engine : nullptr, &failed);
+    if (failed) { post_filter_failed = true; return; }
     cluster_homographies.clear();
     for (int i = 0; i < kept; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
 }
@@ -665,6 +678,22 @@ void mhh_set_neighbour_max_hits(long long max_hits) { g_max_hits = max_hits; }
 static std::vector<std::pair<int, int>> g_tuning;
 extern "C" __attribute__((visibility("default")))
 void mhh_set_engine_tuning(int key, int value) { if (key < 0) g_tuning.clear(); else g_tuning.emplace_back(key, value); }
+
+// multih::CompatibilityCheck with the trials' order statistics from an engine (mh_compat_trial_stats), as Process() runs
+// it, returning the per-cluster median-of-medians too; -1 if the engine fails.  For the GPU tests.
+extern "C" __attribute__((visibility("default")))
+int mhh_compatibility_medians_on_engine(mh_engine* engine, const double* src_xy, const double* dst_xy, int n, int* labels, double* H,
+                                        int nh, const double* F, double sqr_thr, int min_inliers, unsigned long long seed,
+                                        double* medians)
+{
+    multih::CompatStatsFn fn = [engine](const double* pts, const int* begin, int clusters, const int* tri, const double* Ht,
+                                        const unsigned char* ok, int trials, double* out) {
+        return mh_compat_trial_stats(engine, pts, begin, clusters, tri, Ht, ok, trials, out) == MH_OK;
+    };
+    bool failed = false;
+    const int kept = multih::CompatibilityCheck(src_xy, dst_xy, n, labels, H, nh, F, sqr_thr, min_inliers, seed, medians, &fn, &failed);
+    return failed ? -1 : kept;
+}
 
 // ---- C hook for the GPU-side integration test (ctypes; plain arrays in/out) ----------------
 extern "C" __attribute__((visibility("default")))

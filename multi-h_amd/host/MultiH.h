@@ -63,7 +63,8 @@ public:
     double GetHomographyThreshold() { return threshold_homography; }
     // M/MultiH.h:71, M/MultiH.cpp:314-350: a filled circle per labelled correspondence, colour by plane.
     void DrawClusters(cv::Mat& img1, cv::Mat& img2, int size);
-    // Post-filter of the reference (M/MultiH.cpp:100-222), host-side (multih::CompatibilityCheck).
+    // Post-filter of the reference (M/MultiH.cpp:100-222): multih::CompatibilityCheck with the trials' order statistics
+    // from the engine (mh_compat_trial_stats).
     void HomographyCompatibilityCheck();
 
     // ---- extension points: outputs of the reference's OpenCV front half ----
@@ -170,6 +171,7 @@ protected:
     int fundamental_hypotheses = 4000;
     int init_mode = INIT_DLT;
     bool run_compatibility_check = true;
+    bool post_filter_failed = false;             // the engine's part of HomographyCompatibilityCheck returned an error
     uint64_t merge_rng_counter = 0;
     double loop_seconds = 0.0;
     std::vector<cv::Mat> initial_homographies;

@@ -448,73 +448,104 @@ void TrialSelect(std::vector<double>& dist, TrialStats& out)
     out.top[0] = dist[hi + 3]; out.top[1] = dist[hi + 2]; out.top[2] = dist[hi + 1];
 }
 
-// Median-of-medians of one cluster (:128-194).  sx/dx: the cluster's points (x,y pairs) in label order.
-double ClusterMedian(const std::vector<double>& sx, const std::vector<double>& dx, const double F[9],
-                     uint64_t seed, uint64_t& counter)
+// Which three points every trial of one cluster draws (:140-151, :180-189): positions in the cluster's original order.
+// The reference erases from and appends to a vector; only "the idx-th point still in the list" and "append" are needed,
+// so the list is a Fenwick tree over N + 3 * trials slots (erase = find the idx-th live slot, O(log N)) — the vector's
+// 1 503 erases cost 5 ms on a 37 000-point scene.
+std::vector<int> ReplayDraws(int N, int trials, uint64_t seed, uint64_t& counter)
 {
-    const int trials = 501;                                    // MAX(501, MIN(501, ...)), :128
-    const int N = (int)(sx.size() / 2);
-    const int rest = N - 3;
-    std::vector<double> distances(trials);
-
-    // (1) which three points each trial draws: positions in the current order, erased one by one
-    std::vector<int> order(N);
-    for (int i = 0; i < N; ++i) order[i] = i;
+    const int cap = N + 3 * trials;
+    int top = 1;
+    while (top * 2 <= cap) top *= 2;
+    std::vector<int> fen(cap + 1, 0), val(cap, 0);
+    auto add = [&](int slot, int d) { for (int i = slot + 1; i <= cap; i += i & -i) fen[i] += d; };
+    for (int i = 0; i < N; ++i) { val[i] = i; }
+    for (int i = 1; i <= cap; ++i) {                                  // linear build: N live slots in front
+        fen[i] += i <= N ? 1 : 0;
+        const int j = i + (i & -i);
+        if (j <= cap) fen[j] += fen[i];
+    }
+    auto kth = [&](int k) {                                           // slot of the k-th live entry, k from 0
+        int pos = 0, left = k + 1;
+        for (int step = top; step > 0; step >>= 1)
+            if (pos + step <= cap && fen[pos + step] < left) { pos += step; left -= fen[pos]; }
+        return pos;                                                   // 0-based slot
+    };
     std::vector<int> tri(3 * (size_t)trials);
+    int live = N, next = N;
     for (int t = 0; t < trials; ++t) {
         for (int j = 0; j < 3; ++j) {
             const double u = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
-            const int cur = (int)order.size();
-            const int idx = (int)((cur - 1) * u);                             // :142
-            tri[3 * (size_t)t + j] = order[idx];
-            order.erase(order.begin() + idx);                                 // :149-150
+            const int idx = (int)((live - 1) * u);                    // :142
+            const int slot = kth(idx);
+            tri[3 * (size_t)t + j] = val[slot];
+            add(slot, -1);                                            // :149-150
+            --live;
         }
-        for (int j = 2; j >= 0; --j) order.push_back(0);                      // :180-189: sample j returns to slot N-j-1
-        for (int j = 0; j < 3; ++j) order[N - j - 1] = tri[3 * (size_t)t + j];
+        for (int j = 2; j >= 0; --j) {                                // :180-189: sample j returns to slot N-j-1
+            val[next] = tri[3 * (size_t)t + j];
+            add(next, +1);
+            ++next; ++live;
+        }
     }
+    return tri;
+}
 
-    if (rest < 16) {
-        // tiny cluster: the literal buffer semantics
-        std::vector<double> dist(N, 0.0);
-        for (int t = 0; t < trials; ++t) {
-            TrialDistances(sx, dx, &tri[3 * (size_t)t], F, dist.data());      // first N-3 entries
-            std::sort(dist.begin(), dist.end());                              // all N entries, 3 of them stale (:175)
-            distances[t] = (rest % 2) ? dist[rest / 2] : 0.5 * (dist[rest / 2] + dist[rest / 2 + 1]);   // :176
-        }
-    } else {
-        // (2) per-trial statistics, independent of each other
-        std::vector<TrialStats> st(trials);
-        unsigned nthreads = std::thread::hardware_concurrency();
-        if (nthreads == 0) nthreads = 1;
-        if (nthreads > 32) nthreads = 32;
-        if ((size_t)N * trials < 200000) nthreads = 1;
-        std::atomic<int> next(0);
-        auto work = [&]() {
-            std::vector<double> buf(rest);
-            for (;;) {
-                const int t = next.fetch_add(1);
-                if (t >= trials) break;
-                TrialDistances(sx, dx, &tri[3 * (size_t)t], F, buf.data());
-                TrialSelect(buf, st[t]);
-            }
-        };
-        if (nthreads == 1) work();
-        else {
-            std::vector<std::thread> pool;
-            for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(work);
-            for (auto& th : pool) th.join();
-        }
-        // (3) thread the three stale entries through the trials
-        double stale[3] = { 0.0, 0.0, 0.0 };
-        for (int t = 0; t < trials; ++t) {
-            double u[8] = { st[t].mid[0], st[t].mid[1], st[t].mid[2], st[t].mid[3], st[t].mid[4],
-                            stale[0], stale[1], stale[2] };
-            std::sort(u, u + 8);
-            distances[t] = (rest % 2) ? u[3] : 0.5 * (u[3] + u[4]);           // ranks rest/2 and rest/2+1 of the union
-            double v[6] = { st[t].top[0], st[t].top[1], st[t].top[2], stale[0], stale[1], stale[2] };
-            std::sort(v, v + 6);
-            stale[0] = v[3]; stale[1] = v[4]; stale[2] = v[5];
-        }
+// The 3-point homography of one trial (:154, do_numerical_refinement = false).
+bool TrialHomography(const std::vector<double>& sx, const std::vector<double>& dx, const int* tri, const double F[9], double Hc[9])
+{
+    double ms[6], md[6];
+    for (int j = 0; j < 3; ++j) {
+        ms[2 * j] = sx[2 * tri[j]]; ms[2 * j + 1] = sx[2 * tri[j] + 1];
+        md[2 * j] = dx[2 * tri[j]]; md[2 * j + 1] = dx[2 * tri[j] + 1];
+    }
+    return Homography3PTLinear(ms, md, 3, F, Hc);
+}
+
+// `work(i)` for i in [0, count) on the host's cores.
+template <typename Fn>
+void ParallelFor(int count, size_t cost, Fn work)
+{
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 32) nthreads = 32;
+    if (cost < 200000) nthreads = 1;
+    std::atomic<int> next(0);
+    auto loop = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= count) break; work(i); } };
+    if (nthreads == 1) { loop(); return; }
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(loop);
+    for (auto& th : pool) th.join();
+}
+
+// The literal buffer semantics, for clusters so small that the three stale entries reach the median ranks (rest < 16).
+double TinyClusterMedian(const std::vector<double>& sx, const std::vector<double>& dx, const std::vector<int>& tri,
+                         const double F[9], int trials)
+{
+    const int N = (int)(sx.size() / 2), rest = N - 3;
+    std::vector<double> distances(trials), dist(N, 0.0);
+    for (int t = 0; t < trials; ++t) {
+        TrialDistances(sx, dx, &tri[3 * (size_t)t], F, dist.data());          // first N-3 entries
+        std::sort(dist.begin(), dist.end());                                  // all N entries, 3 of them stale (:175)
+        distances[t] = (rest % 2) ? dist[rest / 2] : 0.5 * (dist[rest / 2] + dist[rest / 2 + 1]);   // :176
+    }
+    std::sort(distances.begin(), distances.end());
+    return trials % 2 ? distances[trials / 2] : 0.5 * (distances[trials / 2] + distances[trials / 2 + 1]);   // :193
+}
+
+// (3) of the header: thread the three stale entries through the trials, then the median of the trials' medians (:193).
+double MedianFromStats(const TrialStats* st, int rest, int trials)
+{
+    std::vector<double> distances(trials);
+    double stale[3] = { 0.0, 0.0, 0.0 };
+    for (int t = 0; t < trials; ++t) {
+        double u[8] = { st[t].mid[0], st[t].mid[1], st[t].mid[2], st[t].mid[3], st[t].mid[4],
+                        stale[0], stale[1], stale[2] };
+        std::sort(u, u + 8);
+        distances[t] = (rest % 2) ? u[3] : 0.5 * (u[3] + u[4]);               // ranks rest/2 and rest/2+1 of the union
+        double v[6] = { st[t].top[0], st[t].top[1], st[t].top[2], stale[0], stale[1], stale[2] };
+        std::sort(v, v + 6);
+        stale[0] = v[3]; stale[1] = v[4]; stale[2] = v[5];
     }
     std::sort(distances.begin(), distances.end());
     return trials % 2 ? distances[trials / 2] : 0.5 * (distances[trials / 2] + distances[trials / 2 + 1]);   // :193
@@ -522,9 +553,14 @@ double ClusterMedian(const std::vector<double>& sx, const std::vector<double>& d
 
 } // namespace
 
+static_assert(sizeof(TrialStats) == 8 * sizeof(double), "the statistics travel as 8 doubles per trial");
+
 int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
-                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed, double* medians)
+                       const double F[9], double sqr_thr, int min_inliers, uint64_t seed, double* medians,
+                       const CompatStatsFn* stats_fn, bool* failed)
 {
+    const int trials = 501;                                               // MAX(501, MIN(501, ...)), :128
+    if (failed) *failed = false;
     std::vector<std::vector<double>> src(nh), dst(nh);
     for (int i = 0; i < n; ++i) {
         const int l = labels[i];
@@ -533,18 +569,65 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
             dst[l].push_back(dst_xy[2 * i]); dst[l].push_back(dst_xy[2 * i + 1]);
         }
     }
-    std::vector<char> remove(nh, 0);
+    std::vector<char> remove(nh, 0), has_median(nh, 0);
+    std::vector<double> median(nh, std::nan(""));
+    // (1) the draws of every cluster that gets a median, in cluster order (one RNG counter runs through them)
+    std::vector<std::vector<int>> tri(nh);
+    std::vector<int> big;                                                 // clusters whose trials go through the order statistics
     uint64_t counter = 0;
     for (int c = 0; c < nh; ++c) {
         const int N = (int)(src[c].size() / 2);
-        if (medians) medians[c] = std::nan("");
         if (N >= std::max(min_inliers, 4)) {
-            const double median = ClusterMedian(src[c], dst[c], F, seed, counter);
-            if (medians) medians[c] = median;
-            remove[c] = median > sqr_thr * 81.0 / 16.0;                       // :195
+            tri[c] = ReplayDraws(N, trials, seed, counter);
+            has_median[c] = 1;
+            if (N - 3 < 16) median[c] = TinyClusterMedian(src[c], dst[c], tri[c], F, trials);
+            else big.push_back(c);
         } else if (N < min_inliers) {
-            remove[c] = 1;                                                    // :199-200
+            remove[c] = 1;                                                // :199-200
         }
+    }
+    // (2) per trial, independent of each other: the 3-point fit, then the order statistics of its distances
+    if (!big.empty()) {
+        const int nb = (int)big.size();
+        std::vector<TrialStats> st((size_t)nb * trials);
+        if (stats_fn && *stats_fn) {
+            std::vector<int> begin(nb + 1, 0);
+            for (int b = 0; b < nb; ++b) begin[b + 1] = begin[b] + (int)(src[big[b]].size() / 2);
+            std::vector<double> pts(4 * (size_t)begin[nb]), Ht(9 * (size_t)nb * trials);
+            std::vector<int> tr(3 * (size_t)nb * trials);
+            std::vector<unsigned char> ok((size_t)nb * trials);
+            for (int b = 0; b < nb; ++b) {
+                const std::vector<double>&sx = src[big[b]], &dx = dst[big[b]];
+                double* q = &pts[4 * (size_t)begin[b]];
+                for (size_t i = 0; i < sx.size() / 2; ++i) { q[4 * i] = sx[2 * i]; q[4 * i + 1] = sx[2 * i + 1]; q[4 * i + 2] = dx[2 * i]; q[4 * i + 3] = dx[2 * i + 1]; }
+                std::copy(tri[big[b]].begin(), tri[big[b]].end(), tr.begin() + 3 * (size_t)b * trials);
+            }
+            ParallelFor(nb * trials, (size_t)nb * trials * 400, [&](int i) {
+                const int b = i / trials, t = i % trials;
+                ok[i] = TrialHomography(src[big[b]], dst[big[b]], &tri[big[b]][3 * (size_t)t], F, &Ht[9 * (size_t)i]) ? 1 : 0;
+                if (!ok[i]) for (int k = 0; k < 9; ++k) Ht[9 * (size_t)i + k] = 0.0;
+            });
+            if (!(*stats_fn)(pts.data(), begin.data(), nb, tr.data(), Ht.data(), ok.data(), trials, reinterpret_cast<double*>(st.data()))) {
+                if (failed) *failed = true;
+                return nh;
+            }
+        } else {
+            size_t cost = 0;
+            for (int c : big) cost += src[c].size() / 2 * (size_t)trials;
+            ParallelFor(nb * trials, cost, [&](int i) {
+                const int b = i / trials, t = i % trials;
+                static thread_local std::vector<double> buf;
+                buf.resize(src[big[b]].size() / 2 - 3);
+                TrialDistances(src[big[b]], dst[big[b]], &tri[big[b]][3 * (size_t)t], F, buf.data());
+                TrialSelect(buf, st[i]);
+            });
+        }
+        for (int b = 0; b < nb; ++b)
+            median[big[b]] = MedianFromStats(&st[(size_t)b * trials], (int)(src[big[b]].size() / 2) - 3, trials);
+    }
+    for (int c = 0; c < nh; ++c) {
+        if (medians) medians[c] = median[c];
+        if (has_median[c]) remove[c] = median[c] > sqr_thr * 81.0 / 16.0;  // :195
     }
     int kept = nh;
     for (int c = nh - 1; c >= 0; --c) {                                       // :208-221

@@ -4,6 +4,7 @@
 // N x Nh scoring they feed is done by the GPU engine.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace multih {
@@ -52,8 +53,15 @@ bool Homography3PT(const double* pts1, const double* pts2, int n, const double F
 // buffer keeps N entries, the last three of them stale from the previous trial (:136,:175).
 // rand() (:142) is replaced by the engine's splitmix64 counter RNG.
 // labels: in/out (-1..nh-1); H: nh x 9 in, compacted in place; returns the new model count.
+// stats_fn (optional): where the trials' order statistics are computed for the clusters of at least 19 points — the
+// engine's mh_compat_trial_stats (same arguments; returns false on failure, reported through *failed with the labels
+// and H untouched).  Without it they are computed here on the host's cores; the 3-point fits, the replay of the draws
+// and the threading of the reference's three stale buffer entries through the trials stay on the host either way.
+using CompatStatsFn = std::function<bool(const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                                         const double* H, const unsigned char* ok, int trials, double* stats_out)>;
 int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
                        const double F[9], double sqr_thr, int min_inliers, uint64_t seed,
-                       double* medians = nullptr /* nh, optional: per-cluster median-of-medians */);
+                       double* medians = nullptr /* nh, optional: per-cluster median-of-medians */,
+                       const CompatStatsFn* stats_fn = nullptr, bool* failed = nullptr);
 
 } // namespace multih

@@ -106,6 +106,12 @@ int mh_inliers_of_homography(mh_engine* e, const double*, double, int label, int
     for (int i = 0; i < e->n; ++i) if (i % 2) labels[i] = label;
     return MH_OK;
 }
+int mh_compat_trial_stats(mh_engine*, const double*, const int*, int clusters, const int*, const double*, const unsigned char*, int trials,
+                          double* out)
+{
+    for (long long i = 0; i < 8ll * clusters * trials; ++i) out[i] = 0.0;      // every cluster looks compatible
+    return MH_OK;
+}
 int mh_inlier_moments(mh_engine* e, double, double* mom, double* mineig)
 {
     for (int j = 0; j < e->m; ++j) { for (int q = 0; q < 6; ++q) mom[6 * j + q] = 20.0; mineig[j] = 1.0; }

@@ -49,7 +49,7 @@ def test_host_library_exports_class_hooks(mh, engine_lib):
     assert os.path.exists(host), "host layer not built"
     lib = ctypes.CDLL(host)
     for s in ("mhh_run_process", "mhh_mean_shift", "mhh_homography_3pt", "mhh_homography_3pt_refined",
-              "mhh_compatibility_check", "mhh_homography_features", "mhh_set_sharding", "mhh_set_sharding_stream", "mhh_set_device",
+              "mhh_compatibility_check", "mhh_compatibility_medians_on_engine", "mhh_homography_features", "mhh_set_sharding", "mhh_set_sharding_stream", "mhh_set_device",
               "mhh_set_neighbourhood", "mhh_set_post_filter", "mhh_set_engine_tuning"):
         assert hasattr(lib, s)
     out = subprocess.run(["nm", "-DC", "--defined-only", host], capture_output=True, text=True).stdout

@@ -239,6 +239,9 @@ def test_dominance_reduction_changes_nothing(engine, synth, oracle, lam):
         cost = engine.data_cost()
         lab_ref, e_ref, cyc_ref, _ = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(lam))
         got = {}
+        # (the cascade inside the solver launch to its fixed point: with the default cap of two passes WHICH sites those
+        # passes decide depends on the order the rows run in, and with it the count compared at the end)
+        engine.set_tuning(17, 0)
         for rounds in (0, 1, 4):
             engine.set_tuning(6, rounds)
             labels, energy, cycles = engine.expand()
@@ -248,6 +251,7 @@ def test_dominance_reduction_changes_nothing(engine, synth, oracle, lam):
             got[rounds] = st
         assert got[4]["flow_moves"] <= got[0]["flow_moves"]
     finally:
+        engine.set_tuning(17, 2)
         engine.set_tuning(6, 2)
         engine.set_params(2.6, THR, 0.005, LAM, 20)
 

@@ -19,4 +19,4 @@ ITER_HYP=100000 python tools/loop_bench.py > gpurun_out/ev/loop_reproposal.txt 2
 SECONDS=150 SEED=3 python tools/stress_parity.py > gpurun_out/ev/stress_parity.txt 2>&1
 SECONDS=200 SEED=3 python tools/stress_alternation.py > gpurun_out/ev/stress_process.txt 2>&1
 SECONDS=60 python tools/stress_residual_edges.py > gpurun_out/ev/stress_residual_edges.txt 2>&1
-tail -3 gpurun_out/ev/tests.log gpurun_out/ev/stress_parity.txt gpurun_out/ev/stress_process.txt gpurun_out/ev/stress_residual_edges.txt
+tail -n 3 gpurun_out/ev/tests.log gpurun_out/ev/stress_parity.txt gpurun_out/ev/stress_process.txt gpurun_out/ev/stress_residual_edges.txt
