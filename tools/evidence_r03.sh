@@ -10,7 +10,7 @@ bash tools/profile_bench.sh r03 $SHA > gpurun_out/ev/profile_bench.log 2>&1
 MH_LIB=multi-h_amd/libmultih_hip_tuning.so RV=32,20,22,34,0,3,10,7 OUT=ev/energy.json python tools/energy_probe.py > gpurun_out/ev/energy.log 2>&1
 python tools/score_bench.py > gpurun_out/ev/score_bench.txt 2>&1
 CPU=1 python tools/label_bench.py > gpurun_out/ev/label_bench.txt 2>&1
-bash tools/profile_label.sh r03_label > gpurun_out/ev/profile_label.log 2>&1
+bash tools/profile_label.sh r03_label $SHA > gpurun_out/ev/profile_label.log 2>&1
 python tools/cascade_sweep.py > gpurun_out/ev/cascade_sweep.txt 2>&1
 MULTIH_TIMING=1 python tools/small_scene_bench.py > gpurun_out/ev/small_scenes.txt 2>&1
 MULTIH_TIMING=1 python tools/loop_bench.py > gpurun_out/ev/loop_timing.txt 2>&1
