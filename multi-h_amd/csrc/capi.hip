@@ -651,12 +651,12 @@ void host_jacobi3(double* a, double* v, double* d)
 int score_models(mh_engine* e, const Points& p, const double* Hs, int m, double thr2, const unsigned char* dmask, int* counts_dev)
 {
     const bool fwd = e->residual_mode != MH_RESIDUAL_SYMMETRIC;
-    if (fwd && e->tune_score32 && e->tune_score_variant == 0 && e->coords32_ok && m > 0) {
+    if (fwd && e->tune_score32 && e->tune_score_variant == 0 && e->coords32_ok && m > 0 && thr2 >= 0x1p-40 && thr2 <= 0x1p40) {
         HIPCHK(e->H32.reserve((size_t)m * 16));
         HIPCHK(e->fb_pairs.reserve(1));
         if (e->score_pairs == 0) HIPCHK(hipMemsetAsync(e->fb_pairs.p, 0, sizeof(unsigned long long), e->stream));
         HIPCHK(launch_model32(Hs, m, e->absmax_x, e->absmax_y, e->absmax_dst, e->H32.p, e->stream));
-        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, dmask, counts_dev, e->fb_pairs.p, e->tune_score32_tiling, e->stream));
+        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, e->absmax_dst, dmask, counts_dev, e->fb_pairs.p, e->tune_score32_tiling, e->stream));
         e->score_pairs += (long long)m * p.n;
         return MH_OK;
     }

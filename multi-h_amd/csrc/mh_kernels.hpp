@@ -41,7 +41,8 @@ hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
                         const unsigned char* mask, int* counts, int variant, hipStream_t s);
 // --- score32.hip: the same counts through an FP32 pre-test with a rigorous error bound (FP64 only for the pairs it cannot decide)
 hipError_t launch_model32(const double* H, int M, double X, double Y, double Cmax, float* H32 /* M x 16 */, hipStream_t s);
-hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, const unsigned char* mask,
+// Cmax: the bound on |x2|, |y2| the table was made with; thr2 in [2^-40, 2^40]
+hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                           int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s);
 hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
                                    int label_value, int* labels, hipStream_t s);

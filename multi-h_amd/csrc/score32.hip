@@ -25,17 +25,26 @@
 // roundings, no fma): less than 2^-27 B32.  B = 1.01 B32 covers that and the rounding of the bound's own evaluation (a
 // dozen FP32 operations, every term non-negative).  Models or points outside the magnitudes for which "relative error
 // u per operation" holds (overflow, underflow to subnormals) are not eligible: a model with a coefficient >= 2^100, not
-// finite, or with E_s or E_n below 2^-80 gets tau = +inf and all its pairs go to FP64; the launcher uses this kernel
+// finite, or with E_s or E_n below 2^-80 gets tau = NaN (every comparison against it is false) and all its pairs go to FP64; the launcher uses this kernel
 // only when every coordinate is finite and below 2^20 in magnitude.  A NaN anywhere makes both comparisons false, which
 // also sends the pair to FP64.
 //
 // Most pairs are nowhere near the threshold — a random hypothesis maps a point hundreds of pixels from its match — and
-// for them a much cheaper sufficient test decides "not an inlier" before d2 is even formed.  With w = max(|dx|, |dy|) and
-// Cmax = max |x2|, |y2| over all points: |u| <= Cmax + 1.01 w, so E <= E'|r| + 6.1u Cmax + 0.0177 w with the per-model
-// constant E' = 1.1 (E_n + Cmax E_s) (the term 1.12 w E_s |r| is at most 0.0176 w once sigma >= 64 E_s).  If
-//         sigma >= 64 E_s,     w >= 2.5 thr,     E'|r| + 6.1u Cmax <= 0.08 w
-// then E <= 0.1 w, the true max(|dx|, |dy|) is at least 0.9 w >= 2.25 thr and the true d2 at least 5 thr^2.  When all 64
-// lanes of a wave pass this for a pair, the wave moves on (a wave-uniform branch); otherwise the pair takes the full bound.
+// for them a much cheaper sufficient test decides "not an inlier" before d2, or even a quotient, is formed.  It works on
+//         Wx = x2 s - nx = s dx,     Wy = y2 s - ny = s dy          (one fma each; no reciprocal)
+// With Cmax = max |x2|, |y2| over all points, the computed Wx^ = fl(x2~ s~ - nx~) satisfies
+//         |Wx^ - Wx| <= Cmax (1+u) E_s + E_n + u Cmax |s| + 1.01u |Wx^|         (s~, nx~ as above, x2~ = fl32(x2), the fma's rounding)
+// so with the per-model constant A = 1.01 (Cmax E_s + E_n) and W^ = max(|Wx^|, |Wy^|), if
+//         sigma >= 64 E_s,     W^ >= 2.5 thr sigma,     W^ >= 25 A,     W^ >= 25.4 u Cmax sigma
+// then (|s| <= 65/64 sigma) the true max(|dx|, |dy|) = max(|Wx|, |Wy|) / |s| is at least
+//         W^ (1 - 1.01u - 0.04 - 0.04) / (65/64 sigma) >= 0.905 W^ / sigma >= 2.26 thr
+// and the true d2 at least 5 thr^2.  The second and fourth condition are one comparison against k1 sigma with the
+// per-launch constant k1 = max(2.5 thr, 25.4 u Cmax) (rounded up); the third against the per-model constant 25.2 A.
+// Products cannot overflow: eligible models have |h6| X + |h7| Y + |h8| and both numerators' sums below 2^100 and
+// coordinates are below 2^20; they do not underflow into the subnormals either where it matters: W^ >= k1 sigma with
+// sigma >= 2^-74 (E_s >= 2^-80) and thr^2 >= 2^-40 (the launcher's precondition) is a normal number.  When all 64 lanes
+// of a wave pass this for a pair, the wave moves on (a wave-uniform branch); otherwise the pair takes the full bound.
+// (Until late r03 this test was formed on the quotient, with a reciprocal and two multiplies more per pair.)
 //
 // An FP32 instruction with a scalar-register operand issues in 4 cycles, with vector operands only in 2
 // (tools/ubench/valu_cost.hip), so the per-model constants are staged in LDS once per workgroup and broadcast into
@@ -52,7 +61,7 @@ namespace mh {
 
 constexpr float U32 = 5.9604644775390625e-08f;       // 2^-24
 
-// per model: 9 coefficients in FP32, then 1.1 E_s, 1.1 E_n, tau = 64 E_s (or +inf: not eligible), 12.6 E', 12.6 x 6.1u Cmax, 2 pad
+// per model: 9 coefficients in FP32, then 1.1 E_s, 1.1 E_n, tau = 64 E_s (or NaN: not eligible), 25.2 A (the cheap test), 3 pad
 __global__ void __launch_bounds__(256)
 k_model32(const double* __restrict__ H, int M, double X, double Y, double Cmax, float* __restrict__ out)
 {
@@ -69,21 +78,20 @@ k_model32(const double* __restrict__ H, int M, double X, double Y, double Cmax, 
     const double as = fabs(h[6]) * X + fabs(h[7]) * Y + fabs(h[8]);
     const double an = fmax(fabs(h[0]) * X + fabs(h[1]) * Y + fabs(h[2]), fabs(h[3]) * X + fabs(h[4]) * Y + fabs(h[5]));
     const double es = 5.0 * u * as, en = 5.0 * u * an;
-    ok = ok && es >= 0x1p-80 && en >= 0x1p-80 && es < 0x1p100 && en < 0x1p100;
+    ok = ok && es >= 0x1p-80 && en >= 0x1p-80 && as < 0x1p100 && an < 0x1p100;     // (as, an bound every product formed from this model)
     const double up = 1.0 + 0x1p-22;                  // round the bounds UP on their way to FP32
     o[9] = (float)(1.1 * es * up);
     o[10] = (float)(1.1 * en * up);
-    o[11] = ok ? (float)(64.0 * es * up) : INFINITY;
-    o[12] = (float)(12.6 * 1.1 * (en + Cmax * es) * up);       // 12.6 E' (12.5 = 1 / 0.08, the rest covers the test's own rounding)
-    o[13] = (float)(12.6 * 6.1 * u * Cmax * up);
-    o[14] = o[15] = 0.f;
+    o[11] = ok ? (float)(64.0 * es * up) : NAN;        // NaN, not +inf: an overflowed |s| = inf must not pass "|s| >= tau"
+    o[12] = (float)(25.2 * 1.01 * (Cmax * es + en) * up);      // 25.2 A (25 = 1 / 0.04, the rest covers the test's own rounding)
+    o[13] = o[14] = o[15] = 0.f;
 }
 
 template <int PPL, int MC, bool MASK, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW)
 k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
           const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
-          double thr2, float thr2_f, float c_thr, float w_min, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+          double thr2, float thr2_f, float c_thr, float k1, int* __restrict__ counts, const unsigned char* __restrict__ mask,
           int psplit, unsigned long long* __restrict__ fallback_pairs)
 {
     constexpr int WAVE_PTS = 64 * PPL, TILE = 4 * WAVE_PTS;
@@ -93,14 +101,14 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
     __shared__ float4 s_m[MC * 4];               // this workgroup's rows of the model table
     for (int i = threadIdx.x; i < MC * 4; i += 256) {
         const size_t g = (size_t)m0 * 4 + i;
-        s_m[i] = g < (size_t)M * 4 ? reinterpret_cast<const float4*>(H32)[g] : make_float4(0.f, 0.f, 0.f, INFINITY);
+        s_m[i] = g < (size_t)M * 4 ? reinterpret_cast<const float4*>(H32)[g] : make_float4(0.f, 0.f, 0.f, NAN);
     }
     __syncthreads();
     // kernel-argument constants that enter FP32 instructions: VGPR copies, made once
-    float vthr2, vc_thr, vw_min;
+    float vthr2, vc_thr, vk1;
     asm volatile("v_mov_b32 %0, %1" : "=v"(vthr2) : "s"(thr2_f));
     asm volatile("v_mov_b32 %0, %1" : "=v"(vc_thr) : "s"(c_thr));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(vw_min) : "s"(w_min));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vk1) : "s"(k1));
     int cnt = 0;                                 // lane mi of each wave counts model m0 + mi
     unsigned long long fb = 0;                   // pairs this lane sent to FP64 (diagnostic)
     for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
@@ -125,7 +133,7 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
             // broadcast LDS reads: every lane gets the model's constants in VGPRs
             const float4 ma = s_m[4 * mi], mb = s_m[4 * mi + 1], mc = s_m[4 * mi + 2], md = s_m[4 * mi + 3];
             const float h0 = ma.x, h1 = ma.y, h2 = ma.z, h3 = ma.w, h4 = mb.x, h5 = mb.y, h6 = mb.z, h7 = mb.w, h8 = mc.x;
-            const float es = mc.y, en = mc.z, tau = mc.w, ebar = md.x, c6 = md.y;
+            const float es = mc.y, en = mc.z, tau = mc.w, a25 = md.x;
             // Pass one, all PPL pairs: the cheap test.  Nothing but the PPL lane masks survives it, so it needs few registers.
             unsigned long long farq[PPL], all_far = ~0ull;
 #pragma unroll
@@ -133,11 +141,10 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
                 const float s = __builtin_fmaf(h6, fx[q], __builtin_fmaf(h7, fy[q], h8));
                 const float nx = __builtin_fmaf(h0, fx[q], __builtin_fmaf(h1, fy[q], h2));
                 const float ny = __builtin_fmaf(h3, fx[q], __builtin_fmaf(h4, fy[q], h5));
-                const float r = __builtin_amdgcn_rcpf(s);
-                const float dx = gx[q] - nx * r, dy = gy[q] - ny * r;
-                const float w = fmaxf(fabsf(dx), fabsf(dy));
+                const float wx = __builtin_fmaf(gx[q], s, -nx), wy = __builtin_fmaf(gy[q], s, -ny);      // s dx, s dy
+                const float W = fmaxf(fabsf(wx), fabsf(wy));
                 farq[q] = __builtin_amdgcn_ballot_w64(fabsf(s) >= tau) &
-                          __builtin_amdgcn_ballot_w64(w >= fmaxf(__builtin_fmaf(ebar, fabsf(r), c6), vw_min));
+                          __builtin_amdgcn_ballot_w64(W >= fmaxf(vk1 * fabsf(s), a25));
                 all_far &= farq[q];
             }
             int c_m = 0;
@@ -212,7 +219,7 @@ hipError_t launch_model32(const double* H, int M, double X, double Y, double Cma
 }
 
 template <int PPL, int MC, int MINW = 1>
-static hipError_t launch_score32_t(const Points& p, const double* H, const float* H32, int M, double thr2, const unsigned char* mask,
+static hipError_t launch_score32_t(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                                    int* counts, unsigned long long* fallback_pairs, hipStream_t s)
 {
     const int gx = (M + MC - 1) / MC, ntiles = (p.n + 256 * PPL - 1) / (256 * PPL);
@@ -227,34 +234,35 @@ static hipError_t launch_score32_t(const Points& p, const double* H, const float
     // either way) plus the 2.2u d2 term for d2 up to thr^2 (1 + 3u) (see the kernel)
     const float tf = (float)thr2;
     const float c_thr = (float)(std::fabs((double)tf - thr2) * 1.01 + 3.5 * 5.9604644775390625e-08 * std::fabs(thr2) * 1.01) + 1e-45f;
-    const float w_min = (float)(2.5 * std::sqrt(std::fabs(thr2)) * (1.0 + 1e-6)) + 1e-30f;      // the cheap test's "far from the threshold"
-    if (mask) hipLaunchKernelGGL((k_score32<PPL, MC, true, MINW>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, w_min, counts, mask, psplit, fallback_pairs);
-    else hipLaunchKernelGGL((k_score32<PPL, MC, false, MINW>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, w_min, counts, mask, psplit, fallback_pairs);
+    // the cheap test's k1 = max(2.5 thr, 25.4 u Cmax), rounded up (the product k1 sigma is rounded once more in the kernel)
+    const float k1 = (float)(std::fmax(2.5 * std::sqrt(std::fabs(thr2)), 25.4 * 5.9604644775390625e-08 * Cmax) * (1.0 + 1e-6)) + 1e-30f;
+    if (mask) hipLaunchKernelGGL((k_score32<PPL, MC, true, MINW>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, k1, counts, mask, psplit, fallback_pairs);
+    else hipLaunchKernelGGL((k_score32<PPL, MC, false, MINW>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, k1, counts, mask, psplit, fallback_pairs);
     return hipGetLastError();
 }
 
 // H32: the table launch_model32 made for these M models.  fallback_pairs (nullable): device counter of the pairs decided in
 // FP64.  tiling: points per lane / models per workgroup (a schedule choice; the counts do not depend on it).
-hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, const unsigned char* mask,
+hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                           int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     switch (tiling) {
-    case 1: return launch_score32_t<4, 16>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 2: return launch_score32_t<8, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 3: return launch_score32_t<4, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 4: return launch_score32_t<8, 64>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 5: return launch_score32_t<6, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 6: return launch_score32_t<8, 16>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 7: return launch_score32_t<4, 64>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 8: return launch_score32_t<4, 32, 5>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 9: return launch_score32_t<4, 32, 6>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 10: return launch_score32_t<4, 32, 8>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 11: return launch_score32_t<2, 32, 8>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 12: return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
-    case 13: return launch_score32_t<4, 32>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    case 1: return launch_score32_t<4, 16>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 2: return launch_score32_t<8, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 3: return launch_score32_t<4, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 4: return launch_score32_t<8, 64>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 5: return launch_score32_t<6, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 6: return launch_score32_t<8, 16>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 7: return launch_score32_t<4, 64>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 8: return launch_score32_t<4, 32, 5>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 9: return launch_score32_t<4, 32, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 10: return launch_score32_t<4, 32, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 11: return launch_score32_t<2, 32, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 12: return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 13: return launch_score32_t<4, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     // 4 points per lane, 32 models per workgroup, registers capped at 96 for five waves per SIMD (2.59 against 3.00 ms uncapped)
-    default: return launch_score32_t<4, 32, 5>(p, H, H32, M, thr2, mask, counts, fallback_pairs, s);
+    default: return launch_score32_t<4, 32, 5>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     }
 }
 

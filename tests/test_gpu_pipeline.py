@@ -182,6 +182,33 @@ def test_fp32_pretest_score_equals_the_fp64_formula(engine, synth, oracle):
         engine.set_tuning(15, 1)
 
 
+def test_fp32_pretest_when_the_fp32_denominator_overflows(engine, oracle):
+    """Models whose denominator overflows (or is not representable) in FP32 while the FP64 formula finds inliers: every
+    point is mapped next to the origin, where the matches sit.  The pre-test's cheap test works on s (x2 - u), which is
+    infinite there — such models must not be eligible for it at all (found by tools/stress_residual_edges.py when the
+    cheap test lost its reciprocal: |s| = inf passed "|s| >= tau" with tau = +inf)."""
+    rng = np.random.default_rng(3)
+    n = 700
+    src = rng.uniform(0, 1000, (n, 2))
+    dst = rng.uniform(-1.2, 1.2, (n, 2))
+    dst[::7] = rng.uniform(-40, 40, (dst[::7].shape[0], 2))                  # some matches far from the origin
+    H = np.array([[0, 0, 1, 0, 0, 1, 0, 0, 1e90],                            # u = v = 1e-90
+                  [0, 0, 1, 0, 0, 1, 3e35, 3e35, 1e35],                      # finite in FP32, the sum is not
+                  [1e-3, 0, 0.5, 0, 1e-3, -0.5, 1e36, 1e36, 1e36],
+                  [0, 0, 19.58, 0, 0, 7.9e89, 0.44, -1.2e-136, 1.003e90],    # the stress tool's case, v = 0.79
+                  [0, 0, 1, 0, 0, 1, 0, 0, 1e29],                            # still eligible: below 2^100
+                  [0, 0, 1, 0, 0, 1, 0, 0, 2e30]])                           # just above
+    engine.set_correspondences(src, dst)
+    engine.set_models(H)
+    engine.score_stats(reset=True)
+    cnt = engine.score(THR2)
+    pairs, pairs64 = engine.score_stats(reset=True)
+    with np.errstate(all="ignore"):
+        ref = oracle.score(src, dst, H, THR2)
+    assert pairs == H.shape[0] * n, "the pre-test kernel should have run (coordinates are in its range)"
+    assert np.array_equal(cnt, ref) and (ref > n // 2).all(), (cnt, ref)
+
+
 def test_fp32_pretest_with_thresholds_exactly_on_residual_values(engine, synth, oracle):
     """The strict comparison d2 < thr^2 at its sharpest: thresholds set to a pair's own FP64 residual (that pair is NOT an
     inlier) and to the next double above it (now it is).  The FP32 pre-test cannot tell such pairs apart — its bound
