@@ -2095,7 +2095,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 12 && (value == 1 || value == 2)) { e->tune_reduce_launches = value; return MH_OK; }
     if (key == 14 && value >= 0 && value <= 8) { e->inject_barrier_timeouts = value; return MH_OK; }
     if (key == 15 && (value == 0 || value == 1)) { e->tune_score32 = value; return MH_OK; }
-    if (key == 16 && value >= 0 && value <= 13) { e->tune_score32_tiling = value; return MH_OK; }
+    if (key == 16 && value >= 0 && value <= 16) { e->tune_score32_tiling = value; return MH_OK; }
     if (key == 17 && value >= 0 && value <= 1000) { e->tune_cascade_iters = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });

@@ -50,8 +50,8 @@
 // (tools/ubench/valu_cost.hip), so the per-model constants are staged in LDS once per workgroup and broadcast into
 // VGPRs per model (LDS instructions do not take VALU issue slots).
 //
-// Work split as k_residual: a 256-thread workgroup owns MC = 16 models and sweeps a slice of the points, a lane holds
-// PPL = 4 points.
+// Work split as k_residual: a 256-thread workgroup owns MC models (64 by default) and sweeps a slice of the points, a lane
+// holds PPL = 4 points.
 #include "mh_kernels.hpp"
 #include "mh_device.hpp"
 
@@ -261,8 +261,11 @@ hipError_t launch_score32(const Points& p, const double* H, const float* H32, in
     case 11: return launch_score32_t<2, 32, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     case 12: return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     case 13: return launch_score32_t<4, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
-    // 4 points per lane, 32 models per workgroup, registers capped at 96 for five waves per SIMD (2.59 against 3.00 ms uncapped)
-    default: return launch_score32_t<4, 32, 5>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 14: return launch_score32_t<4, 64, 5>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 15: return launch_score32_t<4, 64, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    case 16: return launch_score32_t<2, 64, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    // 4 points per lane, 64 models per workgroup, registers capped at 80 for six waves per SIMD (2.20 ms; <4, 32, 5> 2.26, uncapped 2.51)
+    default: return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     }
 }
 
