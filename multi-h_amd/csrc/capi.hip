@@ -1461,7 +1461,13 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
     HIPCHK(e->counts.reserve(e->m));
     {
         ScopedTimer t(e, MH_K_COSTMATRIX);
-        HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, e->thr_H * e->thr_H, e->C.p, e->ldc, e->counts.p, e->stream));
+        const double thr2 = e->thr_H * e->thr_H;
+        if (e->tune_score32 && e->coords32_ok && thr2 >= 0x1p-40 && thr2 <= 0x1p40) {      // the FP32 pre-test (score32.hip); same matrix
+            HIPCHK(e->H32.reserve((size_t)e->m * 16));
+            HIPCHK(launch_model32(e->H.p, e->m, e->absmax_x, e->absmax_y, e->absmax_dst, e->H32.p, e->stream));
+            HIPCHK(launch_cost32(e->pts(), e->H.p, e->H32.p, e->m, e->lambda, thr2, e->absmax_dst, e->C.p, e->ldc, e->counts.p, e->stream));
+        } else
+            HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, thr2, e->C.p, e->ldc, e->counts.p, e->stream));
     }
     if (C_host)
         HIPCHK(hipMemcpy2DAsync(C_host, sizeof(int) * e->n, e->C.p, sizeof(int) * e->ldc, sizeof(int) * e->n, e->m,

@@ -48,6 +48,8 @@ k_data_cost(const double* __restrict__ x1, const double* __restrict__ y1,
 // row.  Arithmetic: the shared-reciprocal division of the residual sweep for d2 (bit-identical to `/`), the
 // compiler's IEEE division for d2 / T, C round() — per pair about twice the FP64 work of the residual kernel for half
 // the bytes, so this kernel is FP64-issue bound, not HBM bound; its HBM fraction is reported for completeness.
+// (mh_cost_matrix runs k_cost32 of score32.hip instead — the same matrix behind an FP32 pre-test — wherever that kernel's
+// preconditions hold; this one remains for the other inputs and as its A/B partner, mh_set_tuning key 15.)
 // ---------------------------------------------------------------------------
 template <int MC>
 __global__ void __launch_bounds__(256)

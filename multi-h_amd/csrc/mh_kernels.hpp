@@ -44,6 +44,9 @@ hipError_t launch_model32(const double* H, int M, double X, double Y, double Cma
 // Cmax: the bound on |x2|, |y2| the table was made with; thr2 in [2^-40, 2^40]
 hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                           int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s);
+// the materialised int32 cost matrix (launch_cost_matrix, datacost.hip) through the same pre-test; H32 made with the same Cmax
+hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
+                         int* C, long long ldc, int* counts, hipStream_t s);
 hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
                                    int label_value, int* labels, hipStream_t s);
 hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,

@@ -211,6 +211,160 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_cost32 — the materialised int32 data-cost matrix (k_cost_matrix of datacost.hip: the s = 4 variant of SURVEY 8(d))
+// behind the same pre-test.  dataEnergy (M/MultiH.cpp:473-504) of a pair whose d2 is at least T = thr^2 81/16 is the
+// constant 2 round(lam T), and for a random hypothesis that is nearly every pair: the cheap test above with
+// k1 = max(2.5 x 9/4 thr, 25.4 u Cmax) proves max(|dx|, |dy|) >= 2.26 x 9/4 thr, i.e. d2 >= 5 T, per LANE; the other
+// lanes (both |dx| and |dy| within a dozen pixels, models not eligible for FP32, NaN anywhere) evaluate the reference's
+// FP64 formula — fwd_d2, the IEEE division d2 / T, C round() — exactly as k_cost_matrix does.  Same matrix, same fused
+// inlier counts, bit for bit.  Measured at 50k x 100k DLT hypotheses: 7.7 -> 5.0 ms (the store stream alone would take 3.6 ms:
+// 3.3 % of the pairs of such a batch are near — hypotheses fitted to four matches are often nearly right for a whole
+// plane — and 42 % of the wave-model iterations contain one, each costing a pass through the IEEE formula).
+// ---------------------------------------------------------------------------
+template <int MC, int MINW>
+__global__ void __launch_bounds__(256, MINW)
+k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+         const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+         double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit)
+{
+    constexpr int PPL = 4, WAVE_PTS = 64 * PPL, TILE = 4 * WAVE_PTS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * MC;
+    __shared__ float4 s_m[MC * 4];
+    __shared__ double s_h[MC * 9];               // the FP64 coefficients, for the lanes that need the reference's formula
+    __shared__ double s_p[4 * PPL * 4 * 64];     // [wave][point of the lane][x1 y1 x2 y2][lane]: every lane's own points in FP64
+    for (int i = threadIdx.x; i < MC * 4; i += 256) {
+        const size_t g = (size_t)m0 * 4 + i;
+        s_m[i] = g < (size_t)M * 4 ? reinterpret_cast<const float4*>(H32)[g] : make_float4(0.f, 0.f, 0.f, NAN);
+    }
+    for (int i = threadIdx.x; i < MC * 9; i += 256) {
+        const size_t g = (size_t)m0 * 9 + i;
+        s_h[i] = g < (size_t)M * 9 ? H[g] : 0.0;
+    }
+    __syncthreads();
+    double* wave_p = s_p + (size_t)wave * (PPL * 4 * 64);           // + (q * 4 + component) * 64 + lane
+    double* my_p = wave_p + lane;
+    __shared__ unsigned short s_list[4 * 64 * PPL];                 // per wave: the (point slot, lane) of the pairs that need FP64
+    __shared__ int s_c[4 * 64 * PPL];                               // per wave: their costs, on the way back to the owning lane
+    unsigned short* my_list = s_list + wave * (64 * PPL);
+    int* my_c = s_c + wave * (64 * PPL);
+    float vk1;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vk1) : "s"(k1));
+    const int beyond = 2 * (int)round(lam * T);
+    int cnt = 0;                                 // lane mi of each wave counts model m0 + mi
+    for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
+        const int base_n = base + wave * WAVE_PTS;
+        const int n0 = base_n + lane * PPL;
+        float fx[PPL], fy[PPL], gx[PPL], gy[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int n = n0 + q;
+            const bool ok = n < N;
+            const double px = ok ? x1[n] : 1.0, py = ok ? y1[n] : 1.0, qx = ok ? x2[n] : 1.0, qy = ok ? y2[n] : 1.0;
+            my_p[(q * 4 + 0) * 64] = px; my_p[(q * 4 + 1) * 64] = py; my_p[(q * 4 + 2) * 64] = qx; my_p[(q * 4 + 3) * 64] = qy;
+            fx[q] = (float)px; fy[q] = (float)py; gx[q] = (float)qx; gy[q] = (float)qy;
+        }
+#pragma unroll 1
+        for (int mi = 0; mi < MC; ++mi) {
+            const int m = m0 + mi;
+            if (m >= M) break;
+            const float4 ma = s_m[4 * mi], mb = s_m[4 * mi + 1], mc = s_m[4 * mi + 2], md = s_m[4 * mi + 3];
+            const float h0 = ma.x, h1 = ma.y, h2 = ma.z, h3 = ma.w, h4 = mb.x, h5 = mb.y, h6 = mb.z, h7 = mb.w, h8 = mc.x;
+            const float tau = mc.w, a25 = md.x;
+            int c[PPL];
+            unsigned long long nearq[PPL], any_near = 0ull;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const float s = __builtin_fmaf(h6, fx[q], __builtin_fmaf(h7, fy[q], h8));
+                const float nx = __builtin_fmaf(h0, fx[q], __builtin_fmaf(h1, fy[q], h2));
+                const float ny = __builtin_fmaf(h3, fx[q], __builtin_fmaf(h4, fy[q], h5));
+                const float wx = __builtin_fmaf(gx[q], s, -nx), wy = __builtin_fmaf(gy[q], s, -ny);
+                const float W = fmaxf(fabsf(wx), fabsf(wy));
+                nearq[q] = ~(__builtin_amdgcn_ballot_w64(fabsf(s) >= tau) &
+                             __builtin_amdgcn_ballot_w64(W >= fmaxf(vk1 * fabsf(s), a25)));
+                any_near |= nearq[q];
+                c[q] = beyond;
+            }
+            int c_m = 0;
+            if (any_near) {
+                // The near pairs of the wave's 256 (typically a few dozen, spread over all four point slots) are packed into
+                // a list in LDS and evaluated 64 at a time by whichever lanes come first — a lane works on other lanes'
+                // points, which is why every lane's FP64 copies live in LDS — instead of one masked pass per point slot.
+                asm volatile("; cost32: FP64 pairs");
+                int npairs = 0;
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if ((nearq[q] >> lane) & 1ull) {
+                        const int pos = npairs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nearq[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nearq[q], 0u));
+                        my_list[pos] = (unsigned short)(q * 64 + lane);
+                    }
+                    npairs += __builtin_popcountll(nearq[q]);
+                }
+                const double* h = s_h + 9 * mi;
+                const double h0d = h[0], h1d = h[1], h2d = h[2], h3d = h[3], h4d = h[4], h5d = h[5], h6d = h[6], h7d = h[7], h8d = h[8];
+                for (int p0 = 0; p0 < npairs; p0 += 64) {
+                    bool in64 = false;
+                    if (p0 + lane < npairs) {
+                        const int id = my_list[p0 + lane], q2 = id >> 6, l2 = id & 63;
+                        const double* pp = wave_p + (q2 * 4) * 64 + l2;
+                        const double d2 = fwd_d2(h0d, h1d, h2d, h3d, h4d, h5d, h6d, h7d, h8d, pp[0], pp[64], pp[128], pp[192]);
+                        my_c[id] = d2 < T ? (int)round(lam * (1.0 - (d2 / T))) : beyond;
+                        in64 = (base_n + l2 * PPL + q2 < N) && d2 < thr2;
+                    }
+                    c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in64));
+                }
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+                    if ((nearq[q] >> lane) & 1ull) c[q] = my_c[q * 64 + lane];
+            }
+            int* dst = C + (size_t)m * ldc + n0;
+            if (n0 + 3 < N) {
+                typedef int i4v __attribute__((ext_vector_type(4)));
+                const i4v v = { c[0], c[1], c[2], c[3] };
+                __builtin_nontemporal_store(v, reinterpret_cast<i4v*>(dst));
+            }
+            else
+                for (int q = 0; q < PPL; ++q) if (n0 + q < N) dst[q] = c[q];
+            if (any_near) {
+                const int c_new = __builtin_amdgcn_readlane(cnt, mi) + c_m;
+                asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(c_new), "s"(mi) : "m0");
+            }
+        }
+    }
+    __shared__ int s_cnt[4][MC];
+    if (lane < MC) s_cnt[wave][lane] = cnt;
+    __syncthreads();
+    if (threadIdx.x < MC && m0 + (int)threadIdx.x < M) {
+        const int t = threadIdx.x;
+        const int cc = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+        if (psplit == 1) counts[m0 + t] = cc;
+        else atomicAdd(&counts[m0 + t], cc);
+    }
+}
+
+// H32: the table launch_model32 made for these models with the same Cmax.  thr2 in [2^-40, 2^40], coordinates below 2^20.
+hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
+                         int* C, long long ldc, int* counts, hipStream_t s)
+{
+    if (M <= 0 || p.n <= 0) return hipSuccess;
+    constexpr int MC = 32;
+    const int gx = (M + MC - 1) / MC, ntiles = (p.n + 1023) / 1024;
+    int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 16 ? 4 : 1);
+    if (psplit > ntiles) psplit = ntiles;
+    if (psplit < 1) psplit = 1;
+    if (psplit > 1) {
+        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
+        if (e != hipSuccess) return e;
+    }
+    // far = beyond T = (9/4 thr)^2 with a 2 % margin: the cheap test's k1 with 1.12 x 9/4 thr in place of 2.5 thr
+    const float k1 = (float)(std::fmax(1.12 * 2.25 * std::sqrt(std::fabs(thr2)), 25.4 * 5.9604644775390625e-08 * Cmax) * (1.0 + 1e-6)) + 1e-30f;
+    hipLaunchKernelGGL((k_cost32<MC, 5>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, 100.0 / lambda,
+                       thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, psplit);
+    return hipGetLastError();
+}
+
 hipError_t launch_model32(const double* H, int M, double X, double Y, double Cmax, float* H32, hipStream_t s)
 {
     if (M <= 0) return hipSuccess;

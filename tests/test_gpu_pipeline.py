@@ -69,13 +69,24 @@ def test_cost_matrix_bit_exact(engine, synth, oracle, n, k, seed):
     H = np.concatenate([sc.H_true, sc.H_true[rng.integers(0, k, 20)] * (1 + rng.normal(0, 2e-4, (20, 9))),
                         np.array([[1, 0, 0, 0, 1, 0, 0, 0, 0], [1, 0, 0, 0, 1, 0, 1e-3, -1e-3, 0.0]])])
     _load(engine, sc)
+    engine.propose_dlt4(seed, 0, 300)                                     # random hypotheses: nearly every pair is far out
+    H = np.concatenate([H, engine.get_models(), np.array([[0, 0, 1, 0, 0, 1, 0, 0, 1e90], [np.nan, 0, 0, 0, 1, 0, 0, 0, 1.0]])])
     engine.set_models(H)
-    Cm, cnt = engine.cost_matrix()
     with np.errstate(all="ignore"):
         ref = oracle.data_cost(sc.src, sc.dst, H, 0.5, THR2)           # site-major, label 0 = outlier
-        assert np.array_equal(Cm, ref[:, 1:].T)
-        assert np.array_equal(cnt, oracle.score(sc.src, sc.dst, H, THR2))
+        ref_cnt = oracle.score(sc.src, sc.dst, H, THR2)
+    # through the FP32 pre-test (k_cost32: the constant for pairs proved far out, the FP64 formula for the rest) and with
+    # the FP64 formula for every pair (k_cost_matrix): the same matrix and counts
+    for pretest in (1, 0):
+        engine.set_tuning(15, pretest)
+        try:
+            Cm, cnt = engine.cost_matrix()
+        finally:
+            engine.set_tuning(15, 1)
+        assert np.array_equal(Cm, ref[:, 1:].T), pretest
+        assert np.array_equal(cnt, ref_cnt), pretest
     assert set(np.unique(Cm)).issubset(set(range(0, 201)) | {9802})
+    assert (Cm != 9802).sum() > 0.05 * sc.n
 
 
 def _rccl(mh):
