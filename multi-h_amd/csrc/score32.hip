@@ -220,37 +220,37 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
 // k1 = max(2.5 x 9/4 thr, 25.4 u Cmax) proves max(|dx|, |dy|) >= 2.26 x 9/4 thr, i.e. d2 >= 5 T, per LANE; the other
 // lanes (both |dx| and |dy| within a dozen pixels, models not eligible for FP32, NaN anywhere) evaluate the reference's
 // FP64 formula — fwd_d2, the IEEE division d2 / T, C round() — exactly as k_cost_matrix does.  Same matrix, same fused
-// inlier counts, bit for bit.  Measured at 50k x 100k DLT hypotheses: 7.7 -> 5.0 ms (the store stream alone would take 3.6 ms:
+// inlier counts, bit for bit.  Measured at 50k x 100k DLT hypotheses: 7.7 -> 4.2 ms (the store stream alone would take 3.6 ms:
 // 3.3 % of the pairs of such a batch are near — hypotheses fitted to four matches are often nearly right for a whole
 // plane — and 42 % of the wave-model iterations contain one, each costing a pass through the IEEE formula).
 // ---------------------------------------------------------------------------
-template <int MC, int MINW>
-__global__ void __launch_bounds__(256, MINW)
+template <int MC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
          const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
          double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit)
 {
-    constexpr int PPL = 4, WAVE_PTS = 64 * PPL, TILE = 4 * WAVE_PTS;
+    constexpr int PPL = 4, WAVE_PTS = 64 * PPL, TILE = WAVES * WAVE_PTS, THREADS = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * MC;
     __shared__ float4 s_m[MC * 4];
     __shared__ double s_h[MC * 9];               // the FP64 coefficients, for the lanes that need the reference's formula
-    __shared__ double s_p[4 * PPL * 4 * 64];     // [wave][point of the lane][x1 y1 x2 y2][lane]: every lane's own points in FP64
-    for (int i = threadIdx.x; i < MC * 4; i += 256) {
+    __shared__ double s_p[WAVES * PPL * 4 * 64];     // [wave][point of the lane][x1 y1 x2 y2][lane]: every lane's own points in FP64
+    for (int i = threadIdx.x; i < MC * 4; i += THREADS) {
         const size_t g = (size_t)m0 * 4 + i;
         s_m[i] = g < (size_t)M * 4 ? reinterpret_cast<const float4*>(H32)[g] : make_float4(0.f, 0.f, 0.f, NAN);
     }
-    for (int i = threadIdx.x; i < MC * 9; i += 256) {
+    for (int i = threadIdx.x; i < MC * 9; i += THREADS) {
         const size_t g = (size_t)m0 * 9 + i;
         s_h[i] = g < (size_t)M * 9 ? H[g] : 0.0;
     }
     __syncthreads();
     double* wave_p = s_p + (size_t)wave * (PPL * 4 * 64);           // + (q * 4 + component) * 64 + lane
     double* my_p = wave_p + lane;
-    __shared__ unsigned short s_list[4 * 64 * PPL];                 // per wave: the (point slot, lane) of the pairs that need FP64
-    __shared__ int s_c[4 * 64 * PPL];                               // per wave: their costs, on the way back to the owning lane
-    unsigned short* my_list = s_list + wave * (64 * PPL);
+    __shared__ unsigned char s_list[WAVES * 64 * PPL];                 // per wave: the (point slot, lane) of the pairs that need FP64
+    __shared__ int s_c[WAVES * 64 * PPL];                               // per wave: their costs, on the way back to the owning lane
+    unsigned char* my_list = s_list + wave * (64 * PPL);
     int* my_c = s_c + wave * (64 * PPL);
     float vk1;
     asm volatile("v_mov_b32 %0, %1" : "=v"(vk1) : "s"(k1));
@@ -300,7 +300,7 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
                 for (int q = 0; q < PPL; ++q) {
                     if ((nearq[q] >> lane) & 1ull) {
                         const int pos = npairs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nearq[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nearq[q], 0u));
-                        my_list[pos] = (unsigned short)(q * 64 + lane);
+                        my_list[pos] = (unsigned char)(q * 64 + lane);
                     }
                     npairs += __builtin_popcountll(nearq[q]);
                 }
@@ -335,12 +335,14 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
             }
         }
     }
-    __shared__ int s_cnt[4][MC];
+    __shared__ int s_cnt[WAVES][MC];
     if (lane < MC) s_cnt[wave][lane] = cnt;
     __syncthreads();
     if (threadIdx.x < MC && m0 + (int)threadIdx.x < M) {
         const int t = threadIdx.x;
-        const int cc = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+        int cc = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) cc += s_cnt[w][t];
         if (psplit == 1) counts[m0 + t] = cc;
         else atomicAdd(&counts[m0 + t], cc);
     }
@@ -352,8 +354,11 @@ hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     constexpr int MC = 32;
-    const int gx = (M + MC - 1) / MC, ntiles = (p.n + 1023) / 1024;
-    int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 16 ? 4 : 1);
+    // 512 threads: the FP64 copies of a wave's points take 8 KB of LDS, so two such workgroups (16 waves) fill a CU's 160 KB;
+    // 256-thread workgroups got 12 waves onto a CU (4.7 ms), one 1 024-thread workgroup 16 again but 4.8 ms; this: 4.2 ms
+    constexpr int WAVES = 8;
+    const int gx = (M + MC - 1) / MC, ntiles = (p.n + 256 * WAVES - 1) / (256 * WAVES);
+    int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 8 ? 2 : 1);
     if (psplit > ntiles) psplit = ntiles;
     if (psplit < 1) psplit = 1;
     if (psplit > 1) {
@@ -362,7 +367,7 @@ hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int
     }
     // far = beyond T = (9/4 thr)^2 with a 2 % margin: the cheap test's k1 with 1.12 x 9/4 thr in place of 2.5 thr
     const float k1 = (float)(std::fmax(1.12 * 2.25 * std::sqrt(std::fabs(thr2)), 25.4 * 5.9604644775390625e-08 * Cmax) * (1.0 + 1e-6)) + 1e-30f;
-    hipLaunchKernelGGL((k_cost32<MC, 5>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, 100.0 / lambda,
+    hipLaunchKernelGGL((k_cost32<MC, WAVES>), dim3(gx, psplit), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, 100.0 / lambda,
                        thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, psplit);
     return hipGetLastError();
 }
