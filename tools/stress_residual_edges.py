@@ -12,7 +12,7 @@ budget = float(os.environ.get("SECONDS", 120))
 rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
 e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 thr2 = 2.2 ** 2
-t0 = time.time(); runs = 0
+t0 = time.time(); runs = 0; costs = 0
 pe = np.array([-1030, -600, -460, -451, -450, -449, -300, -256, -255, -254, -20, 0, 0, 0, 0, 7, 10, 118, 119, 120, 121, 257, 300, 600, 1000])
 while time.time() - t0 < budget:
     n, m = int(rng.integers(1, 3000)), int(rng.integers(1, 200))
@@ -34,6 +34,26 @@ while time.time() - t0 < budget:
         and np.array_equal(cnt, ref_cnt) and np.array_equal(cnt2, ref_cnt)
     if not ok:
         print("MISMATCH", dict(n=n, m=m, sym=sym, run=runs)); sys.exit(1)
+    if runs % 3 == 0 and not sym:
+        # the int32 cost matrix (mh_cost_matrix) through the FP32 pre-test and with the FP64 formula for every pair, against
+        # the oracle's dataEnergy; in a third of these runs all coordinates are moderate so that the pre-test kernel is the one
+        # that runs, with models over hundreds of binades
+        if runs % 9 == 0:
+            src = rng.uniform(0, 1000, size=(n, 2)) * rng.choice([1.0, 1.0, 1e-3, 1e-200, 0.0], size=(n, 2))
+            dst = rng.uniform(0, 1000, size=(n, 2)) * rng.choice([1.0, 1.0, 1e-3, 1e-200, 0.0], size=(n, 2))
+            dst[: n // 2] = src[: n // 2] + rng.normal(0, 1.5, size=(n // 2, 2))
+            H[: m // 2] = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1.0]) + rng.normal(0, 1e-3, size=(m // 2, 9)) * np.array([1, 1, 100, 1, 1, 100, 1e-3, 1e-3, 1])
+            e.set_correspondences(src, dst); e.set_models(H)
+        with np.errstate(all="ignore"):
+            want = O.data_cost(src, dst, H, 0.5, thr2)[:, 1:].T
+            want_cnt = O.score(src, dst, H, thr2)
+        for pre in (1, 0):
+            e.set_tuning(15, pre)
+            Cm, ccnt = e.cost_matrix()
+            e.set_tuning(15, 1)
+            if not (np.array_equal(Cm, want) and np.array_equal(ccnt, want_cnt)):
+                print("COST MATRIX MISMATCH", dict(n=n, m=m, run=runs, pretest=pre)); sys.exit(1)
+        costs += 1
     runs += 1
 e.set_residual_mode(False)
-print(f"residual edge stress ok: {runs} random problems in {time.time() - t0:.0f} s")
+print(f"residual edge stress ok: {runs} random problems in {time.time() - t0:.0f} s ({costs} of them also through the cost matrix, both paths)")
