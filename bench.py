@@ -147,7 +147,7 @@ def full_loop_extra(a):
     child process."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(N=str(a.points), K=str(a.planes), HYP=str(a.models), ITERS="20")
+    env.update(N=str(a.points), K=str(a.planes), HYP=str(a.models), ITERS="20", REPEAT="1")
 
     def run(iter_hyp: int):
         e = dict(env, ITER_HYP=str(iter_hyp))
@@ -162,7 +162,10 @@ def full_loop_extra(a):
         return {"error": err}
     out = {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 100000 proposals, then 20 merge/label/re-estimate iterations",
            "iterations": 20, "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
-           "process_s": rec["total_s"], "ms_per_iteration": rec["loop_s"] / 20 * 1e3, "digest": rec["digest"]}
+           "process_s": rec["total_s"], "process_s_second_call": rec.get("total_s_second_call"),
+           "note": "process_s is the first Process() of a fresh process (it also pays for the HIP runtime and the code objects); "
+                   "process_s_second_call is the same call repeated in that process, identical result",
+           "ms_per_iteration": rec["loop_s"] / 20 * 1e3, "digest": rec["digest"]}
     # the same with a fresh batch of proposals in EVERY iteration (PEARL re-proposal on the points left unexplained)
     rec2, err2 = run(a.models)
     out["with_reproposal"] = ({"iter_hypotheses": a.models, "clusters": rec2["clusters"], "energy": rec2["energy"],
