@@ -219,8 +219,11 @@ MH_API int mh_set_transport(mh_engine* e, int rank, int world, mh_allgather_stre
  * Sharded batch (a transport is set; total_m = size of the whole batch, 0 = the resident set is the whole batch): in the
  * first round the ranks all-gather their int32 score vectors (north_star's exchange); in every round they all-gather
  * one 88-byte record each — {best score and its position, that hypothesis' H, an error word} — and pick the same
- * winner.  Outputs do not depend on the number of ranks.  A rank-local failure travels in the error word, so all ranks
- * leave the loop together. */
+ * winner.  Outputs do not depend on the number of ranks.  A rank-local failure (the state of that rank's engine: wrong
+ * shard size, symmetric mode, a failing scoring launch) does not keep the rank out of the round's collectives: it offers
+ * nothing, sets the record's error word, and after the exchange every rank leaves the loop — the failing one with its
+ * own error, the others with MH_ERR_HIP "a rank reported an error".  Arguments (thr2, need, max_models, total_m) must be
+ * the same on every rank. */
 MH_API int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsigned char* point_mask,
                             double* H_out, long long* counters_out, int* counts_out, int* selected_out, long long total_m);
 /* Pipelined propose: mh_prefetch_dlt4 prepares the batch (seed, first .. first+m-1) in the engine's SPARE model buffer on a
@@ -230,10 +233,15 @@ MH_API int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models,
 MH_API int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int m);
 MH_API int mh_adopt_prefetched(mh_engine* e);
 /* Best-supported model of the scored batch (highest resident inlier count, lowest position in the whole batch on ties) by
- * the engine's own arg-max kernel.  With a transport and world > 1 the ranks first all-gather their int32 score vectors
- * on the engine's stream (BASELINE configs[3]; the gathered vector stays resident: MH_BUF_GATHERED_SCORES) and every
- * rank finds the same winner.  best_index / best_count both NULL: enqueue only (no host synchronisation; a later call
- * with outputs, or mh_synchronize, completes it). */
+ * the engine's own arg-max kernel.  With a transport the ranks first all-gather their int32 score vectors (BASELINE
+ * configs[3]; the gathered vector stays resident: MH_BUF_GATHERED_SCORES) and every rank finds the same winner; a rank
+ * whose shard is empty (more ranks than hypotheses) takes part with nothing to offer.
+ * best_index / best_count both NULL: ENQUEUE ONLY.  With a stream-ordered transport (or none) the all-gather, the arg-max
+ * and the publication then run on a stream of their own behind an event of the sweep, OFF the main stream's critical
+ * path: the next sweep starts at once and writes the engine's other counts buffer (after such a call MH_BUF_COUNTS is
+ * undefined until the next scoring call).  A later call with outputs — before anything else has been scored — or
+ * mh_synchronize completes it; the ranks' send buffer is the batch's own counts buffer (no padding kernel).  The
+ * host-synchronised transport runs the same steps on the main stream. */
 MH_API int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* best_count);
 /* mh_score and mh_select_greedy decide most (point, model) pairs in FP32 with a rigorous error bound and only the pairs
  * within that bound of the threshold in FP64 (csrc/score32.hip; the counts are the FP64 formula's, bit for bit).  pairs:
@@ -299,7 +307,11 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * dominance-reduction launches per move (1 or 2), 14 test hook: the first attempts of the next n expansions count as
  * barrier time-outs (exercises the restart with fewer workgroups), 15 the FP32 pre-test of the score kernels (1 on, 0 the
  * FP64 sweep for every pair; the counts are equal by construction), 16 tiling of that pre-test kernel, 17 passes of the
- * dominance cascade inside the solver launch (0 = to its fixed point).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * dominance cascade inside the solver launch (0 = to its fixed point), 18 test hook: the n-th scoring round of the coming
+ * greedy selections fails on this rank (exercises the collective exit of mh_select_greedy), 19 the materialising residual sweep as a resident
+ * grid that hands itself the work items (value = workgroup slots left free beyond its own occupancy, default 0; -1 = one
+ * hardware-dispatched workgroup per item), 20 the sweep is held until the second stream has reached a pending DLT prefetch's
+ * dispatch (1, default) or not (0) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

@@ -5,7 +5,7 @@
 // SURVEY 2.2).  Built as libmultih_rccl.so (links librccl); the engine and the host class do not depend on it.
 //
 // Bootstrap (one process per GPU): rank 0 makes the 128-byte unique id (mhr_unique_id) and hands it to the other ranks by
-// whatever channel the launcher has — multih_harness --ranks N passes it through a file it names (mhr_init_from_file),
+// whatever channel the launcher has — multih_harness --ranks N passes it through pipes made before it forks,
 // bench.py broadcasts it over its torch.distributed process group — then every rank calls mhr_init.
 #pragma once
 #ifdef __cplusplus
@@ -18,7 +18,10 @@ typedef struct mhr_comm mhr_comm;
 __attribute__((visibility("default"))) int mhr_unique_id(unsigned char id[MHR_ID_BYTES]);
 // Collective over the `world` ranks: every rank calls it with the same id.  `device` = the HIP device of this rank.
 __attribute__((visibility("default"))) int mhr_init(mhr_comm** out, int rank, int world, const unsigned char id[MHR_ID_BYTES], int device);
-// The same with the id travelling through `path`: rank 0 creates the file (atomically), the others wait up to timeout_s for it.
+// The same with the id travelling through `path`: rank 0 creates the file (atomically: an exclusively created temporary
+// renamed over it), the others wait up to timeout_s for it.  The caller owns the path: it must not exist beforehand (a stale
+// file of an earlier run would be read as this run's id) and is the caller's to remove.  multih_harness --ranks N hands the id
+// to its children through pipes instead.
 __attribute__((visibility("default"))) int mhr_init_from_file(mhr_comm** out, int rank, int world, const char* path, int device, int timeout_s);
 // mh_allgather_stream_fn: all-gather `bytes_per_rank` bytes per rank, device buffers, rank order, on `hip_stream`.
 __attribute__((visibility("default"))) int mhr_allgather(void* comm, const void* send_dev, void* recv_dev, unsigned long long bytes_per_rank, void* hip_stream);

@@ -102,12 +102,24 @@ struct mh_engine {
     void* t_ctx = nullptr;
     // pipelined propose (mh_prefetch_dlt4): the spare batch and the second stream it is prepared on
     hipStream_t side_stream = nullptr;
-    hipEvent_t ev_side = nullptr, ev_main = nullptr;
+    hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_side_pre = nullptr;
+    int tune_dlt_first = 1;                  // key 20: the sweep waits until the second stream has reached the pending DLT's dispatch (1) or not (0)
     DevBuf<double> H_next;
     DevBuf<int> samples_next;
     int m_next = 0;
     bool next_valid = false;
-    // best model of a scored batch (mh_select_best)
+    // best model of a scored batch (mh_select_best).  The (all-gather +) arg-max of batch i runs on a third stream behind an
+    // event of sweep i, so sweep i+1 starts at once: the batch's counts buffer goes to the exchange and the next sweep
+    // writes the other one (r04)
+    hipStream_t xchg_stream = nullptr;
+    hipEvent_t ev_sweep = nullptr, ev_x[2] = { nullptr, nullptr };
+    DevBuf<int> counts_alt;
+    long long xchg_calls = 0;                  // exchanges enqueued on xchg_stream so far (parity selects ev_x)
+    long long models_seq = 0, best_models_seq = -1;   // model-set generation; the one the last mh_select_best result belongs to
+    bool counts_zeroed_alt = false;            // the same for the other buffer
+    bool counts_zeroed = false;                // the current counts buffer was cleared behind the exchange that last read it (the next sweep skips its memset)
+    bool counts_fresh = false;                 // the current counts buffer holds the scores of the current model set (a scoring call wrote it)
+    bool xchg_pending = false;                 // something enqueued on xchg_stream since the last host wait for it
     DevBuf<unsigned long long> best_key;
     int* h_best = nullptr;                     // mapped pinned: count, global index, sequence number
     int* h_best_dev = nullptr;
@@ -136,9 +148,13 @@ struct mh_engine {
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
     int cu_count = 256;
+    DevBuf<int> sweep_ctl;                   // work counter + exit counter of the resident sweep (cleared by the launch itself)
+    int sweep_wg_per_cu = -1;                // workgroups of the materialising sweep a compute unit holds (-1 = not queried yet)
+    int tune_sweep_headroom = 0;             // key 19: workgroup slots the resident sweep leaves free beyond its own occupancy (-1 = hardware dispatch)
     int solve_grid_max = 0;                  // workgroups of the solver launch that can be resident at once (0 = not queried yet)
     int last_expand_retries = 0;             // restarts of the last expansion after a barrier timeout (shared GPU)
     int last_solve_grid = 0;                 // workgroups of the solver launch in the attempt that completed
+    int inject_select_failure = 0;           // test hook (key 18): the n-th scoring round of the coming greedy selections fails on this rank
     int inject_barrier_timeouts = 0;         // test hook: the next n expansions' first attempts count as timed out
     DevBuf<long long> ew_acc;
     int* h_flags = nullptr;
@@ -257,6 +273,34 @@ int require_models(mh_engine* e)
     int rc = require_points(e);
     if (rc) return rc;
     if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
+    return MH_OK;
+}
+
+// (a re-allocated counts buffer is not the one an exchange cleared)
+hipError_t reserve_counts(mh_engine* e, size_t n)
+{
+    if (n <= e->counts.cap) return hipSuccess;
+    e->counts_zeroed = false;
+    return e->counts.reserve(n);
+}
+
+// Host wait for everything the engine has enqueued: the main stream, the DLT prefetch on the second stream and the
+// (all-gather +) arg-max on the third.
+int quiesce(mh_engine* e)
+{
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->side_stream) HIPCHK(hipStreamSynchronize(e->side_stream));
+    if (e->xchg_stream) HIPCHK(hipStreamSynchronize(e->xchg_stream));
+    e->xchg_pending = false;
+    return MH_OK;
+}
+
+// The main stream waits (on the device) for the last exchange enqueued on the third stream: called by whatever is about to
+// touch the buffers that exchange reads or writes (gathered scores, best key, the counts buffer it was given).
+int join_xchg(mh_engine* e)
+{
+    if (e->xchg_pending && e->xchg_calls > 0)
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_x[(e->xchg_calls - 1) & 1], 0));
     return MH_OK;
 }
 
@@ -727,7 +771,7 @@ void mh_destroy(mh_engine* e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
+    (void)quiesce(e);
     resolve_timers(e);
     e->x1.release(); e->y1.release(); e->x2.release(); e->y2.release();
     e->a11.release(); e->a12.release(); e->a21.release(); e->a22.release();
@@ -760,7 +804,12 @@ void mh_destroy(mh_engine* e)
     if (e->h_best) (void)hipHostFree(e->h_best);
     if (e->ev_side) (void)hipEventDestroy(e->ev_side);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+    if (e->ev_side_pre) (void)hipEventDestroy(e->ev_side_pre);
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    if (e->xchg_stream) { (void)hipStreamSynchronize(e->xchg_stream); (void)hipStreamDestroy(e->xchg_stream); }
+    if (e->ev_sweep) (void)hipEventDestroy(e->ev_sweep);
+    for (int b = 0; b < 2; ++b) if (e->ev_x[b]) (void)hipEventDestroy(e->ev_x[b]);
+    e->counts_alt.release(); e->sweep_ctl.release();
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -782,7 +831,8 @@ int mh_set_stream(mh_engine* e, void* hip_stream, int external)
     return guarded([&]() -> int {
     int rc0 = enter(e);
     if (rc0) return rc0;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    int rcq = quiesce(e);
+    if (rcq) return rcq;
     resolve_timers(e);
     e->stream = external ? (hipStream_t)hip_stream : e->own_stream;
     return MH_OK;
@@ -794,7 +844,8 @@ int mh_synchronize(mh_engine* e)
     return guarded([&]() -> int {
     int rc0 = enter(e);
     if (rc0) return rc0;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    rc0 = quiesce(e);
+    if (rc0) return rc0;
     resolve_timers(e);
     return MH_OK;
     });
@@ -807,6 +858,12 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
     int rc0 = enter(e);
     if (rc0) return rc0;
     if (!src_xy || !dst_xy || n <= 0) return fail(MH_ERR_INVALID, "src/dst must be non-null and n > 0");
+    // A DLT prefetch in flight on the second stream reads the point arrays this call overwrites, and the batch it
+    // prepares belongs to the OLD point set: wait for it and drop it (r03 advisor finding).
+    rc0 = quiesce(e);
+    if (rc0) return rc0;
+    e->next_valid = false;
+    e->m_next = 0;
     // +1 element of slack: the 16-B vector loads of the residual sweep never cross the end,
     // but keep the allocation even-sized for them.
     const size_t cap = (size_t)n + 2;
@@ -833,6 +890,7 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
         // everything sized by the previous point set is stale: the residual matrix and its pitch, the sampled batch,
         // the fundamental-matrix hypotheses
         e->m = 0; e->ldr = 0; e->have_samples = false; e->fm = 0;
+        e->counts_fresh = false; ++e->models_seq;
     }
     {
         double xmin = src_xy[0], xmax = src_xy[0], ymin = src_xy[1], ymax = src_xy[1], dmax = 0.0;
@@ -1324,7 +1382,7 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int 
     if (e->n < 4) return fail(MH_ERR_INVALID, "need at least 4 correspondences");
     HIPCHK(e->H.reserve((size_t)m * 9));
     HIPCHK(e->samples.reserve((size_t)m * 4));
-    HIPCHK(e->counts.reserve(m));
+    HIPCHK(reserve_counts(e, (size_t)m + 1));
     {
         ScopedTimer t(e, MH_K_DLT4);
         HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples.p, e->H.p, e->stream));
@@ -1332,6 +1390,7 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int 
     e->m = m;
     e->have_samples = true;
     e->cost_L = 0;
+    e->counts_fresh = false; ++e->models_seq;
     return MH_OK;
     });
 }
@@ -1341,9 +1400,10 @@ int mh_set_models(mh_engine* e, const double* H, int m)
     return guarded([&]() -> int {
     if (!e || m < 0 || (m > 0 && !H)) return fail(MH_ERR_INVALID, "null argument or m < 0");
     HIPCHK(hipSetDevice(e->device));
+    e->counts_fresh = false; ++e->models_seq;
     if (m == 0) { e->m = 0; e->have_samples = false; e->cost_L = 0; return MH_OK; }     // an empty model set
     HIPCHK(e->H.reserve((size_t)m * 9));
-    HIPCHK(e->counts.reserve(m));
+    HIPCHK(reserve_counts(e, (size_t)m + 1));
     HIPCHK(hipMemcpyAsync(e->H.p, H, sizeof(double) * 9 * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->m = m;
@@ -1401,7 +1461,7 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
     return guarded([&]() -> int {
     int rc = require_models(e);
     if (rc) return rc;
-    HIPCHK(e->counts.reserve(e->m));
+    HIPCHK(reserve_counts(e, (size_t)e->m + 1));
     const unsigned char* dmask = nullptr;
     if (point_mask) {
         HIPCHK(e->mask.reserve((size_t)e->n + 2));
@@ -1413,6 +1473,8 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
         rc = score_models(e, e->pts(), e->H.p, e->m, thr2, dmask, e->counts.p);
         if (rc) return rc;
     }
+    e->counts_zeroed = false;
+    e->counts_fresh = true;
     if (counts) {
         HIPCHK(hipMemcpyAsync(counts, e->counts.p, sizeof(int) * e->m, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1434,13 +1496,34 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     r_elems = std::max(r_elems, (size_t)((e->m + 15) / 16 * 16) * (size_t)((e->n + 1023) / 1024 * 1024));
 #endif
     HIPCHK(e->R.reserve(r_elems));
-    HIPCHK(e->counts.reserve(e->m));
+    HIPCHK(reserve_counts(e, (size_t)e->m + 1));
+    // The sweep runs as a RESIDENT grid — as many workgroups as the chip holds at the kernel's five waves per SIMD, handing
+    // themselves the (model block, point slice) items through a counter (residual.hip, k_residual_resident): 7.27-7.29 ms
+    // against 7.48-7.70 for one hardware-dispatched workgroup per item at 50k x 100k, and it leaves 72 registers per SIMD
+    // free on every compute unit, which is what a workgroup of the DLT solve needs.  Key 19: -1 = hardware dispatch,
+    // h >= 0 = leave h more workgroup slots free.
+    int resident = 0;
+    if (e->tune_sweep_headroom >= 0 && e->residual_mode != MH_RESIDUAL_SYMMETRIC && e->tune_residual_variant == 0) {
+        if (e->sweep_wg_per_cu < 0) e->sweep_wg_per_cu = residual_workgroups_per_cu();
+        resident = e->sweep_wg_per_cu * e->cu_count - e->tune_sweep_headroom;
+        if (resident < e->cu_count) resident = 0;
+        if (resident > 0 && !e->sweep_ctl.p) {
+            HIPCHK(e->sweep_ctl.reserve(2));
+            HIPCHK(hipMemsetAsync(e->sweep_ctl.p, 0, sizeof(int) * 2, e->stream));
+        }
+    }
+    // ... and it starts behind the DLT's dispatch, not beside it: a sweep that reaches the chip first fills every
+    // workgroup slot and keeps them (its queue is dispatched ahead of the other stream's whatever the priorities), and
+    // the DLT then runs after the sweep instead of beside it — the next sweep waits for it (profiles/r04_timeline_*.txt).
+    if (e->next_valid && e->tune_dlt_first && e->ev_side_pre) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_side_pre, 0));
     {
         ScopedTimer t(e, MH_K_RESIDUAL);
         HIPCHK(launch_residual(e->pts(), e->H.p, e->m, thr2, e->R.p, e->ldr, e->counts.p,
                                e->residual_mode == MH_RESIDUAL_SYMMETRIC ? -1 : e->tune_residual_variant,
-                               e->stream));
+                               e->stream, e->counts_zeroed, resident, e->sweep_ctl.p));
     }
+    e->counts_zeroed = false;
+    e->counts_fresh = true;
     if (R_host)
         HIPCHK(hipMemcpy2DAsync(R_host, sizeof(double) * e->n, e->R.p, sizeof(double) * e->ldr,
                                 sizeof(double) * e->n, e->m, hipMemcpyDeviceToHost, e->stream));
@@ -1458,7 +1541,7 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
     if (rc) return rc;
     e->ldc = cost_ld(e->n);
     HIPCHK(e->C.reserve((size_t)e->m * (size_t)e->ldc));
-    HIPCHK(e->counts.reserve(e->m));
+    HIPCHK(reserve_counts(e, (size_t)e->m + 1));
     {
         ScopedTimer t(e, MH_K_COSTMATRIX);
         const double thr2 = e->thr_H * e->thr_H;
@@ -1469,6 +1552,8 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
         } else
             HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, thr2, e->C.p, e->ldc, e->counts.p, e->stream));
     }
+    e->counts_zeroed = false;
+    e->counts_fresh = true;
     if (C_host)
         HIPCHK(hipMemcpy2DAsync(C_host, sizeof(int) * e->n, e->C.p, sizeof(int) * e->ldc, sizeof(int) * e->n, e->m,
                                 hipMemcpyDeviceToHost, e->stream));
@@ -1495,15 +1580,15 @@ int mh_get_residual_rows(mh_engine* e, int first, int count, double* rows_host)
 }
 
 // all-gather on the engine's stream through whichever transport is set; the host-synchronised hook sees an idle stream
-static int exchange(mh_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank)
+static int exchange(mh_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank, hipStream_t on)
 {
     if (e->t_stream_fn) {
-        if (e->t_stream_fn(e->t_ctx, send_dev, recv_dev, (unsigned long long)bytes_per_rank, (void*)e->stream) != 0)
+        if (e->t_stream_fn(e->t_ctx, send_dev, recv_dev, (unsigned long long)bytes_per_rank, (void*)on) != 0)
             return fail(MH_ERR_INVALID, "all-gather failed (stream-ordered transport)");
         return MH_OK;
     }
     if (!e->t_host_fn) return fail(MH_ERR_NOT_SET, "no transport set (mh_set_transport)");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(on));
     if (e->t_host_fn(e->t_ctx, send_dev, recv_dev, (unsigned long long)bytes_per_rank) != 0)
         return fail(MH_ERR_INVALID, "all-gather failed (host-synchronised transport)");
     return MH_OK;
@@ -1516,6 +1601,11 @@ int mh_set_transport(mh_engine* e, int rank, int world, mh_allgather_stream_fn s
     if (world < 1 || rank < 0 || rank >= world) return fail(MH_ERR_INVALID, "bad rank / world");
     if (stream_fn && host_fn) return fail(MH_ERR_INVALID, "give ONE transport: stream-ordered or host-synchronised");
     if (world > 1 && !stream_fn && !host_fn) return fail(MH_ERR_INVALID, "world > 1 needs a transport");
+    if (e->xchg_pending) {                                 // an exchange in flight still uses the old transport
+        HIPCHK(hipSetDevice(e->device));
+        int rcq = quiesce(e);
+        if (rcq) return rcq;
+    }
     e->t_rank = rank; e->t_world = world; e->t_stream_fn = stream_fn; e->t_host_fn = host_fn; e->t_ctx = ctx;
     return MH_OK;
     });
@@ -1528,15 +1618,12 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     int rc = require_points(e);
     if (rc) return rc;
     if (!H_out || !selected_out || max_models <= 0 || need < 1) return fail(MH_ERR_INVALID, "bad argument");
-    if (e->residual_mode == MH_RESIDUAL_SYMMETRIC)
-        return fail(MH_ERR_INVALID, "the greedy selection scores and claims with the forward transfer error (the reference's); "
-                                    "switch back to MH_RESIDUAL_FORWARD for it");
-    const int n = e->n, M = e->m;                     // M may be 0 on a rank without hypotheses (more ranks than hypotheses)
+    const int n = e->n;
+    int M = e->m;                                     // M may be 0 on a rank without hypotheses (more ranks than hypotheses)
     // The transport is used whenever one is set — also with world == 1, where a one-rank communicator runs the whole
     // protocol (how the RCCL path is tested on a box with one GPU).
     const bool sharded = e->t_stream_fn || e->t_host_fn;
     const int world = sharded ? e->t_world : 1, rank = sharded ? e->t_rank : 0;
-    if (!sharded && M <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
     if (total_m <= 0) total_m = M;
     if (total_m > 0xfffffffell) return fail(MH_ERR_INVALID, "more than 2^32 - 2 hypotheses in a batch");
     // contiguous shards of the whole batch, the first `rem` one hypothesis longer
@@ -1544,7 +1631,22 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     const int longest = base + (rem ? 1 : 0);
     const int mine = base + (rank < rem ? 1 : 0);
     const unsigned int my_off = (unsigned int)((long long)rank * base + std::min(rank, rem));
-    if (M != mine) return fail(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
+    // What can be wrong on THIS rank only — the state of its engine — must not keep it out of the collectives: the other
+    // ranks would wait in the all-gather for ever (r03 advisor finding).  Such a failure is remembered (code + text), the
+    // rank goes through one round with an empty candidate list and its error word set, every rank reads that word
+    // after the exchange and all of them leave together; this rank then reports its own failure.
+    int local_rc = MH_OK;
+    std::string local_msg;
+    auto local_failure = [&](int code, const std::string& msg) { if (local_rc == MH_OK) { local_rc = code; local_msg = msg; } };
+    if (e->residual_mode == MH_RESIDUAL_SYMMETRIC)
+        local_failure(MH_ERR_INVALID, "the greedy selection scores and claims with the forward transfer error (the reference's); "
+                                      "switch back to MH_RESIDUAL_FORWARD for it");
+    else if (!sharded && M <= 0) local_failure(MH_ERR_NOT_SET, "model set is empty");
+    else if (M != mine) local_failure(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
+    if (local_rc != MH_OK && !sharded) return fail(local_rc, local_msg);
+    if (local_rc != MH_OK) M = 0;
+    rc = join_xchg(e);                                 // an mh_select_best exchange still in flight shares the gather buffer
+    if (rc) return rc;
     const size_t cap = (size_t)std::max(M, 1);
     for (int b = 0; b < 2; ++b) { HIPCHK(e->sel_orig[b].reserve(cap)); HIPCHK(e->sel_cand_H[b].reserve(cap * 9)); }
     HIPCHK(e->sel_counts.reserve(cap));
@@ -1582,47 +1684,58 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     for (int c = 0; c < 4; ++c) HIPCHK(e->sel_pts[c].reserve((size_t)n + 2));
     HIPCHK(e->sel_pack_count.reserve(1));
 
-    int Mc = M, cur = 0, selected = 0, packed_as = -1, local_err = 0;
+    int Mc = M, cur = 0, selected = 0, packed_as = -1;
     bool first = true;
     for (int round = 0; round < max_models; ++round) {
         const double* Hs = first ? e->H.p : e->sel_cand_H[cur].p;
         const int* orig = first ? nullptr : e->sel_orig[cur].p;
-        if (Mc > 0) {
+        // the rank-local part of a round: score the candidates.  A failure here does not return before the collectives.
+        auto score_round = [&]() -> int {
+            if (e->inject_select_failure > 0 && --e->inject_select_failure == 0)
+                return fail(MH_ERR_HIP, "greedy selection: injected rank-local failure (test hook, mh_set_tuning key 18)");
+            if (Mc <= 0) return MH_OK;
             ScopedTimer t(e, MH_K_SCORE);
-            if (active == n) {
-                rc = score_models(e, e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p);
-                if (rc) return rc;
-            } else if (active > 0) {
+            if (active == n) return score_models(e, e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p);
+            if (active > 0) {
                 HIPCHK(launch_sel_pack_points(e->pts(), e->mask.p, e->sel_pts[0].p, e->sel_pts[1].p, e->sel_pts[2].p, e->sel_pts[3].p,
                                               e->sel_pack_count.p, s));
                 packed_as = active;
                 Points packed = e->pts();                     // (same bounding box: a superset's is valid)
                 packed.x1 = e->sel_pts[0].p; packed.y1 = e->sel_pts[1].p; packed.x2 = e->sel_pts[2].p; packed.y2 = e->sel_pts[3].p;
                 packed.n = active;
-                rc = score_models(e, packed, Hs, Mc, thr2, nullptr, e->sel_counts.p);
-                if (rc) return rc;
-            } else {
-                HIPCHK(hipMemsetAsync(e->sel_counts.p, 0, sizeof(int) * (size_t)Mc, s));
+                return score_models(e, packed, Hs, Mc, thr2, nullptr, e->sel_counts.p);
+            }
+            HIPCHK(hipMemsetAsync(e->sel_counts.p, 0, sizeof(int) * (size_t)Mc, s));
+            return MH_OK;
+        };
+        if (local_rc == MH_OK) {
+            const int src = score_round();
+            if (src != MH_OK) {
+                if (!sharded) return src;
+                local_failure(src, g_err);
+                Mc = 0;                                        // offer nothing; the error word tells the others
             }
         }
+        const int local_err = local_rc != MH_OK ? 1 : 0;
         const bool gather_scores = sharded && first && longest > 0;      // north_star's exchange, once per batch
         HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, my_off, key_local, gather_scores ? e->sel_scores.p : nullptr, s));
         HIPCHK(launch_sel_record(e->sel_counts.p, orig, Hs, Mc, my_off, key_local, local_err, my_record, s));
         if (sharded) {
             if (gather_scores) {
-                rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest);
+                rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, s);
                 if (rc) return rc;
                 HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, key_check, s));
             }
-            rc = exchange(e, my_record, records, sizeof(SelRecord));     // 88 bytes per rank
+            rc = exchange(e, my_record, records, sizeof(SelRecord), s);     // 88 bytes per rank
             if (rc) return rc;
         }
         HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, records, world, my_off, e->sel_orig[cur ^ 1].p,
                                   e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, s));
-        HIPCHK(launch_sel_claim(e->pts(), records, world, gather_scores ? key_check : nullptr, thr2, need, e->mask.p, e->sel_rec.p,
+        HIPCHK(launch_sel_claim(e->pts(), records, world, gather_scores && !local_err ? key_check : nullptr, thr2, need, e->mask.p, e->sel_rec.p,
                                 e->sel_out_H.p, e->sel_counter.p, max_models, s));
         HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, my_record, need, e->h_sel_dev, s));
         HIPCHK(hipStreamSynchronize(s));                 // five control words through mapped memory: no copy
+        if (local_rc != MH_OK) return fail(local_rc, local_msg);     // (the others have read this rank's error word by now)
         if (e->h_sel[4] != 0)                            // every rank sees the same word, so every rank leaves here
             return fail(MH_ERR_HIP, e->h_sel[4] == 2 ? "greedy selection: the gathered score vector and the ranks' records disagree about the winner"
                                                       : "greedy selection: a rank reported an error");
@@ -1666,6 +1779,7 @@ static int ensure_side_stream(mh_engine* e)
     }
     if (!e->ev_side) HIPCHK(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
     if (!e->ev_main) HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+    if (!e->ev_side_pre) HIPCHK(hipEventCreateWithFlags(&e->ev_side_pre, hipEventDisableTiming));
     return MH_OK;
 }
 
@@ -1689,6 +1803,7 @@ int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int
     // up to now may still read them.
     HIPCHK(hipEventRecord(e->ev_main, e->stream));
     HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_main, 0));
+    HIPCHK(hipEventRecord(e->ev_side_pre, e->side_stream));      // the second stream has got as far as this batch's dispatch
     {
         ScopedTimer t(e, MH_K_DLT4, e->side_stream);           // (the kernel's span on the second stream, beside whatever the main one runs)
         HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples_next.p, e->H_next.p, e->side_stream));
@@ -1709,23 +1824,48 @@ int mh_adopt_prefetched(mh_engine* e)
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_side, 0));        // main-stream work behind this point sees the new batch
     std::swap(e->H, e->H_next);
     std::swap(e->samples, e->samples_next);
-    HIPCHK(e->counts.reserve(e->m_next));
+    HIPCHK(reserve_counts(e, (size_t)e->m_next + 1));
     e->m = e->m_next;
     e->have_samples = true;
     e->next_valid = false;
     e->cost_L = 0;
+    e->counts_fresh = false; ++e->models_seq;
     return MH_OK;
     });
 }
 
 // ---- best model of the scored batch --------------------------------------------------------------
+static int ensure_xchg_stream(mh_engine* e)
+{
+    if (!e->xchg_stream) {
+        // high priority, like the DLT's stream: the two or three short kernels of an exchange (and RCCL's own) get compute
+        // units as soon as the sweep on the main stream frees some
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->xchg_stream, hipStreamNonBlocking, hi));
+    }
+    if (!e->ev_sweep) HIPCHK(hipEventCreateWithFlags(&e->ev_sweep, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b)
+        if (!e->ev_x[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_x[b], hipEventDisableTiming));
+    return MH_OK;
+}
+
+// The exchange is OFF the sweep's critical path (r04): with a stream-ordered transport (or none) the
+// all-gather, the arg-max and the publication of batch i are enqueued on a third stream behind an event of sweep i, and
+// the main stream goes straight on to sweep i+1.  The ranks' send buffer is the batch's own counts buffer (no padding
+// kernel: a shard one shorter than the longest carries its -1 in the element behind its counts), which stays with the
+// exchange while the next sweep writes the engine's other counts buffer.  The host-synchronised transport (several ranks
+// rehearsing on one GPU) keeps the r03 form: everything on the main stream.
 int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* best_count)
 {
     return guarded([&]() -> int {
-    int rc = require_models(e);
+    int rc = require_points(e);
     if (rc) return rc;
     const bool sharded = e->t_stream_fn || e->t_host_fn;       // also with world == 1: a one-rank communicator runs the exchange
     const int world = sharded ? e->t_world : 1, rank = sharded ? e->t_rank : 0;
+    // a rank may hold an EMPTY shard (more ranks than hypotheses): it still takes part in the collective
+    if (e->m <= 0 && (!sharded || total_m <= 0)) return fail(MH_ERR_NOT_SET, "model set is empty");
+    HIPCHK(reserve_counts(e, (size_t)e->m + 1));
     if (total_m <= 0) total_m = e->m;
     const int base = (int)(total_m / world), rem = (int)(total_m % world);
     const int longest = base + (rem ? 1 : 0);
@@ -1738,20 +1878,82 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
         HIPCHK(hipMemsetAsync(e->best_key.p, 0, sizeof(unsigned long long), e->stream));
     }
     hipStream_t s = e->stream;
-    if (sharded) {
+    const bool fetch = best_index || best_count;
+    if (!e->counts_fresh && e->m > 0) {
+        // nothing has been scored since the last call: that call's result is the answer ("a later call with outputs
+        // completes it"); without one there is nothing to select from
+        if (e->best_seq == 0 || e->best_models_seq != e->models_seq) return fail(MH_ERR_NOT_SET, "the batch has not been scored (mh_residual_matrix / mh_score / mh_cost_matrix)");
+        if (fetch) {
+            rc = quiesce(e);
+            if (rc) return rc;
+            if (e->h_best[2] != e->best_seq) return fail(MH_ERR_HIP, "best-model result is stale");
+            if (best_index) *best_index = e->h_best[1];
+            if (best_count) *best_count = e->h_best[0];
+        }
+        return MH_OK;
+    }
+    if (e->t_host_fn) {
+        // host-synchronised transport: the r03 sequence on the main stream
+        rc = join_xchg(e);
+        if (rc) return rc;
         HIPCHK(e->sel_scores.reserve((size_t)longest));
         HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
         HIPCHK(launch_pad_scores(e->counts.p, e->m, longest, e->sel_scores.p, s));
-        rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest);     // north_star's all-gather
+        rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, s);     // north_star's all-gather
         if (rc) return rc;
         HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, e->best_key.p, s));
+        HIPCHK(launch_best_publish(e->best_key.p, e->h_best_dev, s));
+        ++e->best_seq;
+        e->best_models_seq = e->models_seq;
+        if (fetch) HIPCHK(hipStreamSynchronize(s));
     } else {
-        HIPCHK(launch_sel_argmax(e->counts.p, nullptr, e->m, 0u, e->best_key.p, nullptr, s));
+        rc = ensure_xchg_stream(e);
+        if (rc) return rc;
+        hipStream_t x = e->xchg_stream;
+        if (sharded) {
+            if (e->sel_gathered.cap < (size_t)world * longest) {
+                rc = quiesce(e);                                   // (re)allocation: an earlier exchange may still write the old buffer
+                if (rc) return rc;
+                HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
+            }
+            if (longest > e->m)                                    // a shard one shorter than the longest: its padding element (every
+                HIPCHK(hipMemsetAsync(e->counts.p + e->m, 0xff, sizeof(int) * (size_t)(longest - e->m), s));   // counts buffer holds m + 1 ints)
+        }
+        if (e->xchg_calls == 0) HIPCHK(hipMemsetAsync(e->best_key.p, 0, sizeof(unsigned long long), s));
+        HIPCHK(hipEventRecord(e->ev_sweep, s));                    // the sweep (and whatever else the main stream holds) up to here
+        HIPCHK(hipStreamWaitEvent(x, e->ev_sweep, 0));
+        if (sharded) {
+            rc = exchange(e, e->counts.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, x);      // north_star's all-gather
+            if (rc) return rc;
+            HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, e->best_key.p, x));
+        } else {
+            HIPCHK(launch_sel_argmax(e->counts.p, nullptr, e->m, 0u, e->best_key.p, nullptr, x));
+        }
+        HIPCHK(launch_best_publish(e->best_key.p, e->h_best_dev, x));
+        // enqueue-only: this buffer comes back to the main stream two calls from now — cleared here, behind the exchange
+        // that read it, so that the sweep that then writes it needs no memset of its own on the main stream
+        if (!fetch) HIPCHK(hipMemsetAsync(e->counts.p, 0, sizeof(int) * e->counts.cap, x));
+        const int par = (int)(e->xchg_calls & 1);
+        HIPCHK(hipEventRecord(e->ev_x[par], x));
+        ++e->xchg_calls;
+        e->xchg_pending = true;
+        ++e->best_seq;
+        e->best_models_seq = e->models_seq;
+        if (fetch) {
+            HIPCHK(hipStreamSynchronize(x));
+            e->xchg_pending = false;
+        } else {
+            // this batch's counts stay with the exchange; the next sweep writes the other buffer — once the exchange that
+            // was given THAT one (the previous call's, a whole step ago) is through
+            std::swap(e->counts, e->counts_alt);
+            std::swap(e->counts_zeroed_alt, e->counts_zeroed);      // (this call's buffer will be clear once ev_x[par] has passed)
+            e->counts_zeroed_alt = true;
+            e->counts_fresh = false;
+            HIPCHK(reserve_counts(e, (size_t)e->m + 1));
+            if (e->xchg_calls >= 2) HIPCHK(hipStreamWaitEvent(s, e->ev_x[par ^ 1], 0));
+        }
     }
-    HIPCHK(launch_best_publish(e->best_key.p, e->h_best_dev, s));
-    ++e->best_seq;
-    if (best_index || best_count) {
-        HIPCHK(hipStreamSynchronize(s));
+    if (fetch) {
         if (e->h_best[2] != e->best_seq) return fail(MH_ERR_HIP, "best-model result is stale");
         if (best_index) *best_index = e->h_best[1];
         if (best_count) *best_count = e->h_best[0];
@@ -2103,6 +2305,9 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 15 && (value == 0 || value == 1)) { e->tune_score32 = value; return MH_OK; }
     if (key == 16 && value >= 0 && value <= 16) { e->tune_score32_tiling = value; return MH_OK; }
     if (key == 17 && value >= 0 && value <= 1000) { e->tune_cascade_iters = value; return MH_OK; }
+    if (key == 18 && value >= 0 && value <= 1000) { e->inject_select_failure = value; return MH_OK; }
+    if (key == 19 && value >= -1 && value <= 1024) { e->tune_sweep_headroom = value; return MH_OK; }
+    if (key == 20 && (value == 0 || value == 1)) { e->tune_dlt_first = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -136,12 +136,20 @@ __device__ __forceinline__ void null9_vector(double (*W)[HPW], int hs, double g[
 #undef WE
 }
 
-__global__ void __launch_bounds__(256)
+// At most 72 VGPRs: that is what the resident residual sweep leaves free on every SIMD (5 waves of 88 registers), so a
+// workgroup of this kernel fits beside it on any compute unit (residual.hip, k_residual_resident).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(72)))
 k_dlt4(const double* __restrict__ x1, const double* __restrict__ y1,
        const double* __restrict__ x2, const double* __restrict__ y2, int N,
        unsigned long long seed, long long first, int M, int* __restrict__ idx_out,
        double* __restrict__ H_out)
 {
+    // Issue priority above the sweep's waves (priority 0).  A SIMD issues from its oldest ready wave first; beside five
+    // resident sweep waves that always have an FP64 instruction ready, a wave of this kernel hardly ever issued: the DLT
+    // of the next batch took the whole sweep and its own run time again after it, whatever the stream's priority and
+    // however many workgroup slots stood free (profiles/r04_timeline_*.txt).  Its total VALU work is a few per cent of
+    // the sweep's, so the sweep does not notice.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double sW[4][WROWS * WCOLS][HPW];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

@@ -36,7 +36,10 @@ inline long long residual_ld(int n) { return ((long long)n + 15) & ~15ll; }
 // --- residual.hip -----------------------------------------------------------
 // variant: 0 default; tuning knob for bench sweeps (see residual.hip).
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
-                           long long ldr, int* counts, int variant, hipStream_t s);
+                           long long ldr, int* counts, int variant, hipStream_t s, bool counts_zeroed = false,
+                           int resident_grid = 0, int* resident_ctl = nullptr);
+// workgroups of the product's materialising sweep that one compute unit holds at a time (occupancy query)
+int residual_workgroups_per_cu();
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
                         const unsigned char* mask, int* counts, int variant, hipStream_t s);
 // --- score32.hip: the same counts through an FP32 pre-test with a rigorous error bound (FP64 only for the pairs it cannot decide)

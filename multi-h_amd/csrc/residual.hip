@@ -39,24 +39,21 @@ namespace mh {
 // no validity mask on the inlier ballot.  Same arithmetic, same bits; what goes is scalar and branch work.
 // TILED (tuning): R stored tile-major — [model block][point tile][MC][TILE] — so that a workgroup writes one contiguous
 // 128-KiB block per tile instead of MC row segments.
-template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
-          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
-__global__ void __launch_bounds__(256, MINW)
-k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
-           const double* __restrict__ x2, const double* __restrict__ y2, int N,
-           const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
-           long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
-           int psplit, int swapxy, double bx0, double bx1, double by0, double by1)
+// residual_wg: the work of ONE workgroup — model block bx (MC models), point slice by.
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB, bool HSGPR,
+          bool SYM, bool CONTRACT, bool LEAN, bool TILED, int SF, bool SEMI>
+__device__ __forceinline__ void
+residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
+            const double* __restrict__ x2, const double* __restrict__ y2, int N,
+            const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
+            long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+            int psplit, double bx0, double bx1, double by0, double by1, const int bx, const int by)
 {
     constexpr int CH = PPL / 2;                 // 16-B chunks per lane
     constexpr int WAVE_PTS = 64 * PPL;          // points per wave per tile
     constexpr int TILE = 4 * WAVE_PTS;          // points per workgroup per tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (tells the compiler it is wave-uniform)
-    // swapxy (tuning): slice index in blockIdx.x, so that consecutive workgroups write neighbouring
-    // chunks of the same rows of R
-    const int bx = swapxy ? blockIdx.y : blockIdx.x;
-    const int by = swapxy ? blockIdx.x : blockIdx.y;
     const int m0 = bx * MC;
 
     // Stage this workgroup's MC x 9 coefficients in LDS once; the sweep reads them
@@ -287,18 +284,85 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
     }
 }
 
+// One workgroup per (model block, point slice), placed by the hardware dispatcher.
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
+k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
+           const double* __restrict__ x2, const double* __restrict__ y2, int N,
+           const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
+           long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+           int psplit, int swapxy, double bx0, double bx1, double by0, double by1)
+{
+    // swapxy (tuning): slice index in blockIdx.x, so that consecutive workgroups write neighbouring
+    // chunks of the same rows of R
+    const int bx = swapxy ? blockIdx.y : blockIdx.x;
+    const int by = swapxy ? blockIdx.x : blockIdx.y;
+    residual_wg<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI>(
+        x1, y1, x2, y2, N, H, M, thr2, R, ldr, counts, mask, psplit, bx0, bx1, by0, by1, bx, by);
+}
+
+// The same work items walked by a RESIDENT grid (r04): gridDim.x workgroups stride over the gx x psplit items, item ->
+// (model block item % gx, slice item / gx).  The launch is sized a little below what the chip holds, so the workgroup
+// slots it leaves free stay free for the whole sweep — that is where the DLT solve of the next batch runs (second
+// stream).  With one hardware-dispatched workgroup per item the sweep refills every slot the moment it frees, stream
+// priority notwithstanding: a 12 500-hypothesis DLT (60 us alone) took the whole 1.07 ms sweep and another 110 us behind
+// it, during which the next sweep waited (profiles/r04_timeline_*.txt).
+template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
+          bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW) __attribute__((amdgpu_num_vgpr(88)))      // 5 waves per SIMD and 72 registers left for k_dlt4
+k_residual_resident(const double* __restrict__ x1, const double* __restrict__ y1,
+                    const double* __restrict__ x2, const double* __restrict__ y2, int N,
+                    const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
+                    long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+                    int psplit, int gx, int nitems, int* __restrict__ ctl, double bx0, double bx1, double by0, double by1)
+{
+    // Items are handed out through one counter, first come first served — the workgroups of a resident grid do not run at
+    // one speed (a compute unit that holds six of them serves each more slowly than one that holds five, and the memory
+    // channels are not equally busy), and a static split waits for the slowest: 8.55 ms against 7.70 at 50k x 100k.
+    // ctl[0] = next item, ctl[1] = workgroups that have left; the last one to leave clears both for the next launch.
+    __shared__ int s_item;
+#pragma unroll 1
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&ctl[0], 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= nitems) break;
+        const int by = item / gx, bx = item - by * gx;
+        residual_wg<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI>(
+            x1, y1, x2, y2, N, H, M, thr2, R, ldr, counts, mask, psplit, bx0, bx1, by0, by1, bx, by);
+        __syncthreads();                        // the item's LDS (coefficients, flags, counts) and s_item are rewritten by the next one
+    }
+    if (threadIdx.x == 0 && atomicAdd(&ctl[1], 1) == (int)gridDim.x - 1) {
+        ctl[1] = 0;
+        __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, bool CALIB = false, bool HSGPR = false,
           bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
-                            int force_psplit = 0, int swapxy = 0)
+                            int force_psplit = 0, int swapxy = 0, bool counts_zeroed = false, int resident_grid = 0,
+                            int* resident_ctl = nullptr)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     const int gx = (M + MC - 1) / MC;
     const int tile = 256 * PPL;
     const int ntiles = (p.n + tile - 1) / tile;
     int psplit = 1;
-    if (gx < 1024) {                       // few models: split the point sweep to fill the chip
+    if (WRITE_R) {
+        // The materialising sweep: aim at ~37 500 workgroups whatever the batch size (at least 4 point slices for a long
+        // sweep).  r04, tools/shard_proxy.py on the per-rank shards of BASELINE configs[3]: with the r03 rule (2 048
+        // workgroups below 1 024 model blocks, else 4 slices) the 12 500-hypothesis shard of an 8-GPU run ran 2 346
+        // workgroups of 16 tiles — 1.5 rounds of the chip's 1 536 resident workgroups, a quarter of the launch in its
+        // tail — and cost 1.06 ms against 7.63 / 8 = 0.95; 1.049 / 1.025 / 1.006 / 0.998 / 0.992 ms at 4 / 8 / 12 / 16 / 32
+        // slices; 25 000: 2.039 -> 1.984 (24), 50 000: 4.044 -> 3.980 (12); 100 000: flat (7.59 at 4, 7.57 at 8).
+        psplit = (37500 + gx - 1) / gx;
+        if (psplit < 4 && ntiles >= 32) psplit = 4;
+        if (psplit > ntiles) psplit = ntiles;
+        if (psplit < 1) psplit = 1;
+    } else if (gx < 1024) {                // few models: split the point sweep to fill the chip
         psplit = (2048 + gx - 1) / gx;
         if (psplit > ntiles) psplit = ntiles;
         if (psplit < 1) psplit = 1;
@@ -311,9 +375,17 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     if (force_psplit > 0) psplit = force_psplit < ntiles ? force_psplit : ntiles;
     bool contiguous = false;
     if (force_psplit < 0) { psplit = -force_psplit < ntiles ? -force_psplit : ntiles; contiguous = true; }
-    if (psplit > 1) {
+    if (psplit > 1 && !counts_zeroed) {
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
         if (e != hipSuccess) return e;
+    }
+    constexpr bool PRODUCT_SWEEP = WRITE_R && !MASK && NT && FAST && !CALIB && HSGPR && !SYM && !CONTRACT && LEAN && !TILED && SF == 0 && SEMI && MINW == 1 && PPL == 4 && MC == 16;
+    if constexpr (PRODUCT_SWEEP)
+    if (resident_grid > 0 && resident_ctl && !contiguous && !swapxy && gx * psplit > resident_grid) {
+        hipLaunchKernelGGL((k_residual_resident<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI, MINW>),
+                           dim3(resident_grid), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit, gx,
+                           gx * psplit, resident_ctl, p.xmin, p.xmax, p.ymin, p.ymax);
+        return hipGetLastError();
     }
     dim3 grid(gx, psplit);
     if (swapxy) grid = dim3(psplit, gx);
@@ -328,18 +400,21 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 // coefficients in SGPRs, store-only calibration, forced slices, fused multiply-adds — the last one NOT bit-exact) and
 // exists only in libraries compiled with -DMH_TUNING (multi-h_amd/build.py --tuning) for tools/kernel_sweep.py.
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
-                           long long ldr, int* counts, int variant, hipStream_t s)
+                           long long ldr, int* counts, int variant, hipStream_t s, bool counts_zeroed, int resident_grid,
+                           int* resident_ctl)
 {
     // PPL 4, MC 16, the lean sweep wherever a tile and a model allow it, non-temporal 16-B stores (r03: the kernel runs at
     // the board's power cap, its time is its energy; nt stores — nothing of R is ever re-read — cost 2.7 % less energy
     // per launch than plain ones, profiles/r03_energy.json)
     // ... and the nine coefficients of the current model through the scalar unit (s_load from H, uniform address) instead
     // of LDS broadcasts into VGPRs: the twelve linear-form operations then read one operand from SGPRs; 2.5 % less energy.
-    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, 0, 0, counts_zeroed, resident_grid, resident_ctl);
     if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant >= 400)         // 400 + psplit: the product kernel with a forced point split (tools/shard_proxy.py)
+        return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 400);
     if (variant >= 300)         // 300 + s: s interleaved slices with the slice index as the fastest grid dimension
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 300, 1);
     if (variant >= 200)         // 200 + s: s contiguous point slices instead of interleaved tiles
@@ -389,6 +464,14 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     }
 #endif
     return hipErrorInvalidValue;
+}
+
+int residual_workgroups_per_cu()
+{
+    int n = 0;
+    const hipError_t he = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &n, (const void*)k_residual_resident<4, 16, true, false, true, true, false, true, false, false, true>, 256, 0);
+    return he == hipSuccess && n > 0 ? n : 0;
 }
 
 hipError_t launch_score(const Points& p, const double* H, int M, double thr2,

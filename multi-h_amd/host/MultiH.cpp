@@ -548,45 +548,63 @@ void MultiH::ClusterMergingAndLabeling()
 // Mode -> homography is GetHomography3PT with its LM refinement (:995-1055, multih::Homography3PT).
 // The N x modes scoring and the 3x3 scatter eigen test (:430-463) run on the GPU
 // (mh_inlier_moments).
+// MergingStep (M/MultiH.cpp:352-471) on a given engine: host candidates (merge_step.cpp MergeCandidates), then the N x
+// candidates scoring and the collinearity filter on the GPU (mh_inlier_moments; :430-463).  kept: the surviving
+// candidates, 9 doubles each.  Returns an MH_* status.  The correspondences must be resident in the engine; its model
+// set is replaced by the candidates.
+static int MergingStepOnEngine(mh_engine* engine, const double* H, int nh, const double F[9], double thr_h, double straightness,
+                               uint64_t seed, std::vector<double>& kept, uint64_t* draws)
+{
+    kept.clear();
+    std::vector<double> cand;
+    const int nc = multih::MergeCandidates(H, nh, F, thr_h, seed, nullptr, nullptr, cand, nullptr, draws);
+    if (nc == 0) return MH_OK;
+    int rc = mh_set_models(engine, cand.data(), nc);
+    if (rc != MH_OK) return rc;
+    std::vector<double> mom(6 * (size_t)nc), mineig(nc);
+    rc = mh_inlier_moments(engine, thr_h * thr_h, mom.data(), mineig.data());
+    if (rc != MH_OK) return rc;
+    for (int i = 0; i < nc; ++i) {
+        const int inl = static_cast<int>(mom[6 * (size_t)i]);
+        if (mineig[i] < straightness || inl < 3) continue;                             // :462
+        kept.insert(kept.end(), cand.begin() + 9 * (size_t)i, cand.begin() + 9 * (size_t)(i + 1));
+    }
+    return MH_OK;
+}
+
+// test hook (tests/test_gpu_alternation.py): one MergingStep of the product on `engine`, to be compared bit for bit with
+// the oracle's mho_merging_step.  kept: capacity nh x 9; returns the number kept or a negative MH_* status.
+extern "C" __attribute__((visibility("default")))
+int mhh_merging_step(mh_engine* engine, const double* H, int nh, const double* F, double thr_h, double straightness,
+                     unsigned long long seed, double* kept_out, int* changed, unsigned long long* draws)
+{
+    std::vector<double> kept;
+    uint64_t d = 0;
+    const int rc = MergingStepOnEngine(engine, H, nh, F, thr_h, straightness, seed, kept, &d);
+    if (rc != MH_OK) return rc;
+    std::copy(kept.begin(), kept.end(), kept_out);
+    if (changed) *changed = (int)(kept.size() / 9) != nh;
+    if (draws) *draws = d;
+    return (int)(kept.size() / 9);
+}
+
 bool MultiH::MergingStep(bool& changed)
 {
     const int nh = static_cast<int>(cluster_homographies.size());
     changed = false;
     if (nh == 0) return true;
-    std::vector<double> H(9 * (size_t)nh), feat(6 * (size_t)nh);
+    std::vector<double> H(9 * (size_t)nh);
     for (int i = 0; i < nh; ++i) {
         const double* p = reinterpret_cast<const double*>(cluster_homographies[i].data);
         for (int k = 0; k < 9; ++k) H[9 * (size_t)i + k] = p[k];
     }
-    multih::HomographyFeatures(H.data(), nh, feat.data());
-    multih::MeanShiftResult ms;
-    uint64_t draws = 0;
-    multih::MeanShiftCluster(feat.data(), nh, 6, threshold_homography, proposal_seed ^ 0x4d53u ^ (merge_rng_counter << 20),
-                             ms, &draws);
+    std::vector<double> kept9;
+    const int rc = MergingStepOnEngine(engine, H.data(), nh, fundamental_matrix, threshold_homography, straightness_threshold,
+                                       proposal_seed ^ 0x4d53u ^ (merge_rng_counter << 20), kept9, nullptr);
     ++merge_rng_counter;
-
-    const int k = static_cast<int>(ms.members.size());
-    std::vector<double> cand;
-    const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                        // :408
-    for (int i = 0; i < k; ++i) {
-        double Hc[9];
-        if (multih::Homography3PT(pts1, &ms.modes[6 * (size_t)i], 3, fundamental_matrix, Hc, true))   // :427
-            cand.insert(cand.end(), Hc, Hc + 9);
-    }
-    const int nc = static_cast<int>(cand.size() / 9);
+    if (!Check(rc, "MergingStep (mh_set_models / mh_inlier_moments)")) return false;
     std::vector<cv::Mat> kept;
-    if (nc > 0) {
-        if (!Check(mh_set_models(engine, cand.data(), nc), "mh_set_models")) return false;
-        std::vector<double> mom(6 * (size_t)nc), mineig(nc);
-        if (!Check(mh_inlier_moments(engine, sqr_threshold_homography, mom.data(), mineig.data()),
-                   "mh_inlier_moments"))
-            return false;
-        for (int i = 0; i < nc; ++i) {
-            const int inl = static_cast<int>(mom[6 * (size_t)i]);
-            if (mineig[i] < straightness_threshold || inl < 3) continue;               // :462
-            kept.push_back(MatFrom9(&cand[9 * (size_t)i]));
-        }
-    }
+    for (size_t i = 0; i + 9 <= kept9.size(); i += 9) kept.push_back(MatFrom9(&kept9[i]));
     changed = kept.size() != cluster_homographies.size();                               // :468
     if (changed) cluster_homographies = kept;                                           // :469-470
     return true;

@@ -14,6 +14,7 @@
 //                                computes the same result; rank 0 writes <out_result.txt>, rank r > 0 <out_result.txt>.rank<r>.
 //                                N = 1 runs the same protocol on a one-rank communicator.
 // Defaults are the harness defaults of the reference (M/main.cpp:55-59).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,7 @@
 
 #include <dlfcn.h>
 #include <sys/wait.h>
+#include <poll.h>
 #include <unistd.h>
 
 #include "MultiH.h"
@@ -91,20 +93,36 @@ int main(int argc, char** argv)
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
 
-    // --ranks N: fork ranks 1..N-1 now — no HIP call has been made yet — then every rank joins the communicator
+    // --ranks N: fork ranks 1..N-1 now — no HIP call has been made yet — then every rank joins the communicator.  RCCL's
+    // 128-byte bootstrap id travels from rank 0 to each child through a pipe made before the fork: no file, so no
+    // predictable path to plant a link at and no stale id of a crashed run to pick up (r03 advisor finding).
     int rank = 0;
     std::vector<pid_t> kids;
+    std::vector<int> id_writers;                 // rank 0: write ends, one per child
+    int id_reader = -1;                          // child: read end
     if (ranks > 1) {
-        const std::string idfile = "/tmp/multih_rccl_id_" + std::to_string((long long)getpid());
-        setenv("MULTIH_RCCL_ID_FILE", idfile.c_str(), 1);
         for (int r = 1; r < ranks; ++r) {
+            int fds[2];
+            if (pipe(fds) != 0) { perror("pipe"); return 1; }
             const pid_t pid = fork();
             if (pid < 0) { perror("fork"); return 1; }
-            if (pid == 0) { rank = r; kids.clear(); break; }
+            if (pid == 0) {
+                rank = r;
+                kids.clear();
+                close(fds[1]);
+                for (int w : id_writers) close(w);
+                id_writers.clear();
+                id_reader = fds[0];
+                break;
+            }
+            close(fds[0]);
+            id_writers.push_back(fds[1]);
             kids.push_back(pid);
         }
     }
     auto finish = [&](int rc) {
+        for (int w : id_writers) close(w);       // (a child still waiting for the id sees end-of-file and gives up)
+        id_writers.clear();
         for (pid_t pid : kids) {
             int st = 0;
             if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
@@ -112,7 +130,6 @@ int main(int argc, char** argv)
                 if (rc == 0) rc = 1;
             }
         }
-        if (rank == 0 && ranks > 1) unlink(getenv("MULTIH_RCCL_ID_FILE"));
         return rc;
     };
     mhr_comm* comm = nullptr;
@@ -121,20 +138,38 @@ int main(int argc, char** argv)
     if (ranks >= 1) {
         void* lib = dlopen("libmultih_rccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) { std::cerr << "cannot load libmultih_rccl.so: " << dlerror() << "\n"; return finish(1); }
-        auto init_file = (int (*)(mhr_comm**, int, int, const char*, int, int))dlsym(lib, "mhr_init_from_file");
         auto init_id = (int (*)(mhr_comm**, int, int, const unsigned char*, int))dlsym(lib, "mhr_init");
         auto make_id = (int (*)(unsigned char*))dlsym(lib, "mhr_unique_id");
         auto last_error = (const char* (*)())dlsym(lib, "mhr_last_error");
         allgather = (int (*)(void*, const void*, void*, unsigned long long, void*))dlsym(lib, "mhr_allgather");
         comm_destroy = (void (*)(mhr_comm*))dlsym(lib, "mhr_destroy");
-        if (!init_file || !init_id || !make_id || !allgather || !comm_destroy || !last_error) { std::cerr << "libmultih_rccl.so lacks a symbol\n"; return finish(1); }
-        int rc;
-        if (ranks == 1) {
-            unsigned char id[MHR_ID_BYTES];
+        if (!init_id || !make_id || !allgather || !comm_destroy || !last_error) { std::cerr << "libmultih_rccl.so lacks a symbol\n"; return finish(1); }
+        unsigned char id[MHR_ID_BYTES];
+        int rc = 0;
+        if (rank == 0) {
             rc = make_id(id);
-            if (rc == 0) rc = init_id(&comm, 0, 1, id, 0);
+            for (int w : id_writers) {
+                if (rc == 0 && write(w, id, MHR_ID_BYTES) != (ssize_t)MHR_ID_BYTES) { std::cerr << "[Multi-H] cannot hand the RCCL id to a rank\n"; rc = 1; }
+                close(w);
+            }
+            id_writers.clear();
         } else {
-            rc = init_file(&comm, rank, ranks, getenv("MULTIH_RCCL_ID_FILE"), rank, 120);
+            // the id arrives within two minutes or not at all (end-of-file: rank 0 gave up)
+            size_t got = 0;
+            struct pollfd pf = { id_reader, POLLIN, 0 };
+            while (got < MHR_ID_BYTES) {
+                if (poll(&pf, 1, 120000) <= 0) break;
+                const ssize_t k = read(id_reader, id + got, MHR_ID_BYTES - got);
+                if (k <= 0) break;
+                got += (size_t)k;
+            }
+            close(id_reader);
+            if (got != MHR_ID_BYTES) { std::cerr << "[Multi-H] rank " << rank << ": no RCCL id from rank 0\n"; return finish(1); }
+        }
+        if (rc == 0) {
+            alarm(300);                          // ncclCommInitRank waits for every rank: a peer that died must not hang the others
+            rc = init_id(&comm, rank, std::max(ranks, 1), id, rank);
+            alarm(0);
         }
         if (rc != 0) { std::cerr << "[Multi-H] rank " << rank << ": RCCL communicator: " << last_error() << "\n"; return finish(1); }
         printf("[Multi-H] rank %d of %d joined the RCCL communicator (device %d)\n", rank, ranks, rank);

@@ -148,7 +148,7 @@ static void jacobi3(double* a, double* v, double* d)
 }
 
 // NormalizePoints, Homography_Refine3PTCallback.h:161-196 (row-matrix branch)
-static void normalize_points(const double* pts, int n, std::vector<double>& out, double T[9], double Tinv[9])
+static void normalize_points(const double* pts, int n, std::vector<double>& out, double T[9])
 {
     double cx = 0.0, cy = 0.0;
     for (int i = 0; i < n; ++i) { cx = cx + pts[2 * i]; cy = cy + pts[2 * i + 1]; }
@@ -165,62 +165,121 @@ static void normalize_points(const double* pts, int n, std::vector<double>& out,
     const double ratio = std::sqrt(2.0) / avg;
     for (int i = 0; i < 2 * n; ++i) out[i] = out[i] * ratio;
     const double t[9] = { ratio, 0, -cx * ratio, 0, ratio, -cy * ratio, 0, 0, 1 };
-    const double ti[9] = { 1.0 / ratio, 0, cx, 0, 1.0 / ratio, cy, 0, 0, 1 };
     std::memcpy(T, t, sizeof(t));
-    std::memcpy(Tinv, ti, sizeof(ti));
 }
 
-bool Homography3PTLinear(const double* pts1, const double* pts2, int n, const double F[9], double H[9])
+// T.inv() of the similarity T = [r 0 tx; 0 r ty; 0 0 1] (:1009, :1054), computed FROM T as the reference computes it from
+// T — not from the centroid behind it, which would round differently.
+static void similarity_inverse(const double T[9], double Ti[9])
 {
+    const double ir = 1.0 / T[0];
+    const double t[9] = { ir, 0, -T[2] * ir, 0, ir, -T[5] * ir, 0, 0, 1 };
+    std::memcpy(Ti, t, sizeof(t));
+}
+
+// x = pinv(A) b (x nullable) and / or pinv(A) itself (P nullable) for a symmetric 3 x 3 A through its eigen-decomposition,
+// eigenvalues within 2 eps sum|w| of zero dropped — what cv::solve / cv::invert do with DECOMP_EIG (M/Utilities.hpp:806,:830)
+// and the stand-in for A.inv(DECOMP_SVD) * b on the normal equations (:1038).
+static void sym_eig_solve3(const double A[9], const double* b, double* x, double* P)
+{
+    double a[9], v[9], w[3];
+    std::memcpy(a, A, sizeof(a));
+    jacobi3(a, v, w);
+    double cut = 0.0;
+    for (int k = 0; k < 3; ++k) cut = cut + std::fabs(w[k]);
+    cut = cut * (2.0 * 2.220446049250313e-16);
+    if (x) for (int i = 0; i < 3; ++i) x[i] = 0.0;
+    if (P) for (int i = 0; i < 9; ++i) P[i] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        if (std::fabs(w[k]) <= cut) continue;
+        if (x) {
+            double proj = 0.0;
+            for (int i = 0; i < 3; ++i) proj = proj + v[3 * i + k] * b[i];
+            proj = proj / w[k];
+            for (int i = 0; i < 3; ++i) x[i] = x[i] + proj * v[3 * i + k];
+        }
+        if (P)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) P[3 * i + j] = P[3 * i + j] + v[3 * i + k] * v[3 * j + k] / w[k];
+    }
+}
+
+namespace {
+
+// Everything GetHomography3PT computes before the optional refinement (M/MultiH.cpp:1003-1050): normalised points,
+// normalised F and epipole, and the third row of the normalised H from the 2n x 3 least-squares system.
+struct Normalised3PT {
     std::vector<double> p1, p2;
-    double T1[9], T1i[9], T2[9], T2i[9];
-    normalize_points(pts1, n, p1, T1, T1i);
-    normalize_points(pts2, n, p2, T2, T2i);
-    // Fn = T2^-T * F * T1^-1   (M/MultiH.cpp:1009)
-    double T2it[9], tmp[9], Fn[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2it[3 * i + j] = T2i[3 * j + i];
+    double T1[9], T2[9], T2i[9], Fn[9], e0, e1, h3[3];
+};
+
+void solve_normalised_3pt(const double* pts1, const double* pts2, int n, const double F[9], Normalised3PT& q)
+{
+    double T1i[9];
+    normalize_points(pts1, n, q.p1, q.T1);
+    normalize_points(pts2, n, q.p2, q.T2);
+    similarity_inverse(q.T1, T1i);
+    similarity_inverse(q.T2, q.T2i);
+    // Fn = T2^-T * F * T1^-1   (:1009)
+    double T2it[9], tmp[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2it[3 * i + j] = q.T2i[3 * j + i];
     mat3_mul(T2it, F, tmp);
-    mat3_mul(tmp, T1i, Fn);
+    mat3_mul(tmp, T1i, q.Fn);
     // epipole of the normalised F: eigenvector of Fn*Fn^T with the smallest eigenvalue (:1013-1017)
     double FFt[9], Fnt[9], v[9], d[3];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fnt[3 * i + j] = Fn[3 * j + i];
-    mat3_mul(Fn, Fnt, FFt);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fnt[3 * i + j] = q.Fn[3 * j + i];
+    mat3_mul(q.Fn, Fnt, FFt);
     jacobi3(FFt, v, d);
     int jm = 0;
     for (int j = 1; j < 3; ++j) if (d[j] < d[jm]) jm = j;
-    const double e0 = v[0 * 3 + jm] / v[2 * 3 + jm], e1 = v[1 * 3 + jm] / v[2 * 3 + jm];
-    // normal equations of the 2n x 3 system (:1019-1038; the reference solves with an SVD pseudo-inverse)
-    double AtA[9] = { 0 }, Atb[3] = { 0 };
+    q.e0 = v[0 * 3 + jm] / v[2 * 3 + jm];
+    q.e1 = v[1 * 3 + jm] / v[2 * 3 + jm];
+    // the 2n x 3 system (:1019-1037), solved through its normal equations (the reference: SVD pseudo-inverse, :1038);
+    // A^T A and A^T b are summed row by row in the order of the rows
+    std::vector<double> A(6 * (size_t)n), rhs(2 * (size_t)n);
+    const double* Fn = q.Fn;
     for (int i = 0; i < n; ++i) {
-        const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
-        const double r0[3] = { e0 * x1 - x2 * x1, e0 * y1 - x2 * y1, e0 - x2 };
-        const double r1[3] = { e1 * x1 - y2 * x1, e1 * y1 - y2 * y1, e1 - y2 };
-        const double b0 = -(x1 * Fn[3] + y1 * Fn[4] + Fn[5]);
-        const double b1 = (x1 * Fn[0] + y1 * Fn[1] + Fn[2]);
-        for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < 3; ++b) AtA[3 * a + b] += r0[a] * r0[b] + r1[a] * r1[b];
-            Atb[a] += r0[a] * b0 + r1[a] * b1;
-        }
+        const double x1 = q.p1[2 * i], y1 = q.p1[2 * i + 1], x2 = q.p2[2 * i], y2 = q.p2[2 * i + 1];
+        double* r = &A[6 * (size_t)i];
+        r[0] = q.e0 * x1 - x2 * x1; r[1] = q.e0 * y1 - x2 * y1; r[2] = q.e0 - x2;
+        r[3] = q.e1 * x1 - y2 * x1; r[4] = q.e1 * y1 - y2 * y1; r[5] = q.e1 - y2;
+        rhs[2 * i] = -(x1 * Fn[3] + y1 * Fn[4] + Fn[5]);
+        rhs[2 * i + 1] = (x1 * Fn[0] + y1 * Fn[1] + Fn[2]);
     }
-    // 3x3 symmetric solve by cofactors
-    const double* m = AtA;
-    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
-    const double inv[9] = {
-        c00 / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
-        c01 / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
-        c02 / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det };
-    double r[3];
-    for (int a = 0; a < 3; ++a) r[a] = inv[3 * a] * Atb[0] + inv[3 * a + 1] * Atb[1] + inv[3 * a + 2] * Atb[2];
-    double Hn[9];
-    Hn[6] = r[0]; Hn[7] = r[1]; Hn[8] = r[2];
-    Hn[3] = e1 * Hn[6] - Fn[0]; Hn[4] = e1 * Hn[7] - Fn[1]; Hn[5] = e1 * Hn[8] - Fn[2];     // :1045-1047
-    Hn[0] = e0 * Hn[6] + Fn[3]; Hn[1] = e0 * Hn[7] + Fn[4]; Hn[2] = e0 * Hn[8] + Fn[5];     // :1048-1050
-    mat3_mul(T2i, Hn, tmp);                                                                 // :1054
-    mat3_mul(tmp, T1, H);
+    double AtA[9], Atb[3];
+    for (int a = 0; a < 3; ++a) {
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int i = 0; i < 2 * n; ++i) s = s + A[3 * (size_t)i + a] * A[3 * (size_t)i + c];
+            AtA[3 * a + c] = s;
+        }
+        double s = 0.0;
+        for (int i = 0; i < 2 * n; ++i) s = s + A[3 * (size_t)i + a] * rhs[i];
+        Atb[a] = s;
+    }
+    sym_eig_solve3(AtA, Atb, q.h3, nullptr);
+}
+
+// rows of the normalised H from its third row (:1040-1050) and the de-normalisation H = T2^-1 Hn T1 (:1054)
+bool assemble_3pt(const Normalised3PT& q, const double h3[3], double H[9])
+{
+    double Hn[9], tmp[9];
+    Hn[6] = h3[0]; Hn[7] = h3[1]; Hn[8] = h3[2];
+    Hn[3] = q.e1 * h3[0] - q.Fn[0]; Hn[4] = q.e1 * h3[1] - q.Fn[1]; Hn[5] = q.e1 * h3[2] - q.Fn[2];     // :1045-1047
+    Hn[0] = q.e0 * h3[0] + q.Fn[3]; Hn[1] = q.e0 * h3[1] + q.Fn[4]; Hn[2] = q.e0 * h3[2] + q.Fn[5];     // :1048-1050
+    mat3_mul(q.T2i, Hn, tmp);
+    mat3_mul(tmp, q.T1, H);
     for (int i = 0; i < 9; ++i) if (!std::isfinite(H[i])) return false;
     return true;
+}
+
+} // namespace
+
+bool Homography3PTLinear(const double* pts1, const double* pts2, int n, const double F[9], double H[9])
+{
+    Normalised3PT q;
+    solve_normalised_3pt(pts1, pts2, n, F, q);
+    return assemble_3pt(q, q.h3, H);
 }
 
 // ---- LM refinement of the 3-point homography ------------------------------------------------
@@ -251,22 +310,6 @@ struct Lm3 {
         }
     }
 };
-
-// x = pinv(A) b through the symmetric eigen-decomposition (cv::solve(..., DECOMP_EIG) /
-// cv::invert(..., DECOMP_EIG)): eigenvalues below 2*eps*sum|w| are dropped.
-void eig_pinv3(const double A[9], double P[9])
-{
-    double a[9], v[9], w[3];
-    std::memcpy(a, A, sizeof(a));
-    jacobi3(a, v, w);
-    const double thr = 2 * 2.220446049250313e-16 * (std::fabs(w[0]) + std::fabs(w[1]) + std::fabs(w[2]));
-    for (int i = 0; i < 9; ++i) P[i] = 0.0;
-    for (int k = 0; k < 3; ++k) {
-        if (!(std::fabs(w[k]) > thr)) continue;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) P[3 * i + j] += v[3 * i + k] * v[3 * j + k] / w[k];
-    }
-}
 
 void atA_atb(const std::vector<double>& J, const std::vector<double>& r, int rows, double A[9], double v[3])
 {
@@ -300,8 +343,7 @@ int lm_run3(const Lm3& cb, double x[3], int max_iters)
         double Ap[9], P[9], d[3], xd[3];
         std::memcpy(Ap, A, sizeof(Ap));
         for (int i = 0; i < 3; ++i) Ap[4 * i] += lambda * D[i];
-        eig_pinv3(Ap, P);
-        for (int i = 0; i < 3; ++i) d[i] = P[3 * i] * v[0] + P[3 * i + 1] * v[1] + P[3 * i + 2] * v[2];
+        sym_eig_solve3(Ap, v, d, nullptr);                          // solve(Ap, v, d, DECOMP_EIG), :806
         for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
         cb.compute(xd, rd, nullptr);
         const double Sd = sumsq(rd);
@@ -318,7 +360,7 @@ int lm_run3(const Lm3& cb, double x[3], int max_iters)
             double nu = (Sd - S) / (std::fabs(t) > DEPS ? t : 1) + 2;
             nu = std::min(std::max(nu, 2.), 10.);
             if (lambda == 0) {
-                eig_pinv3(A, P);
+                sym_eig_solve3(A, nullptr, nullptr, P);               // invert(A, Ap, DECOMP_EIG), :830
                 double maxval = DEPS;
                 for (int i = 0; i < 3; ++i) maxval = std::max(maxval, std::fabs(P[4 * i]));
                 lambda = lc = 1. / maxval;
@@ -345,42 +387,17 @@ bool Homography3PT(const double* pts1, const double* pts2, int n, const double F
                    bool do_numerical_refinement, int* iterations)
 {
     if (iterations) *iterations = 0;
-    if (!do_numerical_refinement) return Homography3PTLinear(pts1, pts2, n, F, H);
-    // Same normalised system as Homography3PTLinear, kept so that the refinement runs where the
-    // reference runs it: on norm_pts1/norm_pts2 with the normalised F and epipole (:1052-1054).
-    std::vector<double> p1, p2;
-    double T1[9], T1i[9], T2[9], T2i[9];
-    normalize_points(pts1, n, p1, T1, T1i);
-    normalize_points(pts2, n, p2, T2, T2i);
-    double T2it[9], tmp[9], Fn[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2it[3 * i + j] = T2i[3 * j + i];
-    mat3_mul(T2it, F, tmp);
-    mat3_mul(tmp, T1i, Fn);
-    double FFt[9], Fnt[9], v[9], dd[3];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fnt[3 * i + j] = Fn[3 * j + i];
-    mat3_mul(Fn, Fnt, FFt);
-    jacobi3(FFt, v, dd);
-    int jm = 0;
-    for (int j = 1; j < 3; ++j) if (dd[j] < dd[jm]) jm = j;
-    const double e0 = v[0 * 3 + jm] / v[2 * 3 + jm], e1 = v[1 * 3 + jm] / v[2 * 3 + jm];
-    // linear start: de-normalised result of the linear solver, pulled back to the normalised frame
-    double Hl[9];
-    if (!Homography3PTLinear(pts1, pts2, n, F, Hl)) return false;
-    double Hn[9];
-    mat3_mul(T2, Hl, tmp);
-    mat3_mul(tmp, T1i, Hn);
-    double h3[3] = { Hn[6], Hn[7], Hn[8] };
-    Lm3 cb{ p1.data(), p2.data(), n, Fn, e0, e1 };
-    const int it = lm_run3(cb, h3, 1000);
-    if (iterations) *iterations = it;
-    double Hr[9];
-    Hr[6] = h3[0]; Hr[7] = h3[1]; Hr[8] = h3[2];
-    Hr[3] = e1 * h3[0] - Fn[0]; Hr[4] = e1 * h3[1] - Fn[1]; Hr[5] = e1 * h3[2] - Fn[2];   // 3PTCallback.h:46-51
-    Hr[0] = e0 * h3[0] + Fn[3]; Hr[1] = e0 * h3[1] + Fn[4]; Hr[2] = e0 * h3[2] + Fn[5];
-    mat3_mul(T2i, Hr, tmp);
-    mat3_mul(tmp, T1, H);
-    for (int i = 0; i < 9; ++i) if (!std::isfinite(H[i])) return false;
-    return true;
+    // The refinement runs where the reference runs it (:1052-1054): on norm_pts1 / norm_pts2 with the normalised F and
+    // epipole, starting from the third row of the normalised H as the linear solve left it.
+    Normalised3PT q;
+    solve_normalised_3pt(pts1, pts2, n, F, q);
+    double h3[3] = { q.h3[0], q.h3[1], q.h3[2] };
+    if (do_numerical_refinement) {
+        Lm3 cb{ q.p1.data(), q.p2.data(), n, q.Fn, q.e0, q.e1 };
+        const int it = lm_run3(cb, h3, 1000);
+        if (iterations) *iterations = it;
+    }
+    return assemble_3pt(q, h3, H);                                                       // 3PTCallback.h:46-51, :1054
 }
 
 // ---- HomographyCompatibilityCheck ----------------------------------------------------------
@@ -642,10 +659,51 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
     return kept;
 }
 
+int MergeCandidates(const double* H, int nh, const double F[9], double thr_h, uint64_t seed, std::vector<double>* feat_out,
+                    std::vector<double>* modes_out, std::vector<double>& cand, std::vector<int>* cand_mode, uint64_t* draws)
+{
+    std::vector<double> feat(6 * (size_t)nh);
+    HomographyFeatures(H, nh, feat.data());
+    MeanShiftResult ms;
+    MeanShiftCluster(feat.data(), nh, 6, thr_h, seed, ms, draws);
+    const int k = static_cast<int>(ms.members.size());
+    cand.clear();
+    if (cand_mode) cand_mode->clear();
+    const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                        // :408
+    for (int i = 0; i < k; ++i) {
+        double Hc[9];
+        if (Homography3PT(pts1, &ms.modes[6 * (size_t)i], 3, F, Hc, true)) {            // :427
+            cand.insert(cand.end(), Hc, Hc + 9);
+            if (cand_mode) cand_mode->push_back(i);
+        }
+    }
+    if (feat_out) *feat_out = std::move(feat);
+    if (modes_out) *modes_out = std::move(ms.modes);
+    return static_cast<int>(cand.size() / 9);
+}
+
 } // namespace multih
 
 // ---- C hooks for the CPU-side tests (no GPU needed) ----------------------------
 extern "C" {
+
+// MergeCandidates for tests: feat nh x 6, modes up to nh x 6 (*n_modes of them), cand up to nh x 9, cand_mode up to nh.
+__attribute__((visibility("default")))
+int mhh_merge_candidates(const double* H, int nh, const double* F, double thr_h, unsigned long long seed, double* feat,
+                         double* modes, int* n_modes, double* cand, int* cand_mode, unsigned long long* draws)
+{
+    std::vector<double> f, m, c;
+    std::vector<int> cm;
+    uint64_t d = 0;
+    const int nc = multih::MergeCandidates(H, nh, F, thr_h, seed, &f, &m, c, &cm, &d);
+    std::copy(f.begin(), f.end(), feat);
+    std::copy(m.begin(), m.end(), modes);
+    *n_modes = (int)(m.size() / 6);
+    std::copy(c.begin(), c.end(), cand);
+    std::copy(cm.begin(), cm.end(), cand_mode);
+    if (draws) *draws = d;
+    return nc;
+}
 
 __attribute__((visibility("default")))
 void mhh_homography_features(const double* H, int nh, double* feat) { multih::HomographyFeatures(H, nh, feat); }

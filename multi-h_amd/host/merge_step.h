@@ -45,6 +45,15 @@ bool Homography3PTLinear(const double* pts1, const double* pts2, int n, const do
 bool Homography3PT(const double* pts1, const double* pts2, int n, const double F[9], double H[9],
                    bool do_numerical_refinement, int* iterations = nullptr);
 
+// The host half of MergingStep (M/MultiH.cpp:352-428): 6-D features of the nh models (:364-390), their mean-shift
+// modes at band width thr_h (:394-397), and one LM-refined 3-point homography per mode from the images of (0,0), (1,0),
+// (0,1) (:408-427).  feat (nh x 6) and modes (k x 6) are outputs for tests (nullable / may be ignored); cand receives
+// 9 doubles per mode whose fit succeeded, cand_mode (nullable) the mode each candidate came from.  Returns the number
+// of candidates.  The N x candidates scoring and the collinearity filter (:430-463) are the engine's.
+int MergeCandidates(const double* H /* nh x 9 */, int nh, const double F[9], double thr_h, uint64_t seed,
+                    std::vector<double>* feat, std::vector<double>* modes, std::vector<double>& cand,
+                    std::vector<int>* cand_mode = nullptr, uint64_t* draws = nullptr);
+
 // HomographyCompatibilityCheck (M/MultiH.cpp:100-222): per cluster 501 trials of {3 random cluster
 // points -> GetHomography3PT without refinement -> median squared transfer error of the remaining
 // points}; a cluster whose median-of-medians exceeds thr^2*81/16, or that has fewer than

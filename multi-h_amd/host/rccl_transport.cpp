@@ -6,9 +6,12 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
+
+#include <unistd.h>
 
 struct mhr_comm {
     ncclComm_t comm = nullptr;
@@ -60,10 +63,13 @@ int mhr_init_from_file(mhr_comm** out, int rank, int world, const char* path, in
     unsigned char id[MHR_ID_BYTES];
     if (rank == 0) {
         if (mhr_unique_id(id)) return 1;
-        const std::string tmp = std::string(path) + ".tmp";
-        FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(id, 1, MHR_ID_BYTES, f) != MHR_ID_BYTES) { if (f) std::fclose(f); return fail("write", tmp.c_str()); }
-        std::fclose(f);
+        // a private temporary next to `path`, created exclusively (never through a planted link), then renamed over it
+        std::string tmp = std::string(path) + ".XXXXXX";
+        const int fd = mkstemp(&tmp[0]);
+        if (fd < 0) return fail("mkstemp", tmp.c_str());
+        const bool ok = write(fd, id, MHR_ID_BYTES) == (ssize_t)MHR_ID_BYTES;
+        close(fd);
+        if (!ok) { unlink(tmp.c_str()); return fail("write", tmp.c_str()); }
         if (std::rename(tmp.c_str(), path) != 0) return fail("rename", path);      // readers see the whole id or nothing
     } else {
         const auto t0 = std::chrono::steady_clock::now();

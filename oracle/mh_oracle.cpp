@@ -1444,7 +1444,13 @@ static int mean_shift_reference_order(const double* data, int n, int d, double b
                 }
             }
             if (members == 0) { visited[st] = 1; break; }            // deviation: no row captured -> the climb ends
-            for (int j = 0; j < d; ++j) mean[j] = sum[j] / (double)members;    // :96
+            // :96 `myMean = myMean / inInds.size()` is cv::Mat / double, which OpenCV evaluates as a SCALE by the
+            // reciprocal: operator/(const Mat&, double) builds MatOp_AddEx(a, alpha = 1./s) and the assignment is
+            // a.convertTo(m, type, alpha), i.e. every element is src * (1/s) — not src / s (OpenCV 3.1.0 core/matop.cpp,
+            // outside /root/reference: restated from the published source, unpinnable here).  Product and oracle both
+            // multiply by the reciprocal (r04: until r03 this line divided).
+            const double inv_members = 1.0 / (double)members;
+            for (int j = 0; j < d; ++j) mean[j] = sum[j] * inv_members;
             double nrm = 0.0;
             for (int j = 0; j < d; ++j) { const double r = mean[j] - old[j]; nrm = nrm + r * r; }
             if (sqrt(nrm) < stop) {                                  // :98
@@ -1693,18 +1699,41 @@ MHO_API int mho_homography_3pt(const double* p1, const double* p2, int n, const 
 
 // MergingStep, M/MultiH.cpp:352-471.  H: Nh*9 in; kept: capacity >= Nh*9 (the modes that survive).  Returns the number
 // of kept candidates; *changed = (that number != Nh).  The caller replaces its model set only when changed (:468-470).
+// The host half of MergingStep (M/MultiH.cpp:352-428) for tests: features (:364-390), modes (:394-397), one 3-point
+// homography per mode (:408-427).  feat: Nh x 6; modes: up to Nh x 6, *n_modes of them; cand: up to Nh x 9 (9 per mode
+// whose fit succeeded), cand_mode: the mode each came from.  Returns the number of candidates.
+MHO_API int mho_merge_candidates(const double* H, int Nh, const double* F, double thr_h, uint64_t seed, double* feat,
+                                 double* modes_out, int* n_modes, double* cand, int* cand_mode, uint64_t* draws)
+{
+    std::vector<double> modes;
+    for (int i = 0; i < Nh; ++i) homography_feature(H + 9 * (size_t)i, feat + 6 * (size_t)i);
+    const int k = mean_shift_reference_order(feat, Nh, 6, thr_h, seed, modes, draws);            // :394-397
+    for (size_t q = 0; q < modes.size(); ++q) modes_out[q] = modes[q];
+    *n_modes = k;
+    const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                                // :408
+    int nc = 0;
+    for (int i = 0; i < k; ++i) {
+        double Hc[9];
+        if (!homography_3pt(pts1, &modes[6 * (size_t)i], 3, F, Hc, true)) continue;             // :427
+        for (int q = 0; q < 9; ++q) cand[9 * (size_t)nc + q] = Hc[q];
+        cand_mode[nc++] = i;
+    }
+    return nc;
+}
+
+// MergingStep, M/MultiH.cpp:352-471.  H: Nh*9 in; kept: capacity >= Nh*9 (the modes that survive).  Returns the number
+// of kept candidates; *changed = (that number != Nh).  The caller replaces its model set only when changed (:468-470).
 MHO_API int mho_merging_step(const double* x1, const double* y1, const double* x2, const double* y2, int N,
                              const double* H, int Nh, const double* F, double thr_h, double straightness,
                              uint64_t seed, double* kept /* up to Nh*9 */, int* changed, uint64_t* draws)
 {
-    std::vector<double> feat(6 * (size_t)Nh), modes;
-    for (int i = 0; i < Nh; ++i) homography_feature(H + 9 * (size_t)i, &feat[6 * (size_t)i]);
-    const int k = mean_shift_reference_order(feat.data(), Nh, 6, thr_h, seed, modes, draws);     // :394-397
-    const double pts1[6] = { 0, 0, 1, 0, 0, 1 };                                                // :408
+    std::vector<double> feat(6 * (size_t)Nh), modes(6 * (size_t)Nh), cand(9 * (size_t)Nh);
+    std::vector<int> cand_mode(Nh);
+    int k = 0;
+    const int nc = mho_merge_candidates(H, Nh, F, thr_h, seed, feat.data(), modes.data(), &k, cand.data(), cand_mode.data(), draws);
     int nk = 0;
-    for (int i = 0; i < k; ++i) {
-        double Hc[9];
-        if (!homography_3pt(pts1, &modes[6 * (size_t)i], 3, F, Hc, true)) continue;             // :427
+    for (int i = 0; i < nc; ++i) {
+        const double* Hc = &cand[9 * (size_t)i];
         double mom[6], mineig = 0.0;
         mho_inlier_moments(x1, y1, x2, y2, N, Hc, 1, thr_h * thr_h, mom, &mineig);              // :430-461
         if (mineig < straightness || (int)mom[0] < 3) continue;                                 // :462

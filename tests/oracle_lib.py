@@ -424,3 +424,15 @@ def ref_expand_formula(src, dst, H, lam, thr2, rowptr, col, init_labels=None):
     e = r.ref_gco_expand_formula(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0],
                                  C.c_double(lam), C.c_double(thr2), _i(rowptr), _i(col), init, _i(out))
     return out, int(e)
+
+
+def merge_candidates(H, F, thr_h, seed):
+    """mho_merge_candidates: (features [Nh,6], modes [k,6], candidates [nc,9], the mode of each candidate, draws)."""
+    H = f64(H).reshape(-1, 9)
+    nh = H.shape[0]
+    feat, modes, cand = np.zeros((nh, 6)), np.zeros((nh, 6)), np.zeros((nh, 9))
+    cand_mode = np.zeros(nh, dtype=np.int32)
+    k, draws = C.c_int(0), C.c_ulonglong(0)
+    nc = lib().mho_merge_candidates(_d(H), nh, _d(f64(F).reshape(9)), C.c_double(thr_h), C.c_ulonglong(seed), _d(feat), _d(modes),
+                                    C.byref(k), _d(cand), _i(cand_mode), C.byref(draws))
+    return feat, modes[:k.value].copy(), cand[:nc].copy(), cand_mode[:nc].copy(), int(draws.value)

@@ -192,3 +192,29 @@ def test_radius_list_beyond_its_bound_falls_back_to_the_nearest_hits(mh, engine_
     assert "exceed the limit" in out and "nearest hits instead" in out
     assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[3] == want[3] and got[4] == want[4]
     assert np.array_equal(got[2], want[2])
+
+
+def test_one_merging_step_equals_the_oracles_bit_for_bit(mh, engine, synth, oracle):
+    """one whole MergingStep of the product — host candidates (features, modes, 3-point fits), then
+    the N x candidates scoring and the collinearity filter on the GPU — against mho_merging_step: the kept homographies
+    equal in every bit, `changed` and the number of RNG draws equal, on scenes where the mean shift merges copies and
+    the filter drops strays."""
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    dp = C.POINTER(C.c_double)
+    changed_seen = set()
+    for seed, (dup, strays) in enumerate([(4, 0), (6, 2), (0, 3), (0, 0), (9, 1)]):
+        sc = synth.make_scene(3000, 4, seed=40 + seed, with_neighbours=False)
+        H0 = _initial_models(sc, seed, dup, strays)
+        engine.set_correspondences(sc.src, sc.dst, sc.aff)
+        F = np.ascontiguousarray(sc.F)
+        kept = np.zeros_like(H0)
+        changed, draws = C.c_int(-1), C.c_ulonglong(0)
+        nk = host.mhh_merging_step(engine._h, H0.ctypes.data_as(dp), H0.shape[0], F.ctypes.data_as(dp), C.c_double(THR),
+                                   C.c_double(0.005), C.c_ulonglong(1000 + seed), kept.ctypes.data_as(dp), C.byref(changed),
+                                   C.byref(draws))
+        assert nk >= 0, mh.load_library().mh_last_error()
+        want, want_changed, want_draws = oracle.merging_step(sc.src, sc.dst, H0, F, THR, 1000 + seed)
+        assert nk == want.shape[0] and bool(changed.value) == want_changed and int(draws.value) == want_draws, seed
+        assert np.array_equal(kept[:nk].view(np.uint64), want.view(np.uint64)), seed
+        changed_seen.add(want_changed)
+    assert changed_seen == {True, False}

@@ -240,3 +240,118 @@ def test_fp32_pretest_with_thresholds_exactly_on_residual_values(engine, synth, 
                 assert np.array_equal(cnt, want), (m, int(i), float(thr2))
                 tried += 1
     assert tried >= 60
+
+
+@pytest.mark.parametrize("transport", ["none", "rccl-one-rank"])
+def test_select_best_off_the_critical_path(mh, engine, synth, transport):
+    """r04: an enqueue-only mh_select_best runs its (all-gather +) arg-max on a third stream behind an event of the
+    sweep; the next sweep starts at once into the engine's other counts buffer.  Several pipelined steps without a
+    single host wait, then one fetch: every step's winner is the one a synchronous propose + score + arg-max finds, the
+    scores the exchange read are the batch's own (no padding kernel), and a scoring call after an enqueue-only call
+    lands in a buffer the pending exchange does not read."""
+    sc = synth.make_scene(3000, 3, seed=18, with_neighbours=False)
+    _load(engine, sc)
+    sizes = (901, 901, 640, 1200, 1200, 333)
+    want = []
+    for i, m in enumerate(sizes):
+        engine.propose_dlt4(5, 5000 * i, m)
+        cnt = engine.score(THR2)
+        want.append((int(np.argmax(cnt)), int(cnt.max())))
+    comm = rl = None
+    if transport != "none":
+        rl = _rccl(mh)
+        uid = (C.c_ubyte * 128)()
+        assert rl.mhr_unique_id(uid) == 0, rl.mhr_last_error()
+        comm = C.c_void_p()
+        assert rl.mhr_init(C.byref(comm), 0, 1, uid, 0) == 0, rl.mhr_last_error()
+        engine.set_transport(0, 1, stream_fn=rl.mhr_allgather, ctx=comm)
+    try:
+        # (a) read every step's result: the fetch completes the pending exchange, it does not start a new one
+        engine.prefetch_dlt4(5, 0, sizes[0])
+        for i, m in enumerate(sizes):
+            engine.adopt_prefetched()
+            if i + 1 < len(sizes):
+                engine.prefetch_dlt4(5, 5000 * (i + 1), sizes[i + 1])
+            engine.residual_matrix(THR2, fetch_R=False, fetch_counts=False)
+            before = rl.mhr_calls(comm) if comm else 0
+            assert engine.select_best(m, fetch=False) is None
+            assert engine.select_best(m) == want[i], i
+            if comm:
+                assert rl.mhr_calls(comm) - before == 1, "the fetch must not run a second collective"
+        # (b) no host wait at all between the steps; only the last result is read
+        engine.prefetch_dlt4(5, 0, sizes[0])
+        for i, m in enumerate(sizes):
+            engine.adopt_prefetched()
+            if i + 1 < len(sizes):
+                engine.prefetch_dlt4(5, 5000 * (i + 1), sizes[i + 1])
+            engine.residual_matrix(THR2, fetch_R=False, fetch_counts=False)
+            last = engine.select_best(m, fetch=(i + 1 == len(sizes)))
+        assert last == want[-1]
+        # (c) scoring right behind an enqueue-only call: the sweep's counts must be intact when the exchange reads them
+        engine.propose_dlt4(5, 0, sizes[0])
+        engine.residual_matrix(THR2, fetch_R=False, fetch_counts=False)
+        engine.select_best(sizes[0], fetch=False)
+        engine.propose_dlt4(5, 5000, sizes[1])              # another batch, scored into the other buffer at once
+        cnt1 = engine.score(THR2)
+        assert (int(np.argmax(cnt1)), int(cnt1.max())) == want[1]
+        engine.synchronize()                                # completes the pending exchange of batch 0
+        assert engine.select_best(sizes[1]) == want[1]
+        # a model set that has never been scored has no best model
+        engine.propose_dlt4(5, 10000, 77)
+        with pytest.raises(mh.MultiHError) as ei:
+            engine.select_best(77)
+        assert ei.value.code == -4
+    finally:
+        engine.set_transport(0, 1)
+        if comm:
+            rl.mhr_destroy(comm)
+
+
+def test_new_correspondences_drop_a_prefetched_batch(mh, engine, synth):
+    """r03 advisor finding: mh_set_correspondences waits for a DLT prefetch in flight on the second stream (it reads the
+    point arrays the call overwrites) and drops the batch — it was sampled from the old point set."""
+    a = synth.make_scene(3000, 3, seed=1, with_neighbours=False)
+    b = synth.make_scene(3000, 3, seed=2, with_neighbours=False)
+    _load(engine, a)
+    engine.prefetch_dlt4(9, 0, 20000)
+    engine.set_correspondences(b.src, b.dst, b.aff)          # same n: only the prefetch state can tell
+    with pytest.raises(mh.MultiHError) as ei:
+        engine.adopt_prefetched()
+    assert ei.value.code == -4
+    engine.prefetch_dlt4(9, 0, 512)
+    engine.adopt_prefetched()
+    got = engine.get_models()
+    engine.propose_dlt4(9, 0, 512)
+    assert np.array_equal(got.view(np.uint64), engine.get_models().view(np.uint64))
+
+
+def test_resident_sweep_beside_a_prefetch_equals_the_dispatched_sweep(engine, synth, oracle):
+    """r04: while a DLT prefetch is pending the materialising sweep runs as a resident grid that strides over the
+    (model block, point slice) items and leaves workgroup slots free for the DLT (k_residual_resident).  Same matrix,
+    same counts, bit for bit, as the hardware-dispatched launch — for several headrooms, a ragged model count and a point
+    count that is not a multiple of the tile."""
+    sc = synth.make_scene(20011, 4, seed=23, with_neighbours=False)
+    _load(engine, sc)
+    M = 6007
+    engine.propose_dlt4(41, 0, M)
+    engine.set_tuning(19, -1)                              # reference: one hardware-dispatched workgroup per item
+    _, cnt_ref = engine.residual_matrix(THR2, fetch_R=False)
+    rows = [0, 1, 15, 16, 3000, M - 1]
+    R_ref = np.stack([engine.get_residual_rows(r, 1)[0] for r in rows])
+    H = engine.get_models()
+    with np.errstate(all="ignore"):
+        want = oracle.residual_matrix(sc.src, sc.dst, H[rows])
+    ok = ~np.isnan(want)
+    assert np.array_equal(R_ref[ok].view(np.uint64), want[ok].view(np.uint64))
+    try:
+        for headroom in (64, 0, 700, -1):
+            engine.set_tuning(19, headroom)
+            engine.prefetch_dlt4(41, 0, M)                # pending: the sweep below is held until the DLT has been dispatched
+            _, cnt = engine.residual_matrix(THR2, fetch_R=False)
+            R = np.stack([engine.get_residual_rows(r, 1)[0] for r in rows])
+            assert np.array_equal(cnt, cnt_ref), headroom
+            assert np.array_equal(R.view(np.uint64), R_ref.view(np.uint64)), headroom
+            engine.adopt_prefetched()
+            assert np.array_equal(engine.get_models().view(np.uint64), H.view(np.uint64))
+    finally:
+        engine.set_tuning(19, 0)

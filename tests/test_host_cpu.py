@@ -333,3 +333,61 @@ def test_oracle_greedy_selection_known_answer(synth, oracle):
     assert mask.sum() == sc.n - cnt.sum()
     full = oracle.score(sc.src, sc.dst, H, 2.2 ** 2)
     assert cnt[0] == full[idx[0]]
+
+
+def _merge_scene(synth, seed):
+    """Models of a MergingStep in which the mean shift has something to merge: each true plane in 1..7 slightly perturbed
+    copies (clusters of 3, 5, 6, 7 members: sizes for which x / n and x * (1 / n) round differently), shuffled."""
+    rng = np.random.default_rng(seed)
+    K = int(rng.integers(2, 7))
+    sc = synth.make_scene(600, K, seed=seed, with_neighbours=False)
+    Hs = []
+    for k in range(K):
+        for _ in range(int(rng.integers(1, 8))):
+            Hs.append(sc.H_true[k] * (1 + rng.normal(0, 2e-5, 9)))
+    H = np.ascontiguousarray(np.array(Hs))
+    return sc, np.ascontiguousarray(H[rng.permutation(len(H))])
+
+
+def _host_merge_candidates(host, H, F, thr_h, seed):
+    nh = H.shape[0]
+    feat, modes, cand = np.zeros((nh, 6)), np.zeros((nh, 6)), np.zeros((nh, 9))
+    cand_mode = np.zeros(nh, np.int32)
+    k, draws = C.c_int(0), C.c_ulonglong(0)
+    nc = host.mhh_merge_candidates(H.ctypes.data_as(_dp), nh, F.ctypes.data_as(_dp), C.c_double(thr_h), C.c_ulonglong(seed),
+                                   feat.ctypes.data_as(_dp), modes.ctypes.data_as(_dp), C.byref(k), cand.ctypes.data_as(_dp),
+                                   cand_mode.ctypes.data_as(C.POINTER(C.c_int)), C.byref(draws))
+    return feat, modes[:k.value].copy(), cand[:nc].copy(), cand_mode[:nc].copy(), int(draws.value)
+
+
+def test_merging_step_candidates_equal_the_oracles_bit_for_bit(host, oracle, synth):
+    """the host half of MergingStep (M/MultiH.cpp:352-428) — 6-D features, mean-shift modes
+    in the reference's summation order with `myMean / inInds.size()` as OpenCV evaluates it (a scale by the reciprocal,
+    MeanShiftClustering.h:96), one LM-refined 3-point homography per mode in the operation order of GetHomography3PT —
+    is the same arithmetic in the product (host/merge_step.cpp) and in the oracle (oracle/mh_oracle.cpp section 11): every
+    double equal, on scenes whose clusters have sizes for which the division and the scale differ."""
+    differing = 0
+    for seed in range(24):
+        sc, H = _merge_scene(synth, seed)
+        F = np.ascontiguousarray(sc.F)
+        want = oracle.merge_candidates(H, F, 2.2, 7 * seed + 1)
+        got = _host_merge_candidates(host, H, F, 2.2, 7 * seed + 1)
+        for name, a, b in zip(("features", "modes", "candidates"), want[:3], got[:3]):
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (seed, name)
+        assert np.array_equal(want[3], got[3]) and want[4] == got[4], seed
+        assert len(want[1]) < len(H), "the scene should merge something"
+        # does this scene tell the two roundings of :96 apart?  (members of a mode in row order, as :85-96 adds them)
+        feat = want[0]
+        assign = np.zeros(len(H), np.int32)
+        modes = np.zeros((len(H), 6))
+        host.mhh_mean_shift(feat.ctypes.data_as(_dp), len(H), 6, C.c_double(2.2), C.c_ulonglong(7 * seed + 1),
+                            modes.ctypes.data_as(_dp), len(H), assign.ctypes.data_as(C.POINTER(C.c_int)), None)
+        for c in range(len(want[1])):
+            rows = feat[assign == c]
+            if len(rows) == 0:
+                continue
+            s = np.zeros(6)
+            for r in rows:
+                s = s + r
+            differing += int(np.any(s / len(rows) != s * (1.0 / len(rows))))
+    assert differing >= 5, "the scenes must contain clusters for which x / n and x * (1 / n) differ"
