@@ -943,6 +943,9 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
                             r[q] = nb[q] >= 0 ? c0[q] - so[q] + r[q] : 0;
                             if (r[q] > 0 && hq[q] < hu) D += r[q];
                         }
+                        static_assert(SLPN == 8, "the prefix below is row_shr 1, 2, 4: complete for rows of 8 lanes only (16 would need a row_shr 8 step)");
+                        // (the lanes of a row are convergent here and at every row_min / row_sum: the DPP moves use bound_ctrl,
+                        // a lane switched off by EXEC would read as 0)
                         int incl = D;                               // prefix over the row's lanes: row_shr 1, 2, 4
                         { const int y = dpp_mov<0x111>(incl); if (sub >= 1) incl += y; }
                         { const int y = dpp_mov<0x112>(incl); if (sub >= 2) incl += y; }

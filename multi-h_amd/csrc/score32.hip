@@ -217,13 +217,24 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
 // k_cost32 — the materialised int32 data-cost matrix (k_cost_matrix of datacost.hip: the s = 4 variant of SURVEY 8(d))
 // behind the same pre-test.  dataEnergy (M/MultiH.cpp:473-504) of a pair whose d2 is at least T = thr^2 81/16 is the
 // constant 2 round(lam T), and for a random hypothesis that is nearly every pair: the cheap test above with
-// k1 = max(2.5 x 9/4 thr, 25.4 u Cmax) proves max(|dx|, |dy|) >= 2.26 x 9/4 thr, i.e. d2 >= 5 T, per LANE; the other
-// lanes (both |dx| and |dy| within a dozen pixels, models not eligible for FP32, NaN anywhere) evaluate the reference's
+// k1 = max(1.12 x 9/4 thr, 25.4 u Cmax) (launch_cost32) proves max(|dx|, |dy|) >= 1.014 x 9/4 thr, i.e. d2 >= 1.028 T — a
+// 2.8 % margin beyond the truncation threshold — per LANE; the other lanes (both |dx| and |dy| within 1.12 x 9/4 thr, models
+// not eligible for FP32, NaN anywhere) evaluate the reference's
 // FP64 formula — fwd_d2, the IEEE division d2 / T, C round() — exactly as k_cost_matrix does.  Same matrix, same fused
 // inlier counts, bit for bit.  Measured at 50k x 100k DLT hypotheses: 7.7 -> 4.2 ms (the store stream alone would take 3.6 ms:
 // 3.3 % of the pairs of such a batch are near — hypotheses fitted to four matches are often nearly right for a whole
 // plane — and 42 % of the wave-model iterations contain one, each costing a pass through the IEEE formula).
 // ---------------------------------------------------------------------------
+// Lanes of ONE wave hand data to each other through LDS below (no workgroup barrier: the other waves are not involved).
+// The LDS operations of a wave complete in program order, so what is needed is that the COMPILER keeps the writes in front
+// of the cross-lane reads: a wave-scope release / acquire pair around a wave barrier (r03 advisor finding).
+__device__ __forceinline__ void wave_lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int MC, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
@@ -268,6 +279,7 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
             my_p[(q * 4 + 0) * 64] = px; my_p[(q * 4 + 1) * 64] = py; my_p[(q * 4 + 2) * 64] = qx; my_p[(q * 4 + 3) * 64] = qy;
             fx[q] = (float)px; fy[q] = (float)py; gx[q] = (float)qx; gy[q] = (float)qy;
         }
+        wave_lds_handover();                     // the FP64 copies are read by OTHER lanes of this wave below
 #pragma unroll 1
         for (int mi = 0; mi < MC; ++mi) {
             const int m = m0 + mi;
@@ -304,6 +316,7 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
                     }
                     npairs += __builtin_popcountll(nearq[q]);
                 }
+                wave_lds_handover();             // the list is read across lanes
                 const double* h = s_h + 9 * mi;
                 const double h0d = h[0], h1d = h[1], h2d = h[2], h3d = h[3], h4d = h[4], h5d = h[5], h6d = h[6], h7d = h[7], h8d = h[8];
                 for (int p0 = 0; p0 < npairs; p0 += 64) {
@@ -317,9 +330,11 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
                     }
                     c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in64));
                 }
+                wave_lds_handover();             // the costs go back to the lanes that own the pairs
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
                     if ((nearq[q] >> lane) & 1ull) c[q] = my_c[q * 64 + lane];
+                wave_lds_handover();             // (the next model's list and costs overwrite these)
             }
             int* dst = C + (size_t)m * ldc + n0;
             if (n0 + 3 < N) {

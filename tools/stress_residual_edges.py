@@ -42,6 +42,11 @@ while time.time() - t0 < budget:
             src = rng.uniform(0, 1000, size=(n, 2)) * rng.choice([1.0, 1.0, 1e-3, 1e-200, 0.0], size=(n, 2))
             dst = rng.uniform(0, 1000, size=(n, 2)) * rng.choice([1.0, 1.0, 1e-3, 1e-200, 0.0], size=(n, 2))
             dst[: n // 2] = src[: n // 2] + rng.normal(0, 1.5, size=(n // 2, 2))
+            # a quarter of the points sit ON the cost's truncation threshold T = thr^2 81/16 for the near-identity models:
+            # d2 in [0.97 T, 1.06 T], the band the pre-test's far proof (d2 >= 1.028 T) must not reach into (r03 advisor finding)
+            q = n // 4
+            rr = np.sqrt(thr2 * 81.0 / 16.0 * rng.uniform(0.97, 1.06, size=q)); th = rng.uniform(0, 2 * np.pi, size=q)
+            dst[n - q:] = src[n - q:] + np.stack([rr * np.cos(th), rr * np.sin(th)], axis=1)
             H[: m // 2] = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1.0]) + rng.normal(0, 1e-3, size=(m // 2, 9)) * np.array([1, 1, 100, 1, 1, 100, 1e-3, 1e-3, 1])
             e.set_correspondences(src, dst); e.set_models(H)
         with np.errstate(all="ignore"):
