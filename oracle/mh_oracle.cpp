@@ -1842,7 +1842,14 @@ MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* 
     int selected = 0;
     std::vector<int> counts(M);
     for (int round = 0; round < max_models; ++round) {
-        mho_score(x1, y1, x2, y2, N, H, M, thr2, mask, counts.data());
+        // the score of :430-443 for every hypothesis over the support set; the hypotheses are independent, so a large
+        // batch is spread over the host's cores (integer counts: the same whatever the number of threads) — at BASELINE
+        // configs[4] size, 100 000 x 50 000 pairs per round, one core would need 8.5 s per round
+        if ((long long)M * N >= 100000000ll) {
+#pragma omp parallel for schedule(static)
+            for (int m = 0; m < M; ++m) mho_score(x1, y1, x2, y2, N, H + 9 * (size_t)m, 1, thr2, mask, &counts[m]);
+        } else
+            mho_score(x1, y1, x2, y2, N, H, M, thr2, mask, counts.data());
         int best = -1, bm = -1;
         for (int m = 0; m < M; ++m) if (counts[m] > best) { best = counts[m]; bm = m; }
         if (bm < 0 || best < need) break;

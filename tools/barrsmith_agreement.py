@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Quantitative agreement with the ONE output the reference ships: Executable/results/barrsmith/
+result_barrsmith.txt holds the 1 094 correspondences the reference kept of the 2 903 in barrsmith_points_with_no_annotation.txt
+(both stored as arrays in tests/golden/barrsmith.npz) and the label it gave each: -1 (182), planes 0..4 (33, 514, 128, 83,
+154).  The result file carries x1 y1 twice (quirk A-9), so each row is matched back to the input by (x1, y1) — and, where
+several input matches share that source point, by the closest affinity — to recover x2 y2 and the input affinity.  EXACTLY
+those correspondences then go through Process() with the harness defaults (M/main.cpp:55-59: 2.6 / 2.2 / 0.005 / 0.5 / 20):
+F by the engine's own 8-point RANSAC on them (cv::findFundamentalMat is outside /root/reference), then
+  (i)  the reference's own route: INIT_STABLE_SETS (per-point HAF homographies, mean shift, 3-point fits), and
+  (ii) the default route: DLT proposals + greedy selection,
+each with the post-filter on, as the harness runs it.  Reported: number of planes, adjusted Rand index against the
+reference's labels (all points with -1 as a class of its own; and on the reference's non-outliers only), per-plane purity
+(share of a reference plane's points under our dominant label for it) and the outlier agreement.  The reference's run
+is not bit-reproducible (OpenCV RANSAC + FLANN + MSVC rand()), so this is agreement, not parity."""
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+mh = importlib.import_module("multi-h_amd")
+
+
+def kept_correspondences():
+    """(x1 y1 x2 y2 a11 a12 a21 a22) of the reference's 1 094 kept correspondences, in result-file order, and their labels."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "barrsmith.npz"))
+    pts, res = g["points"], g["result"]
+    by_key = {}
+    for i, (a, b) in enumerate(pts[:, :2]):
+        by_key.setdefault((round(a, 3), round(b, 3)), []).append(i)
+    used, rows = set(), []
+    for r in res:
+        cand = [i for i in by_key.get((round(r[0], 3), round(r[1], 3)), []) if i not in used]
+        if not cand:
+            rows.append(-1)
+            continue
+        best = min(cand, key=lambda i: float(np.abs(pts[i, 4:8] - r[4:8]).sum()))
+        used.add(best)
+        rows.append(best)
+    rows = np.asarray(rows)
+    ok = rows >= 0
+    return pts[rows[ok]], res[ok, 8].astype(int), int(ok.sum()), int(len(res))
+
+
+def adjusted_rand(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    _, ai = np.unique(a, return_inverse=True)
+    _, bi = np.unique(b, return_inverse=True)
+    n = a.size
+    cont = np.zeros((ai.max() + 1, bi.max() + 1), dtype=np.int64)
+    np.add.at(cont, (ai, bi), 1)
+    comb = lambda x: x * (x - 1) // 2
+    s_ij, s_a, s_b = comb(cont).sum(), comb(cont.sum(1)).sum(), comb(cont.sum(0)).sum()
+    exp = s_a * s_b / comb(n)
+    mx = 0.5 * (s_a + s_b)
+    return float((s_ij - exp) / (mx - exp)) if mx != exp else 1.0
+
+
+def agreement(ours, ref):
+    out = {"planes": int(ours.max() + 1), "ours_histogram": np.bincount(ours + 1).tolist(), "ari_all": adjusted_rand(ours, ref)}
+    inl = ref >= 0
+    out["ari_reference_inliers"] = adjusted_rand(ours[inl], ref[inl])
+    both = inl & (ours >= 0)
+    out["ari_points_both_assign_to_a_plane"] = adjusted_rand(ours[both], ref[both])
+    pur = {}
+    for p in np.unique(ref[inl]):
+        mine = ours[ref == p]
+        vals, cnts = np.unique(mine, return_counts=True)
+        pur[int(p)] = {"points": int(mine.size), "dominant_label": int(vals[np.argmax(cnts)]), "purity": float(cnts.max() / mine.size)}
+    out["per_reference_plane"] = pur
+    out["outliers_agreeing"] = float(((ours == -1) & (ref == -1)).sum() / max((ref == -1).sum(), 1))
+    out["reference_inliers_we_call_outliers"] = float(((ours == -1) & inl).sum() / inl.sum())
+    return out
+
+
+def run(route, corr, F, e2, seed=1234, hypotheses=20000):
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    dp = C.POINTER(C.c_double)
+    src, dst, aff = (np.ascontiguousarray(corr[:, a:b]) for a, b in ((0, 2), (2, 4), (4, 8)))
+    n = len(src)
+    labels = np.full(n, -7, dtype=np.int32)
+    Hout = np.zeros((256, 9))
+    it, en = C.c_int(0), C.c_double(0)
+    Fc, e2c = np.ascontiguousarray(F.reshape(9)), np.ascontiguousarray(e2)
+    host.mhh_set_post_filter(1)
+    k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n, Fc.ctypes.data_as(dp),
+                             e2c.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2), C.c_double(0.005), C.c_double(0.5), 20,
+                             C.c_ulonglong(seed), hypotheses, 32, 0, None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)),
+                             Hout.ctypes.data_as(dp), 256, C.byref(it), C.byref(en), None, 0, -1 if route == "stable_sets" else 4)
+    C.CDLL(None).fflush(None)
+    return k, labels, it.value, en.value
+
+
+def main():
+    corr, ref, matched, total = kept_correspondences()
+    e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+    e.set_correspondences(corr[:, 0:2], corr[:, 2:4], corr[:, 4:8])
+    F, e2, mask, inl = e.estimate_fundamental(1234 ^ 0xf00d, 4000, 2.6)
+    e.close()
+    rec = {"matched_rows": matched, "result_rows": total, "reference_histogram": np.bincount(ref + 1).tolist(),
+           "F_inliers_at_2.6px": int(inl), "routes": {}}
+    for route in ("stable_sets", "dlt"):
+        k, labels, it, en = run(route, corr, F, e2)
+        a = agreement(labels, ref) if k > 0 else {"planes": int(k)}
+        a.update(iterations=it, energy=en)
+        rec["routes"][route] = a
+        print(f"{route:12s}: {k} planes, ARI all {a.get('ari_all', float('nan')):.3f}, on the reference's inliers {a.get('ari_reference_inliers', float('nan')):.3f}, "
+              f"where both assign a plane {a.get('ari_points_both_assign_to_a_plane', float('nan')):.3f}; purity per reference plane "
+              + ", ".join(f"{p}:{v['purity']:.2f}" for p, v in a.get("per_reference_plane", {}).items())
+              + f"; reference outliers we also reject {a.get('outliers_agreeing', float('nan')):.2f}", flush=True)
+    print(json.dumps(rec))
+    return rec
+
+
+if __name__ == "__main__":
+    main()
