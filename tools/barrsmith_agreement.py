@@ -77,8 +77,9 @@ def agreement(ours, ref):
     return out
 
 
-def run(route, corr, F, e2, seed=1234, hypotheses=20000):
+def run(route, corr, F, e2, seed=1234, hypotheses=20000, knn=0):
     host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    host.mhh_set_neighbourhood(int(knn), C.c_double(0.0))      # 0 = the class default (16 nearest hits within 1 / locality)
     dp = C.POINTER(C.c_double)
     src, dst, aff = (np.ascontiguousarray(corr[:, a:b]) for a, b in ((0, 2), (2, 4), (4, 8)))
     n = len(src)
@@ -112,6 +113,16 @@ def main():
               f"where both assign a plane {a.get('ari_points_both_assign_to_a_plane', float('nan')):.3f}; purity per reference plane "
               + ", ".join(f"{p}:{v['purity']:.2f}" for p, v in a.get("per_reference_plane", {}).items())
               + f"; reference outliers we also reject {a.get('outliers_agreeing', float('nan')):.2f}", flush=True)
+    # sensitivity (printed, not part of the record's headline): neighbourhood size and seeds
+    if os.environ.get("SWEEP"):
+        for route in ("stable_sets", "dlt"):
+            for knn in (16, 32, 64):
+                for seed in (1234, 7, 99):
+                    k, labels, it, en = run(route, corr, F, e2, seed=seed, knn=knn)
+                    a = agreement(labels, ref)
+                    print(f"  sweep {route:12s} k-NN {knn:3d} seed {seed:5d}: {k} planes, ARI inliers {a['ari_reference_inliers']:.3f}, all {a['ari_all']:.3f}, "
+                          f"histogram {a['ours_histogram']}", flush=True)
+        run("dlt", corr, F, e2, knn=0)
     print(json.dumps(rec))
     return rec
 
