@@ -271,7 +271,8 @@ MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int*
  * relabel/push rounds that began with fewer than 64 solver rows still holding excess (the tail of a move), 20 restarts of
  * the expansion after a grid-barrier timeout (a GPU shared with other persistent launches: each restart halves the
  * solver's workgroups; results never depend on their number), 21 workgroups of the solver launch in the attempt that
- * completed, 22 moves solved inside one XCD (small cores), 23 reserved}. */
+ * completed, 22 moves solved inside one XCD (small cores), 23 the longest single wait at a grid barrier in microseconds (the give-up time of
+ * the next expansion's first attempts is max(20 ms, 50 x the longest such wait the engine has seen); only the last attempt waits 3 s)}. */
 MH_API int mh_get_expand_stats(mh_engine* e, long long stats[24]);
 /* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid

@@ -391,7 +391,7 @@ class Engine:
         return dict(zip(("cycles", "moves", "accepted", "push_phases", "relax_intervals", "host_syncs",
                          "reduce_launches", "flow_moves", "launches", "moves_run", "moves_solved",
                          "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us", "tail_us",
-                         "barrier_timeout_retries", "solver_workgroups", "xcd_local_moves", "reserved"),
+                         "barrier_timeout_retries", "solver_workgroups", "xcd_local_moves", "longest_barrier_wait_us"),
                         list(st)))
 
     def expand_trace(self, moves: int):

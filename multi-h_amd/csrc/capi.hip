@@ -152,6 +152,7 @@ struct mh_engine {
     int sweep_wg_per_cu = -1;                // workgroups of the materialising sweep a compute unit holds (-1 = not queried yet)
     int tune_sweep_headroom = 0;             // key 19: workgroup slots the resident sweep leaves free beyond its own occupancy (-1 = hardware dispatch)
     int solve_grid_max = 0;                  // workgroups of the solver launch that can be resident at once (0 = not queried yet)
+    double longest_barrier_wait_ms = 0.0;    // longest wait at a grid barrier any completed expansion of this engine has seen
     int last_expand_retries = 0;             // restarts of the last expansion after a barrier timeout (shared GPU)
     int last_solve_grid = 0;                 // workgroups of the solver launch in the attempt that completed
     int inject_select_failure = 0;           // test hook (key 18): the n-th scoring round of the coming greedy selections fails on this rank
@@ -629,6 +630,13 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         e->last_expand_retries = 0;
         for (int attempt = 0; attempt < 5; ++attempt) {
             w.solve_grid = solve_grid;
+            // How long a barrier may wait before the launch gives up and the expansion restarts with half the workgroups: a
+            // healthy barrier takes about 8 us, so max(20 ms, 50 x the longest wait this engine has seen) tells "a workgroup
+            // is not resident" from "slow" within tens of milliseconds instead of the fixed 3 s of r03; only the last
+            // attempt (or a launch already down to one workgroup) waits the full 3 s before the call fails.
+            const bool last_attempt = attempt == 4 || solve_grid == 1;
+            w.barrier_timeout_ticks = last_attempt ? 300000000ll
+                                                   : (long long)(std::max(20.0, 50.0 * e->longest_barrier_wait_ms) * 1e5);
             if (w.saved_flow) HIPCHK(hipMemsetAsync(e->ew_saved.p, 0, sizeof(int) * recycle_words, e->stream));
             HIPCHK(launch_init_labeling(e->cost.p, e->cost_L, e->n, init_dev, w.label, w.cur_cost, e->stream));
             he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
@@ -656,6 +664,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         HIPCHK(he);
     }
     e->last_expand = st;
+    if (st.max_barrier_wait_ms > e->longest_barrier_wait_ms) e->longest_barrier_wait_ms = std::min(st.max_barrier_wait_ms, 50.0);
     if (st.energy > 0x7fffffffll || st.energy < -0x7fffffffll)
         return fail(MH_ERR_OVERFLOW, "total energy exceeds the reference's int32 EnergyType");
     if (energy) *energy = st.energy;
@@ -2142,7 +2151,7 @@ int mh_get_expand_stats(mh_engine* e, long long stats[24])
     stats[20] = e->last_expand_retries;
     stats[21] = e->last_solve_grid;
     stats[22] = 0;
-    stats[23] = 0;
+    stats[23] = (long long)(e->last_expand.max_barrier_wait_ms * 1e3);
     return MH_OK;
     });
 }

@@ -88,7 +88,7 @@ enum { A_DELTA_S = 64, A_ENERGY_S = A_DELTA_S + STRIPES * STRIPE_LL, A_EXCESS_S 
        A_TOTAL = A_EXCESS_S + STRIPES * STRIPE_LL };
 static_assert(A_TOTAL <= EXPAND_ACC_WORDS, "accumulator block too small");
 enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_CORE_SUM = 3, A_OUTER = 4, A_RELAX = 5, A_PUSH = 6,
-       A_BARRIERS = 7, A_TICKS = 8, A_T_BAR = 9, A_T_RELAX = 10, A_T_PUSH = 11, A_T_TAIL = 12, A_TAIL_ROUNDS = 13, A_COUNT = 16 /* mirrored to the host */ };
+       A_BARRIERS = 7, A_TICKS = 8, A_T_BAR = 9, A_T_RELAX = 10, A_T_PUSH = 11, A_T_TAIL = 12, A_TAIL_ROUNDS = 13, A_MAX_WAIT = 14, A_COUNT = 16 /* mirrored to the host */ };
 enum { ERR_OVERFLOW = 1, ERR_BARRIER_TIMEOUT = 2, ERR_NO_CONVERGENCE = 3 };
 
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -436,7 +436,7 @@ constexpr int SOLVE_THREADS = 512;
 constexpr int SOLVE_ROWS = SOLVE_THREADS / SLPN;
 constexpr int H_SHIFT = 24, H_MASK = (1 << H_SHIFT) - 1, H_EPOCHS = 126;   // height word = (H_EPOCHS - epoch) << 24 | height
 
-struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer, cascade_iters; };
+struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer, cascade_iters; unsigned long long barrier_timeout; };
 
 // Grid barrier with reductions, two levels: the workgroups of one XCD meet on a line of their own, the last
 // arriver of each XCD carries the XCD's reductions to the top line and arrives there, everybody polls the top
@@ -449,14 +449,16 @@ struct GridBarrier {
     int xcd, xcd_wgs, xcds;
     unsigned seq;        // barriers passed on the two-level counters
     unsigned long long ticks;
+    unsigned long long timeout;      // 100 MHz ticks a poll may last before the launch gives up (a workgroup is not resident)
+    unsigned long long max_wait;     // longest poll of this workgroup's leader so far
 };
 
-__device__ __forceinline__ bool spin_until(const int* word, int target, int* flags)
+__device__ __forceinline__ bool spin_until(const int* word, int target, int* flags, unsigned long long timeout)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
     while (LD(word) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {          // 3 s: a workgroup of this launch is not resident
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {               // a workgroup of this launch is not resident
             atomicExch(&flags[C_ERROR], ERR_BARRIER_TIMEOUT);
             return false;
         }
@@ -477,7 +479,7 @@ __device__ __forceinline__ bool grid_sync_first(GridBarrier& b)
         atomicAdd(&b.flags[C_XCD + b.xcd * C_LINE], 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         atomicAdd(&b.flags[C_ARRIVE], 1);
-        if (!spin_until(&b.flags[C_ARRIVE], b.P, b.flags)) b.s_red[6] = 1;
+        if (!spin_until(&b.flags[C_ARRIVE], b.P, b.flags, b.timeout)) b.s_red[6] = 1;
         int used = 0;
         for (int x = 0; x < 8; ++x) used += LD(&b.flags[C_XCD + x * C_LINE]) > 0 ? 1 : 0;
         b.s_red[3] = used;
@@ -546,12 +548,13 @@ __device__ __forceinline__ bool grid_sync(GridBarrier& b, bool c_changed, bool c
             hm = LD(&top[10 + slot]);
             if ((int)(v & 0xffffull) >= target) break;
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {      // 3 s: a workgroup of this launch is not resident
+            if (__builtin_amdgcn_s_memrealtime() - t0 > b.timeout) {         // a workgroup of this launch is not resident
                 atomicExch(&b.flags[C_ERROR], ERR_BARRIER_TIMEOUT);
                 abort = 1;
                 break;
             }
         }
+        { const u64 waited = __builtin_amdgcn_s_memrealtime() - t0; if (waited > b.max_wait) b.max_wait = waited; }
         b.s_red[3] = (int)((v >> 16) & 0xffffull);
         b.s_red[4] = (int)(v >> 32);
         b.s_red[5] = hm;
@@ -594,7 +597,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
     const int INF = K + 1;                           // no residual path in the core is longer than K
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
-    GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull };
+    GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull, sp.barrier_timeout, 0ull };
     long long st_outer = 0, st_relax = 0, st_push = 0;
     unsigned long long tk_relax = 0, tk_push = 0, tk_tail = 0;
     long long st_tail = 0;                           // relabel/push rounds that began with fewer than 64 active rows
@@ -1065,6 +1068,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
         atomicAdd((unsigned long long*)&acc[A_T_PUSH], tk_push);
         atomicAdd((unsigned long long*)&acc[A_T_TAIL], tk_tail);
         atomicAdd((unsigned long long*)&acc[A_TAIL_ROUNDS], (unsigned long long)st_tail);
+        atomicMax((unsigned long long*)&acc[A_MAX_WAIT], bar.max_wait);
         atomicMax(&flags[C_XCD_USED], bar.xcds);
         if (trace) {
             int* tr = trace + 8 * (size_t)t;
@@ -1298,7 +1302,8 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     stats.launches += 1;
     energy = w.h_acc[A_ENERGY];
 
-    SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20, w.cascade_iters };
+    SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20, w.cascade_iters,
+                    w.barrier_timeout_ticks > 0 ? (unsigned long long)w.barrier_timeout_ticks : 300000000ull };
     int solve_grid = w.solve_grid > 0 ? w.solve_grid : 128;
     // slots per solver row for a core of all n sites, and the LDS that holds their scalars
     const int mslots = std::max(1, (g.n + solve_grid * SOLVE_ROWS - 1) / (solve_grid * SOLVE_ROWS));
@@ -1361,6 +1366,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     stats.push_ms = (double)w.h_acc[A_T_PUSH] * 1e-5;
     stats.tail_ms = (double)w.h_acc[A_T_TAIL] * 1e-5;
     stats.tail_rounds = w.h_acc[A_TAIL_ROUNDS];
+    stats.max_barrier_wait_ms = (double)w.h_acc[A_MAX_WAIT] * 1e-5;
     if (st) *st = stats;
     return hipSuccess;
 }

@@ -160,6 +160,9 @@ struct ExpandWork {         // scratch owned by the engine
     // expansion ended with; null = every move starts from the zero flow
     int* saved_flow;
     int* saved_sink;
+    // 100 MHz ticks a poll at a grid barrier may last before the launch gives up (a workgroup of it is not resident: a GPU
+    // shared with other persistent launches); 0 = 3 s
+    long long barrier_timeout_ticks = 0;
 };
 constexpr int EXPAND_FLAG_WORDS = 896;     // device control block (expand.hip)
 constexpr int EXPAND_HOST_WORDS = 32;      // its head, mirrored to the host
@@ -182,6 +185,7 @@ struct ExpandStats {
     double barrier_ms, relax_ms, push_ms;     // of which: inside grid barriers; global relabels; push phases (the last two include their barriers)
     double tail_ms;                           // of which: relabel/push rounds that began with fewer than 64 rows still holding excess
     long long tail_rounds;
+    double max_barrier_wait_ms;               // longest single wait of the leader workgroup at a grid barrier
 };
 
 // resident workgroups of the solver launch per CU, as the occupancy query sees k_solve

@@ -2056,4 +2056,68 @@ MHO_API int mho_process(const double* x1, const double* y1, const double* x2, co
     return nh;
 }
 
-MHO_API int mho_abi_version(void) { return 2; }
+// ---------------------------------------------------------------------------
+// 13. Process() from RAW correspondences (M/MultiH.cpp:42-98 with GetFundamentalMatrixAndRefineData, :770-848)
+// ---------------------------------------------------------------------------
+// Epipoles with third coordinate 1 (:786-799): e2 = eigenvector of F F^T, e1 = eigenvector of F^T F with the smallest
+// eigenvalue (the last row of cv::eigen's descending order), divided by its third entry.  cv::eigen -> the Jacobi of
+// section 5 (parity unpinned at that boundary, like every cv::eigen call of the path).
+MHO_API void mho_epipoles(const double* F, double* e1, double* e2)
+{
+    for (int which = 0; which < 2; ++which) {
+        double A[9], V[9], W[3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < 3; ++k)
+                    a = a + (which == 0 ? F[3 * k + i] * F[3 * k + j]          // Ft * F  (:795)
+                                        : F[3 * i + k] * F[3 * j + k]);        // F * Ft  (:789)
+                A[3 * i + j] = a;
+            }
+        jacobi_sym(3, A, V, W);
+        int jm = 0;
+        for (int j = 1; j < 3; ++j) if (W[j] < W[jm]) jm = j;
+        double* out = which == 0 ? e1 : e2;
+        out[0] = V[0 * 3 + jm] / V[2 * 3 + jm];
+        out[1] = V[1 * 3 + jm] / V[2 * 3 + jm];
+    }
+}
+
+// The front half as the build defines it where the reference calls cv::findFundamentalMat(RANSAC) (:775; OpenCV is outside
+// /root/reference — parity unpinned): `hypotheses` normalised 8-point fits from counter-RNG 8-tuples
+// (seed, counters 0..), Sampson inlier counts at thr_f^2, the best-supported (lowest index on ties), two rounds of
+// {inliers -> least-squares 8-point -> rank 2}, the inlier mask of the result; then the reference's own steps: the
+// degenerate test ||F|| < 1e-5 (:779), the epipoles (:786-799), and per masked correspondence the Hartley-Sturm
+// correction, the affine-consistency filter and the optimal affinity (:807-838, mho_refine_points).
+// keep: N flags; refined: N x 8 (x1 y1 x2 y2 a11 a12 a21 a22 of the survivors, zero elsewhere).  Returns the number kept,
+// or -1 in the degenerate case.
+MHO_API int mho_front_half(const double* x1, const double* y1, const double* x2, const double* y2, const double* aff, int N,
+                           uint64_t seed, int hypotheses, double thr_f, double* F_out, double* e1_out, double* e2_out,
+                           unsigned char* keep, double* refined)
+{
+    std::vector<int> idx(8 * (size_t)hypotheses), counts(hypotheses);
+    std::vector<double> Fh(9 * (size_t)hypotheses);
+    mho_sample8(seed, 0, hypotheses, N, idx.data());
+    mho_fund8(x1, y1, x2, y2, idx.data(), hypotheses, Fh.data());
+    const double thr2 = thr_f * thr_f;
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < hypotheses; ++m) mho_sampson_score(x1, y1, x2, y2, N, Fh.data() + 9 * (size_t)m, 1, thr2, &counts[m]);
+    int best = 0;
+    for (int m = 1; m < hypotheses; ++m) if (counts[m] > counts[best]) best = m;
+    double Fa[9], Fb[9], Fc[9];
+    std::vector<unsigned char> mask(N);
+    mho_fund_refit(x1, y1, x2, y2, N, Fh.data() + 9 * (size_t)best, thr2, Fa, nullptr);
+    mho_fund_refit(x1, y1, x2, y2, N, Fa, thr2, Fb, nullptr);
+    mho_fund_refit(x1, y1, x2, y2, N, Fb, thr2, Fc, mask.data());            // (its mask = the inliers of Fb, the F returned)
+    for (int i = 0; i < 9; ++i) F_out[i] = Fb[i];
+    mho_epipoles(Fb, e1_out, e2_out);
+    double nrm = 0.0;
+    for (int i = 0; i < 9; ++i) nrm += Fb[i] * Fb[i];
+    if (!(sqrt(nrm) >= 1e-5) || !std::isfinite(e2_out[0]) || !std::isfinite(e2_out[1])) return -1;     // :779
+    mho_refine_points(x1, y1, x2, y2, aff, N, Fb, e1_out, e2_out, mask.data(), keep, refined);
+    int kept = 0;
+    for (int i = 0; i < N; ++i) kept += keep[i] ? 1 : 0;
+    return kept;
+}
+
+MHO_API int mho_abi_version(void) { return 3; }

@@ -436,3 +436,21 @@ def merge_candidates(H, F, thr_h, seed):
     nc = lib().mho_merge_candidates(_d(H), nh, _d(f64(F).reshape(9)), C.c_double(thr_h), C.c_ulonglong(seed), _d(feat), _d(modes),
                                     C.byref(k), _d(cand), _i(cand_mode), C.byref(draws))
     return feat, modes[:k.value].copy(), cand[:nc].copy(), cand_mode[:nc].copy(), int(draws.value)
+
+
+def epipoles(F):
+    e1, e2 = np.zeros(2), np.zeros(2)
+    lib().mho_epipoles(_d(f64(F).reshape(9)), _d(e1), _d(e2))
+    return e1, e2
+
+
+def front_half(src, dst, aff, seed, hypotheses, thr_f):
+    """mho_front_half: (kept or -1, F, e1, e2, keep mask, refined [n,8])."""
+    x1, y1, x2, y2 = soa(src, dst)
+    aff = f64(aff)
+    F, e1, e2 = np.zeros(9), np.zeros(2), np.zeros(2)
+    keep = np.zeros(x1.size, dtype=np.uint8)
+    refined = np.zeros((x1.size, 8))
+    k = lib().mho_front_half(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, C.c_ulonglong(seed), int(hypotheses), C.c_double(thr_f),
+                             _d(F), _d(e1), _d(e2), keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(refined))
+    return int(k), F, e1, e2, keep, refined
