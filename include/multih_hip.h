@@ -278,6 +278,10 @@ MH_API int mh_get_expand_stats(mh_engine* e, long long stats[24]);
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid
  * barriers, 100 MHz ticks inside the launch, of which inside barriers}; all zero for moves that were skipped or had an empty core. */
 MH_API int mh_get_expand_trace(mh_engine* e, int* trace /* moves x 8 */, int moves);
+/* Diagnostic (mh_set_tuning key 21 = number of moves): connected components of each move's undecided core, 16 ints per move
+ * {core sites, components, largest, second largest, sites in components of <= 64 / 256 / 1024 / 2048 / 8192 sites, components of
+ * those sizes, propagation rounds, 0}; zeros for skipped moves.  Never changes a result. */
+MH_API int mh_get_core_components(mh_engine* e, int* out /* moves x 16 */, int moves);
 /* GetHomographyHAFNonminimal for every label (M/MultiH.cpp:913-989 + the 1/lambda rescale of
  * Homography_RefineHAFCallback.h:33-34).  labels: -1..Nh-1 per point.  Updates the current
  * model set in place; H_out (nullable) receives a host copy. */
@@ -312,7 +316,7 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * greedy selections fails on this rank (exercises the collective exit of mh_select_greedy), 19 the materialising residual sweep as a resident
  * grid that hands itself the work items (value = workgroup slots left free beyond its own occupancy, default 0; -1 = one
  * hardware-dispatched workgroup per item), 20 the sweep is held until the second stream has reached a pending DLT prefetch's
- * dispatch (1, default) or not (0) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * dispatch (1, default) or not (0) — schedule only, 21 moves whose core components are diagnosed (mh_get_core_components; 0 = off).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

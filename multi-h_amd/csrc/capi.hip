@@ -144,6 +144,8 @@ struct mh_engine {
     int cost_L = 0;
     DevBuf<int> cost, labels_in, labels_pts, label_counts;
     DevBuf<int> ew_label, ew_cur, ew_cap, ew_sent, ew_excess, ew_sink, ew_height, ew_decided, ew_flags, ew_core, ew_trace, ew_saved, d_order, d_wsum;
+    int comp_moves = 0;                      // > 0: component diagnostic of the first n moves' cores (mh_set_tuning key 21)
+    DevBuf<int> ew_comp, ew_comp_out;
     int trace_moves = 0;                     // > 0: k_solve logs 8 ints per move (mh_set_tuning key 8)
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
@@ -622,6 +624,12 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         w.trace = e->ew_trace.p;
         w.trace_moves = e->trace_moves;
     }
+    if (e->comp_moves > 0) {
+        HIPCHK(e->ew_comp.reserve(2 * (size_t)g.n));
+        HIPCHK(e->ew_comp_out.reserve(16 * (size_t)e->comp_moves));
+        HIPCHK(hipMemsetAsync(e->ew_comp_out.p, 0, sizeof(int) * 16 * (size_t)e->comp_moves, e->stream));
+        w.comp_out = e->ew_comp_out.p; w.comp_scratch = e->ew_comp.p; w.comp_moves = e->comp_moves;
+    }
     const int potts = (int)std::round(100.0 * e->lambda);     // M/MultiH.h:41, MultiH.cpp:510
     ExpandStats st{};
     {
@@ -795,6 +803,7 @@ void mh_destroy(mh_engine* e)
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
+    e->ew_comp.release(); e->ew_comp_out.release();
     e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release(); e->d_wsum.release();
     e->knn_tmp.release(); e->knn_part_i.release(); e->knn_part_d.release();
     for (int c = 0; c < 4; ++c) e->sel_pts[c].release();
@@ -2172,6 +2181,20 @@ int mh_get_expand_trace(mh_engine* e, int* trace, int moves)
     });
 }
 
+int mh_get_core_components(mh_engine* e, int* out, int moves)
+{
+    return guarded([&]() -> int {
+    int rc = enter(e);
+    if (rc) return rc;
+    if (!out || moves <= 0) return fail(MH_ERR_INVALID, "null output or moves <= 0");
+    if (e->comp_moves <= 0 || !e->ew_comp_out.p) return fail(MH_ERR_NOT_SET, "the component diagnostic is off (mh_set_tuning key 21) or no expansion has run");
+    const int m = std::min(moves, (int)(e->ew_comp_out.cap / 16));
+    HIPCHK(hipMemcpyAsync(out, e->ew_comp_out.p, sizeof(int) * 16 * (size_t)m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MH_OK;
+    });
+}
+
 int mh_reestimate(mh_engine* e, const int* labels, double* H_out)
 {
     return guarded([&]() -> int {
@@ -2317,6 +2340,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 18 && value >= 0 && value <= 1000) { e->inject_select_failure = value; return MH_OK; }
     if (key == 19 && value >= -1 && value <= 1024) { e->tune_sweep_headroom = value; return MH_OK; }
     if (key == 20 && (value == 0 || value == 1)) { e->tune_dlt_first = value; return MH_OK; }
+    if (key == 21 && value >= 0 && value <= (1 << 16)) { e->comp_moves = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -1078,6 +1078,62 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
     }
 }
 
+// DIAGNOSTIC (mh_set_tuning key 21): connected components of a move's undecided core — the sites the
+// dominance reduction left to the flow solver, joined where two of them are neighbours (their n-link has capacity; links
+// to decided sites were folded into t-links).  One workgroup: min-label propagation with pointer jumping to the fixed
+// point, then sizes.  out[16]: {core sites, components, largest, second largest, sites in components of <= 64 / 256 / 1024 /
+// 2048 / 8192 sites (cumulative), components of <= 64 / 256 / 1024 / 2048 / 8192 sites (cumulative), propagation rounds, 0}.
+// comp, csize: n ints of scratch each.  Never on the product path.
+__global__ void __launch_bounds__(1024)
+k_core_components(Graph g, int L, int t, const int* __restrict__ decided, const int* __restrict__ flags, int* __restrict__ comp,
+                  int* __restrict__ csize, int* __restrict__ out)
+{
+    __shared__ int s_changed, s_acc[16];
+    if (threadIdx.x < 16) { s_acc[threadIdx.x] = 0; out[threadIdx.x] = 0; }
+    if (move_is_skipped(flags, t, L)) return;
+    for (int i = threadIdx.x; i < g.n; i += 1024) { comp[i] = decided[i] == 0 ? i : -1; csize[i] = 0; }
+    __syncthreads();
+    int rounds = 0;
+    for (;;) {
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < g.n; i += 1024) {
+            int c = comp[i];
+            if (c < 0) continue;
+            int m = c;
+            for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) { const int cj = comp[g.col[k]]; if (cj >= 0 && cj < m) m = cj; }
+            if (m < c) { atomicMin(&comp[i], m); atomicMin(&comp[c], m); s_changed = 1; }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < g.n; i += 1024) {          // pointer jumping
+            int c = comp[i];
+            if (c < 0) continue;
+            while (comp[c] < c) c = comp[c];
+            comp[i] = c;
+        }
+        __syncthreads();
+        ++rounds;
+        if (!s_changed || rounds > 4096) break;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < g.n; i += 1024) if (comp[i] >= 0) { atomicAdd(&csize[comp[i]], 1); atomicAdd(&s_acc[0], 1); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.n; i += 1024) {
+        const int sz = csize[i];
+        if (sz <= 0) continue;
+        atomicAdd(&s_acc[1], 1);
+        const int old = atomicMax(&s_acc[2], sz);
+        atomicMax(&s_acc[3], old < sz ? old : sz);              // (a lower bound of the second largest; exact when sizes arrive in any order but ties)
+        if (sz <= 64) { atomicAdd(&s_acc[4], sz); atomicAdd(&s_acc[9], 1); }
+        if (sz <= 256) { atomicAdd(&s_acc[5], sz); atomicAdd(&s_acc[10], 1); }
+        if (sz <= 1024) { atomicAdd(&s_acc[6], sz); atomicAdd(&s_acc[11], 1); }
+        if (sz <= 2048) { atomicAdd(&s_acc[7], sz); atomicAdd(&s_acc[12], 1); }
+        if (sz <= 8192) { atomicAdd(&s_acc[8], sz); atomicAdd(&s_acc[13], 1); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x == 14 ? rounds : s_acc[threadIdx.x];
+}
+
 __global__ void __launch_bounds__(SOLVE_THREADS)
 k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, int* height, int* decided,
         const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
@@ -1323,6 +1379,9 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
                                    w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds, 1);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
                                w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds, w.reduce_launches > 1 ? 0 : 1);
+            if (w.comp_out && t < w.comp_moves)             // diagnostic: components of the core the reduction left
+                hipLaunchKernelGGL(k_core_components, dim3(1), dim3(1024), 0, s, g, L, t, w.decided, w.flags, w.comp_scratch,
+                                   w.comp_scratch + g.n, w.comp_out + 16 * (size_t)t);
             hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), solve_lds, s, g, L, t, w.cap, w.sent, w.excess,
                                w.sink_cap, w.height, w.decided, w.core, w.flags, w.acc,
                                (w.trace && t < w.trace_moves) ? w.trace : nullptr,

@@ -163,6 +163,10 @@ struct ExpandWork {         // scratch owned by the engine
     // 100 MHz ticks a poll at a grid barrier may last before the launch gives up (a workgroup of it is not resident: a GPU
     // shared with other persistent launches); 0 = 3 s
     long long barrier_timeout_ticks = 0;
+    // diagnostic (expand.hip, k_core_components): 16 ints per move for the first comp_moves moves; scratch 2 n ints
+    int* comp_out = nullptr;
+    int* comp_scratch = nullptr;
+    int comp_moves = 0;
 };
 constexpr int EXPAND_FLAG_WORDS = 896;     // device control block (expand.hip)
 constexpr int EXPAND_HOST_WORDS = 32;      // its head, mirrored to the host
