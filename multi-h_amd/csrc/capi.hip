@@ -1523,7 +1523,10 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     int resident = 0;
     if (e->tune_sweep_headroom >= 0 && e->residual_mode != MH_RESIDUAL_SYMMETRIC && e->tune_residual_variant == 0) {
         if (e->sweep_wg_per_cu < 0) e->sweep_wg_per_cu = residual_workgroups_per_cu();
-        resident = e->sweep_wg_per_cu * e->cu_count - e->tune_sweep_headroom;
+        // With a stream-ordered transport over several ranks, RCCL's own kernel (one or two workgroups for an exchange of this
+        // size) has to find room while the NEXT sweep is resident: 32 slots are left free for it unless the caller chose.
+        const int headroom = e->tune_sweep_headroom > 0 ? e->tune_sweep_headroom : (e->t_stream_fn && e->t_world > 1 ? 32 : 0);
+        resident = e->sweep_wg_per_cu * e->cu_count - headroom;
         if (resident < e->cu_count) resident = 0;
         if (resident > 0 && !e->sweep_ctl.p) {
             HIPCHK(e->sweep_ctl.reserve(2));

@@ -226,13 +226,15 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
 // plane — and 42 % of the wave-model iterations contain one, each costing a pass through the IEEE formula).
 // ---------------------------------------------------------------------------
 // Lanes of ONE wave hand data to each other through LDS below (no workgroup barrier: the other waves are not involved).
-// The LDS operations of a wave complete in program order, so what is needed is that the COMPILER keeps the writes in front
-// of the cross-lane reads: a wave-scope release / acquire pair around a wave barrier (r03 advisor finding).
+// The LDS operations of a wave complete in program order, so all that is needed is that the COMPILER keeps the writes in
+// front of the cross-lane reads: a compiler-level memory barrier and a wave barrier (a scheduling fence; no instruction).
+// (r03 advisor finding.  A wave-scope release / acquire fence pair was tried first: the backend emits s_waitcnt for it and
+// the kernel went from 4.3 to 4.9 ms.)
 __device__ __forceinline__ void wave_lds_handover()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 template <int MC, int WAVES>

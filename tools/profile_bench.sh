@@ -3,7 +3,7 @@
 # traffic and instruction mix.  Outputs under gpurun_out/prof_<tag>/; the summary names the source revision it was taken
 # from (HEAD sha passed in by the caller — .git does not travel to the box — and the hash of bench.py as it ran).
 #   tools/profile_bench.sh <tag> <head-sha>
-TAG=${1:-r03}
+TAG=${1:-r04}
 HEAD_SHA=${2:-unknown}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT

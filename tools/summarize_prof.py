@@ -10,8 +10,10 @@ print("== source: HEAD", os.environ.get("HEAD_SHA", "unknown"), " bench_py_sha16
 KEEP = [k for k in os.environ.get("KERNELS", "k_residual,k_dlt4").split(",") if k]
 ROWS = int(os.environ.get("STAT_ROWS", "14"))
 def materialising(name):
-    """the residual kernel with WRITE_R = true (third template argument), demangled or mangled"""
-    return "k_residual<4, 16, true" in name or "k_residualILi4ELi16ELb1" in name
+    """the residual kernel with WRITE_R = true (third template argument), demangled or mangled — the hardware-dispatched
+    form (k_residual, r01-r03) or the resident grid (k_residual_resident, r04)"""
+    return any(k in name for k in ("k_residual<4, 16, true", "k_residualILi4ELi16ELb1", "k_residual_resident<4, 16, true",
+                                   "k_residual_residentILi4ELi16ELb1"))
 def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 for f in find("trace", "*kernel_stats.csv"):
