@@ -133,7 +133,7 @@ MH_API int mh_local_homographies(mh_engine* e, double locality, double* H_out, d
  * every climb (:62-123) runs on the GPU, the sequential seed/merge/vote logic (:52-56,:100-146) on
  * the host; seeds come from the counter RNG instead of rand(), 256 at a time from the rows unvisited
  * at that moment (their climbs share the launches; a seed visited by an earlier climb of its batch
- * is dropped — DESIGN.md 3.8).  modes: up to max_modes x d;
+ * is dropped — HISTORY.md 3.8).  modes: up to max_modes x d;
  * assign: per row the index of its mode (-1 if none); n_modes: number of modes found. */
 MH_API int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_width,
                   unsigned long long seed, double* modes, int max_modes, int* assign, int* n_modes);

@@ -1,7 +1,7 @@
 // dlt4.hip — propose step: counter-RNG 4-tuples + batched normalised 4-point
 // DLT, gfx950.  Stands where the reference calls cv::findHomography on minimal
 // samples (M/MultiH.cpp:725, M/MultipleHomographies.h:118-144,328-339); there
-// is no in-tree reference arithmetic, the definition is DESIGN.md §Propose.
+// is no in-tree reference arithmetic, the definition is DESIGN.md 3.3 (HISTORY.md 3.3).
 //
 // Per hypothesis: Hartley-normalise the 4 correspondences (centroid, mean
 // distance sqrt 2 — the recipe of NormalizePoints,

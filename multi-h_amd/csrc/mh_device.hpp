@@ -155,7 +155,7 @@ __device__ __forceinline__ double fwd_d2_lean(double h0, double h1, double h2, d
 // pair instead of 28).  It rounds differently from the reference (last-bit differences in d2, and
 // therefore possibly different inlier decisions within an ulp of the threshold), so it exists only
 // as tuning variant 10 of the residual kernel, to measure what the exact-rounding requirement costs
-// (DESIGN.md section 7).
+// (HISTORY.md section 7).
 __device__ __forceinline__ double fwd_d2_contracted(double h0, double h1, double h2, double h3, double h4,
                                                     double h5, double h6, double h7, double h8, double x,
                                                     double y, double x2, double y2)

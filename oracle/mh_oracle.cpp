@@ -1392,7 +1392,7 @@ MHO_API int mho_labeling_step(const double* x1, const double* y1, const double* 
 // systems through the Jacobi solver of section 5): "parity unpinned" at those boundaries.  The product's
 // 3-point solver may therefore differ from this one in the last bits of a homography; what must agree is
 // every DECISION taken from them (inlier sets, kept modes, `changed`, labels, energies).
-// Deviations shared with the product (DESIGN.md section 8): explicit splitmix64 seeds instead of rand();
+// Deviations shared with the product (DESIGN.md section 7): explicit splitmix64 seeds instead of rand();
 // a climb whose window captures no row ends (the reference would loop on a NaN mean).
 
 // Feature vector of a homography: the images of (0,0), (1,0), (0,1).  M/MultiH.cpp:364-390.
@@ -1866,7 +1866,7 @@ MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* 
 
 // ComputeLocalHomographies (:696-717) + EstablishStablePointSets (:604-694): per-point HAF homographies and their 10-D
 // features (mho_haf_point), mean shift with band width thr_h (the engine-order restatement mho_mean_shift, see its
-// header and DESIGN.md 3.8 for what that order defines), one LM-refined 3-point homography per cluster of >= 3 points
+// header and HISTORY.md 3.8 for what that order defines), one LM-refined 3-point homography per cluster of >= 3 points
 // (:664-688).  A per-point solve that degenerates leaves non-finite features; the product parks such rows at 1e300 so
 // that the L1 ball test never sees a NaN, and so does this.  Returns the number of models (H_out: capacity max_models*9).
 MHO_API int mho_establish_stable_point_sets(const double* x1, const double* y1, const double* x2, const double* y2,
@@ -2084,7 +2084,7 @@ MHO_API void mho_epipoles(const double* F, double* e1, double* e2)
 }
 
 // The front half as the build defines it where the reference calls cv::findFundamentalMat(RANSAC) (:775; OpenCV is outside
-// /root/reference — parity unpinned, DESIGN.md 8.1b): `hypotheses` normalised 8-point fits from counter-RNG 8-tuples
+// /root/reference — parity unpinned, DESIGN.md 7.1b): `hypotheses` normalised 8-point fits from counter-RNG 8-tuples
 // (seed, counters 0..), Sampson inlier counts at thr_f^2, the best-supported (lowest index on ties), two rounds of
 // {inliers -> least-squares 8-point -> rank 2}, the inlier mask of the result; then the reference's own steps: the
 // degenerate test ||F|| < 1e-5 (:779), the epipoles (:786-799), and per masked correspondence the Hartley-Sturm

@@ -663,7 +663,7 @@ def test_shared_reciprocal_precondition_boundaries(engine, oracle, symmetric):
 
 
 def test_product_library_carries_no_measurement_variants(mh, engine, synth, oracle):
-    """The residual / score kernel variants used for the A/B evidence of DESIGN.md section 7 — one of them, fused
+    """The residual / score kernel variants used for the A/B evidence of HISTORY.md section 7 — one of them, fused
     multiply-adds, is not bit-exact — live only in the measurement library (build.py --tuning).  The product library
     refuses to select them, so nothing reachable through its ABI can change a result; a sweep over points whose
     bounding box lets the per-model |s| proof succeed AND points that defeat it stays bit-exact."""

@@ -290,7 +290,7 @@ def test_poly_roots_and_point_refinement(oracle, synth):
 
 
 def test_mean_shift_oracle_vs_sequential_sums(oracle):
-    """The oracle's mean shift mirrors the GPU's summation order (256 strided partial sums + a binary tree, DESIGN.md
+    """The oracle's mean shift mirrors the GPU's summation order (256 strided partial sums + a binary tree, HISTORY.md
     section 3.8) so that GPU and oracle agree bit for bit; the reference adds the members up one after the other
     (MeanShiftClustering.h:85-96).  The two orders differ in the last bits of a mean only: on separated data the modes
     agree to 1e-9 and every row lands in the same mode (parity with the reference's own order is to this tolerance,

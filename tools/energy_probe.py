@@ -5,7 +5,7 @@ For each variant the kernel is launched back to back for SECONDS while a thread 
 the shader clock; J per launch = mean power x mean launch time, pJ per pair = that / (N x M).  If a kernel is bound by
 the board's power cap, variants that do less work per pair draw the SAME power and finish sooner (time follows energy);
 if it is bound by something else, power falls below the cap.  Writes gpurun_out/energy_probe.json; the copy under
-profiles/ is what DESIGN.md section 7 cites.
+profiles/ is what HISTORY.md section 7 cites.
 
 Measurement variants live in the tuning library only:
     MH_LIB=multi-h_amd/libmultih_hip_tuning.so python tools/energy_probe.py"""

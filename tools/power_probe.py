@@ -2,7 +2,7 @@
 """Board power and clock telemetry while the residual kernel runs back to back for several seconds (runs on the GPU
 box through gpurun): starts `bench.py --steps S` as a child and samples rocm-smi (power, shader / memory clocks,
 temperature, power cap) a few times per second until it exits.  Writes gpurun_out/power_probe/{samples.jsonl,
-summary.json}; the summary is what profiles/ keeps to support the clock-throttling reading of DESIGN.md section 7."""
+summary.json}; the summary is what profiles/ keeps to support the clock-throttling reading of HISTORY.md section 7."""
 import json, os, re, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "power_probe")
