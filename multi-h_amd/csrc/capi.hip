@@ -103,6 +103,8 @@ struct mh_engine {
     // pipelined propose (mh_prefetch_dlt4): the spare batch and the second stream it is prepared on
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_side_pre = nullptr;
+    int tune_stream_shift = 0;               // key 22 (experiment): dummy streams created in front of the second / third stream (shifts their hardware queue / pipe)
+    std::vector<hipStream_t> dummy_streams;
     int tune_dlt_first = 1;                  // key 20: the sweep waits until the second stream has reached the pending DLT's dispatch (1) or not (0)
     DevBuf<double> H_next;
     DevBuf<int> samples_next;
@@ -828,6 +830,7 @@ void mh_destroy(mh_engine* e)
     if (e->ev_sweep) (void)hipEventDestroy(e->ev_sweep);
     for (int b = 0; b < 2; ++b) if (e->ev_x[b]) (void)hipEventDestroy(e->ev_x[b]);
     e->counts_alt.release(); e->sweep_ctl.release();
+    for (hipStream_t d : e->dummy_streams) (void)hipStreamDestroy(d);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1792,6 +1795,11 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
 static int ensure_side_stream(mh_engine* e)
 {
     if (!e->side_stream) {
+        for (int k = 0; k < e->tune_stream_shift; ++k) {
+            hipStream_t d = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
+            e->dummy_streams.push_back(d);
+        }
         // highest priority: the short DLT kernel gets its compute units as soon as the sweep on the main stream frees
         // some, so it is done early in the sweep instead of trickling in behind it and delaying the next one
         int lo = 0, hi = 0;
@@ -2344,6 +2352,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 19 && value >= -1 && value <= 1024) { e->tune_sweep_headroom = value; return MH_OK; }
     if (key == 20 && (value == 0 || value == 1)) { e->tune_dlt_first = value; return MH_OK; }
     if (key == 21 && value >= 0 && value <= (1 << 16)) { e->comp_moves = value; return MH_OK; }
+    if (key == 22 && value >= 0 && value <= 16 && !e->side_stream) { e->tune_stream_shift = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

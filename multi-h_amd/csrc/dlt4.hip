@@ -72,9 +72,15 @@ constexpr int WROWS = 17, WCOLS = 9;
 // moving LDS accesses across the round boundary.  (Workgroup barriers here cost ~25 % of the kernel.)
 __device__ __forceinline__ void wave_sync()
 {
+#ifdef MH_DLT_WAVE_FENCES          // the r01-r03 form: wave-scope release / acquire fences (the backend emits s_waitcnt for them)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#endif
 }
 
 // One-sided (Hestenes) Jacobi on W = [A (8x9); I9] in LDS, 4 lanes per hypothesis: lane slot s
