@@ -1948,20 +1948,19 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
             if (longest > e->m)                                    // a shard one shorter than the longest: its padding element (every
                 HIPCHK(hipMemsetAsync(e->counts.p + e->m, 0xff, sizeof(int) * (size_t)(longest - e->m), s));   // counts buffer holds m + 1 ints)
         }
-        if (e->xchg_calls == 0) HIPCHK(hipMemsetAsync(e->best_key.p, 0, sizeof(unsigned long long), s));
         HIPCHK(hipEventRecord(e->ev_sweep, s));                    // the sweep (and whatever else the main stream holds) up to here
         HIPCHK(hipStreamWaitEvent(x, e->ev_sweep, 0));
+        // enqueue-only: this batch's counts buffer comes back to the main stream two calls from now — cleared by the same
+        // launch that reads it, so that the sweep that then writes it needs no memset of its own on the main stream
+        int* clear = fetch ? nullptr : e->counts.p;
+        const int clear_count = fetch ? 0 : (int)e->counts.cap;       // (all of it: the next batch it serves may be larger)
         if (sharded) {
             rc = exchange(e, e->counts.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, x);      // north_star's all-gather
             if (rc) return rc;
-            HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, e->best_key.p, x));
+            HIPCHK(launch_best_fused(e->sel_gathered.p, world, longest, base, rem, e->h_best_dev, clear, clear_count, x));
         } else {
-            HIPCHK(launch_sel_argmax(e->counts.p, nullptr, e->m, 0u, e->best_key.p, nullptr, x));
+            HIPCHK(launch_best_fused(e->counts.p, 1, e->m, 0, 0, e->h_best_dev, clear, clear_count, x));
         }
-        HIPCHK(launch_best_publish(e->best_key.p, e->h_best_dev, x));
-        // enqueue-only: this buffer comes back to the main stream two calls from now — cleared here, behind the exchange
-        // that read it, so that the sweep that then writes it needs no memset of its own on the main stream
-        if (!fetch) HIPCHK(hipMemsetAsync(e->counts.p, 0, sizeof(int) * e->counts.cap, x));
         const int par = (int)(e->xchg_calls & 1);
         HIPCHK(hipEventRecord(e->ev_x[par], x));
         ++e->xchg_calls;

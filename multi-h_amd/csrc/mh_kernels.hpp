@@ -221,6 +221,8 @@ hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world
                             hipStream_t s);
 hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_record, int need, int* h_rec_dev, hipStream_t s);
 hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s);
+hipError_t launch_best_fused(const int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,
+                             int clear_count, hipStream_t s);
 hipError_t launch_pad_scores(const int* counts, int m, int longest, int* scores, hipStream_t s);
 
 // --- knn.hip ----------------------------------------------------------------

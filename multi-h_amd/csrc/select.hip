@@ -194,6 +194,40 @@ __global__ void k_best_publish(unsigned long long* __restrict__ key, int* __rest
     *key = 0;
 }
 
+// Arg-max + publication + clearing in ONE launch (r04): what follows a sweep (or the all-gather of a sharded batch) on the
+// exchange's stream.  Kernels dispatched while the next sweep is resident do not run before it ends, so the
+// fewer dispatches an exchange consists of, the more of it fits into the gap between two sweeps.  One workgroup: the best
+// key over `scores` — plain (world = 1: entry j is hypothesis j) or gathered (world x longest, -1 = padding, entry (r, j) =
+// hypothesis r * base + min(r, rem) + j) —, the three words for the host, then `clear` (nullable; may be `scores` itself)
+// is zeroed for the sweep after next.
+__global__ void __launch_bounds__(1024)
+k_best_fused(const int* __restrict__ scores, int world, int longest, int base, int rem, int* __restrict__ h_best,
+             int* __restrict__ clear, int clear_count)
+{
+    const int total = world * longest;
+    unsigned long long k = 0;
+    for (int c = threadIdx.x; c < total; c += 1024) {
+        const int v = scores[c];
+        if (v < 0) continue;
+        const int r = world > 1 ? c / longest : 0, j = c - r * longest;
+        const unsigned long long kk = sel_key(v, (unsigned int)(r * base + (r < rem ? r : rem) + j));
+        k = kk > k ? kk : k;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(k, m, 64); k = o > k ? o : k; }
+    __shared__ unsigned long long s_k[16];
+    if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = k;
+    __syncthreads();                                  // (also: every score has been read before anything is cleared)
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0;
+        for (int w = 0; w < 16; ++w) b = s_k[w] > b ? s_k[w] : b;
+        h_best[0] = b ? (int)(b >> 32) : -1;
+        h_best[1] = (int)(0xffffffffu - (unsigned int)(b & 0xffffffffull));
+        h_best[2] += 1;                               // sequence number: the host can tell a fresh result from an old one
+    }
+    if (clear) for (int c = threadIdx.x; c < clear_count; c += 1024) clear[c] = 0;
+}
+
 // scores[0, m) <- counts, scores[m, longest) <- -1: the send buffer of the score all-gather
 __global__ void __launch_bounds__(256)
 k_pad_scores(const int* __restrict__ counts, int m, int longest, int* __restrict__ scores)
@@ -284,6 +318,13 @@ hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_
 hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s)
 {
     hipLaunchKernelGGL(k_best_publish, dim3(1), dim3(64), 0, s, key, h_best_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_best_fused(const int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,
+                             int clear_count, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_best_fused, dim3(1), dim3(1024), 0, s, scores, world, longest, base, rem, h_best_dev, clear, clear_count);
     return hipGetLastError();
 }
 
