@@ -359,17 +359,22 @@ def main():
         fence()
         eng.profile_reset()
         eng.profile_enable(True)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        # A timing event at every step boundary is a marker packet on the engine's stream: about 25 us per step
+        # (tools/enqueue_probe.py: 0.970 ms per 12 500-hypothesis step without them, 0.995-1.005 with).  Nothing at the 7.4 ms
+        # steps of one GPU, 2.5 % at the 1 ms steps of an 8-GPU strong split — so with several ranks only the ends are marked.
+        every = 1 if world == 1 else steps
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps // every + 1)]
         t0 = time.perf_counter()
         marks[0].record()
         last = None
         for i in range(steps):
             last = step(warmup + i, last=(i == steps - 1))
-            marks[i + 1].record()
+            if (i + 1) % every == 0:
+                marks[(i + 1) // every].record()
         fence()
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
-        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) / every for i in range(len(marks) - 1))
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
