@@ -103,6 +103,7 @@ struct mh_engine {
     // pipelined propose (mh_prefetch_dlt4): the spare batch and the second stream it is prepared on
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_side_pre = nullptr;
+    int tune_cost32_resident = 8;            // key 23: the int32 cost matrix as a resident grid with n point slices (8: 4.12 ms against 4.25 hardware-dispatched at 50k x 100k, tools/cost32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_stream_shift = 0;               // key 22 (experiment): dummy streams created in front of the second / third stream (shifts their hardware queue / pipe)
     std::vector<hipStream_t> dummy_streams;
     int tune_dlt_first = 1;                  // key 20: the sweep waits until the second stream has reached the pending DLT's dispatch (1) or not (0)
@@ -1572,7 +1573,16 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
         if (e->tune_score32 && e->coords32_ok && thr2 >= 0x1p-40 && thr2 <= 0x1p40) {      // the FP32 pre-test (score32.hip); same matrix
             HIPCHK(e->H32.reserve((size_t)e->m * 16));
             HIPCHK(launch_model32(e->H.p, e->m, e->absmax_x, e->absmax_y, e->absmax_dst, e->H32.p, e->stream));
-            HIPCHK(launch_cost32(e->pts(), e->H.p, e->H32.p, e->m, e->lambda, thr2, e->absmax_dst, e->C.p, e->ldc, e->counts.p, e->stream));
+            int* ctl = nullptr;
+            if (e->tune_cost32_resident != 0) {
+                if (!e->sweep_ctl.p) {
+                    HIPCHK(e->sweep_ctl.reserve(2));
+                    HIPCHK(hipMemsetAsync(e->sweep_ctl.p, 0, sizeof(int) * 2, e->stream));
+                }
+                ctl = e->sweep_ctl.p;
+            }
+            HIPCHK(launch_cost32(e->pts(), e->H.p, e->H32.p, e->m, e->lambda, thr2, e->absmax_dst, e->C.p, e->ldc, e->counts.p, e->stream,
+                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0));
         } else
             HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, thr2, e->C.p, e->ldc, e->counts.p, e->stream));
     }
@@ -2352,6 +2362,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 20 && (value == 0 || value == 1)) { e->tune_dlt_first = value; return MH_OK; }
     if (key == 21 && value >= 0 && value <= (1 << 16)) { e->comp_moves = value; return MH_OK; }
     if (key == 22 && value >= 0 && value <= 16 && !e->side_stream) { e->tune_stream_shift = value; return MH_OK; }
+    if (key == 23 && value >= -1 && value <= 64) { e->tune_cost32_resident = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -237,16 +237,18 @@ __device__ __forceinline__ void wave_lds_handover()
     asm volatile("" ::: "memory");
 }
 
+// cost32_wg: the work of ONE workgroup — model block bx (MC models), point slice by.
 template <int MC, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
-k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
-         const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
-         double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit)
+__device__ __forceinline__ void
+cost32_wg(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+          const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+          double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit,
+          const int bx, const int by)
 {
     constexpr int PPL = 4, WAVE_PTS = 64 * PPL, TILE = WAVES * WAVE_PTS, THREADS = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m0 = blockIdx.x * MC;
+    const int m0 = bx * MC;
     __shared__ float4 s_m[MC * 4];
     __shared__ double s_h[MC * 9];               // the FP64 coefficients, for the lanes that need the reference's formula
     __shared__ double s_p[WAVES * PPL * 4 * 64];     // [wave][point of the lane][x1 y1 x2 y2][lane]: every lane's own points in FP64
@@ -269,7 +271,7 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
     asm volatile("v_mov_b32 %0, %1" : "=v"(vk1) : "s"(k1));
     const int beyond = 2 * (int)round(lam * T);
     int cnt = 0;                                 // lane mi of each wave counts model m0 + mi
-    for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
+    for (int base = by * TILE; base < N; base += psplit * TILE) {
         const int base_n = base + wave * WAVE_PTS;
         const int n0 = base_n + lane * PPL;
         float fx[PPL], fy[PPL], gx[PPL], gy[PPL];
@@ -365,9 +367,43 @@ k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const dou
     }
 }
 
+template <int MC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+         const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+         double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit)
+{
+    cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, blockIdx.x, blockIdx.y);
+}
+
+// The same work items walked by a resident grid that hands them out through a counter (as k_residual_resident, residual.hip).
+template <int MC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+                  const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+                  double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit,
+                  int gx, int nitems, int* __restrict__ ctl)
+{
+    __shared__ int s_item;
+#pragma unroll 1
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&ctl[0], 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= nitems) break;
+        const int by = item / gx, bx = item - by * gx;
+        cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, bx, by);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && atomicAdd(&ctl[1], 1) == (int)gridDim.x - 1) {
+        ctl[1] = 0;
+        __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // H32: the table launch_model32 made for these models with the same Cmax.  thr2 in [2^-40, 2^40], coordinates below 2^20.
 hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
-                         int* C, long long ldc, int* counts, hipStream_t s)
+                         int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     constexpr int MC = 32;
@@ -384,6 +420,22 @@ hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int
     }
     // far = beyond T = (9/4 thr)^2 with a 2 % margin: the cheap test's k1 with 1.12 x 9/4 thr in place of 2.5 thr
     const float k1 = (float)(std::fmax(1.12 * 2.25 * std::sqrt(std::fabs(thr2)), 25.4 * 5.9604644775390625e-08 * Cmax) * (1.0 + 1e-6)) + 1e-30f;
+    if (resident_ctl) {
+        // resident grid: as many workgroups as the chip holds, ~37 500 items (r04 experiment: mh_set_tuning key 23)
+        static int per_cu = -1;
+        if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cost32_resident<MC, WAVES>, 64 * WAVES, 0) != hipSuccess) per_cu = 0;
+        const int grid = per_cu * cu_count;
+        int ps = psplit_override > 0 ? psplit_override : (37500 + gx - 1) / gx;
+        if (ps > ntiles) ps = ntiles;
+        if (ps < 1) ps = 1;
+        if (grid > 0 && gx * ps > grid) {
+            hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_cost32_resident<MC, WAVES>), dim3(grid), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M,
+                               100.0 / lambda, thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, ps, gx, gx * ps, resident_ctl);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((k_cost32<MC, WAVES>), dim3(gx, psplit), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, 100.0 / lambda,
                        thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, psplit);
     return hipGetLastError();

@@ -89,6 +89,24 @@ def test_cost_matrix_bit_exact(engine, synth, oracle, n, k, seed):
     assert (Cm != 9802).sum() > 0.05 * sc.n
 
 
+def test_cost_matrix_as_a_resident_grid_equals_the_dispatched_one(engine, synth):
+    """r04: k_cost32 walked by a resident grid that hands itself the (model block, point slice) items (mh_set_tuning key 23) —
+    the same int32 matrix and counts as one hardware-dispatched workgroup per item, at a size where the resident form runs."""
+    sc = synth.make_scene(20011, 4, seed=3, with_neighbours=False)
+    _load(engine, sc)
+    engine.propose_dlt4(5, 0, 3001)
+    try:
+        engine.set_tuning(23, 0)
+        C0, cnt0 = engine.cost_matrix()
+        for v in (8, -1, 3):
+            engine.set_tuning(23, v)
+            C1, cnt1 = engine.cost_matrix()
+            assert np.array_equal(cnt1, cnt0) and np.array_equal(C1, C0), v
+    finally:
+        engine.set_tuning(23, 8)
+    assert (C0 != C0.max()).sum() > 1000
+
+
 def _rccl(mh):
     lib = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so"))
     lib.mhr_last_error.restype = C.c_char_p
