@@ -318,7 +318,8 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * hardware-dispatched workgroup per item), 20 the sweep is held until the second stream has reached a pending DLT prefetch's
  * dispatch (1, default) or not (0) — schedule only, 21 moves whose core components are diagnosed (mh_get_core_components; 0 = off), 22 experiment: dummy streams
  * created in front of the engine's second stream (before its first use), 23 the int32 cost matrix as a resident grid (n point slices,
- * default 8; 0 = one hardware-dispatched workgroup per item; -1 = about 37 500 items) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * default 8; 0 = one hardware-dispatched workgroup per item; -1 = about 37 500 items), 24 the same for the FP32 pre-test score
+ * (default 12) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

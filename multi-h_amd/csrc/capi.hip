@@ -103,6 +103,7 @@ struct mh_engine {
     // pipelined propose (mh_prefetch_dlt4): the spare batch and the second stream it is prepared on
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_side_pre = nullptr;
+    int tune_score32_resident = 12;          // key 24: the FP32 pre-test score as a resident grid with n point slices (12: 1.98 ms against 2.14 hardware-dispatched at 50k x 100k, tools/score32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_cost32_resident = 8;            // key 23: the int32 cost matrix as a resident grid with n point slices (8: 4.12 ms against 4.25 hardware-dispatched at 50k x 100k, tools/cost32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_stream_shift = 0;               // key 22 (experiment): dummy streams created in front of the second / third stream (shifts their hardware queue / pipe)
     std::vector<hipStream_t> dummy_streams;
@@ -720,7 +721,16 @@ int score_models(mh_engine* e, const Points& p, const double* Hs, int m, double 
         HIPCHK(e->fb_pairs.reserve(1));
         if (e->score_pairs == 0) HIPCHK(hipMemsetAsync(e->fb_pairs.p, 0, sizeof(unsigned long long), e->stream));
         HIPCHK(launch_model32(Hs, m, e->absmax_x, e->absmax_y, e->absmax_dst, e->H32.p, e->stream));
-        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, e->absmax_dst, dmask, counts_dev, e->fb_pairs.p, e->tune_score32_tiling, e->stream));
+        int* ctl = nullptr;
+        if (e->tune_score32_resident != 0) {
+            if (!e->sweep_ctl.p) {
+                HIPCHK(e->sweep_ctl.reserve(2));
+                HIPCHK(hipMemsetAsync(e->sweep_ctl.p, 0, sizeof(int) * 2, e->stream));
+            }
+            ctl = e->sweep_ctl.p;
+        }
+        HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, e->absmax_dst, dmask, counts_dev, e->fb_pairs.p, e->tune_score32_tiling, e->stream,
+                              ctl, e->cu_count, e->tune_score32_resident));
         e->score_pairs += (long long)m * p.n;
         return MH_OK;
     }
@@ -2363,6 +2373,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 21 && value >= 0 && value <= (1 << 16)) { e->comp_moves = value; return MH_OK; }
     if (key == 22 && value >= 0 && value <= 16 && !e->side_stream) { e->tune_stream_shift = value; return MH_OK; }
     if (key == 23 && value >= -1 && value <= 64) { e->tune_cost32_resident = value; return MH_OK; }
+    if (key == 24 && value >= -1 && value <= 64) { e->tune_score32_resident = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

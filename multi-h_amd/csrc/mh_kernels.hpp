@@ -46,7 +46,8 @@ hipError_t launch_score(const Points& p, const double* H, int M, double thr2,
 hipError_t launch_model32(const double* H, int M, double X, double Y, double Cmax, float* H32 /* M x 16 */, hipStream_t s);
 // Cmax: the bound on |x2|, |y2| the table was made with; thr2 in [2^-40, 2^40]
 hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
-                          int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s);
+                          int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s, int* resident_ctl = nullptr,
+                          int cu_count = 256, int resident_slices = 0);
 // the materialised int32 cost matrix (launch_cost_matrix, datacost.hip) through the same pre-test; H32 made with the same Cmax
 hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
                          int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl = nullptr, int cu_count = 256,

@@ -89,17 +89,18 @@ k_model32(const double* __restrict__ H, int M, double X, double Y, double Cmax, 
     o[13] = o[14] = o[15] = 0.f;
 }
 
-template <int PPL, int MC, bool MASK, int MINW = 1>
-__global__ void __launch_bounds__(256, MINW)
-k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
-          const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
-          double thr2, float thr2_f, float c_thr, float k1, int* __restrict__ counts, const unsigned char* __restrict__ mask,
-          int psplit, unsigned long long* __restrict__ fallback_pairs)
+// score32_wg: the work of ONE workgroup — model block bx (MC models), point slice by.
+template <int PPL, int MC, bool MASK>
+__device__ __forceinline__ void
+score32_wg(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+           const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+           double thr2, float thr2_f, float c_thr, float k1, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+           int psplit, unsigned long long* __restrict__ fallback_pairs, const int bx, const int by)
 {
     constexpr int WAVE_PTS = 64 * PPL, TILE = 4 * WAVE_PTS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m0 = blockIdx.x * MC;
+    const int m0 = bx * MC;
     __shared__ float4 s_m[MC * 4];               // this workgroup's rows of the model table
     for (int i = threadIdx.x; i < MC * 4; i += 256) {
         const size_t g = (size_t)m0 * 4 + i;
@@ -113,7 +114,7 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
     asm volatile("v_mov_b32 %0, %1" : "=v"(vk1) : "s"(k1));
     int cnt = 0;                                 // lane mi of each wave counts model m0 + mi
     unsigned long long fb = 0;                   // pairs this lane sent to FP64 (diagnostic)
-    for (int base = blockIdx.y * TILE; base < N; base += psplit * TILE) {
+    for (int base = by * TILE; base < N; base += psplit * TILE) {
         const int n0 = base + wave * WAVE_PTS + lane * PPL;
         // only the FP32 copies of the points stay in registers; the rare FP64 decision reloads its point (L2-resident)
         float fx[PPL], fy[PPL], gx[PPL], gy[PPL], cx[PPL];
@@ -210,6 +211,41 @@ k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const do
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) fb += __shfl_xor(fb, o, 64);
         if (lane == 0 && fb) atomicAdd(fallback_pairs, fb);
+    }
+}
+
+template <int PPL, int MC, bool MASK, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
+k_score32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+          const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+          double thr2, float thr2_f, float c_thr, float k1, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+          int psplit, unsigned long long* __restrict__ fallback_pairs)
+{
+    score32_wg<PPL, MC, MASK>(x1, y1, x2, y2, N, H, H32, M, thr2, thr2_f, c_thr, k1, counts, mask, psplit, fallback_pairs, blockIdx.x, blockIdx.y);
+}
+
+// The same work items walked by a resident grid that hands them out through a counter (as k_residual_resident, residual.hip).
+template <int PPL, int MC, bool MASK, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
+k_score32_resident(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+                   const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+                   double thr2, float thr2_f, float c_thr, float k1, int* __restrict__ counts, const unsigned char* __restrict__ mask,
+                   int psplit, unsigned long long* __restrict__ fallback_pairs, int gx, int nitems, int* __restrict__ ctl)
+{
+    __shared__ int s_item;
+#pragma unroll 1
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&ctl[0], 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= nitems) break;
+        const int by = item / gx, bx = item - by * gx;
+        score32_wg<PPL, MC, MASK>(x1, y1, x2, y2, N, H, H32, M, thr2, thr2_f, c_thr, k1, counts, mask, psplit, fallback_pairs, bx, by);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && atomicAdd(&ctl[1], 1) == (int)gridDim.x - 1) {
+        ctl[1] = 0;
+        __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -450,10 +486,20 @@ hipError_t launch_model32(const double* H, int M, double X, double Y, double Cma
 
 template <int PPL, int MC, int MINW = 1>
 static hipError_t launch_score32_t(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
-                                   int* counts, unsigned long long* fallback_pairs, hipStream_t s)
+                                   int* counts, unsigned long long* fallback_pairs, hipStream_t s, int* resident_ctl = nullptr,
+                                   int cu_count = 256, int resident_slices = 0)
 {
     const int gx = (M + MC - 1) / MC, ntiles = (p.n + 256 * PPL - 1) / (256 * PPL);
     int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 16 ? 4 : 1);
+    int resident = 0;
+    if (resident_ctl && resident_slices != 0 && !mask) {
+        static int per_cu = -1;
+        if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_score32_resident<PPL, MC, false, MINW>, 256, 0) != hipSuccess) per_cu = 0;
+        int ps = resident_slices > 0 ? resident_slices : (37500 + gx - 1) / gx;
+        if (ps > ntiles) ps = ntiles;
+        if (ps < 1) ps = 1;
+        if (per_cu * cu_count > 0 && gx * ps > per_cu * cu_count) { resident = per_cu * cu_count; psplit = ps; }
+    }
     if (psplit > ntiles) psplit = ntiles;
     if (psplit < 1) psplit = 1;
     if (psplit > 1) {
@@ -466,6 +512,11 @@ static hipError_t launch_score32_t(const Points& p, const double* H, const float
     const float c_thr = (float)(std::fabs((double)tf - thr2) * 1.01 + 3.5 * 5.9604644775390625e-08 * std::fabs(thr2) * 1.01) + 1e-45f;
     // the cheap test's k1 = max(1.12 thr, 25.4 u Cmax), rounded up (the product k1 sigma is rounded once more in the kernel)
     const float k1 = (float)(std::fmax(1.12 * std::sqrt(std::fabs(thr2)), 25.4 * 5.9604644775390625e-08 * Cmax) * (1.0 + 1e-6)) + 1e-30f;
+    if (resident > 0) {
+        hipLaunchKernelGGL((k_score32_resident<PPL, MC, false, MINW>), dim3(resident), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf,
+                           c_thr, k1, counts, mask, psplit, fallback_pairs, gx, gx * psplit, resident_ctl);
+        return hipGetLastError();
+    }
     if (mask) hipLaunchKernelGGL((k_score32<PPL, MC, true, MINW>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, k1, counts, mask, psplit, fallback_pairs);
     else hipLaunchKernelGGL((k_score32<PPL, MC, false, MINW>), dim3(gx, psplit), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, thr2, tf, c_thr, k1, counts, mask, psplit, fallback_pairs);
     return hipGetLastError();
@@ -474,9 +525,12 @@ static hipError_t launch_score32_t(const Points& p, const double* H, const float
 // H32: the table launch_model32 made for these M models.  fallback_pairs (nullable): device counter of the pairs decided in
 // FP64.  tiling: points per lane / models per workgroup (a schedule choice; the counts do not depend on it).
 hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
-                          int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s)
+                          int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s, int* resident_ctl, int cu_count,
+                          int resident_slices)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
+    if (tiling == 0 && resident_ctl && resident_slices != 0)
+        return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s, resident_ctl, cu_count, resident_slices);
     switch (tiling) {
     case 1: return launch_score32_t<4, 16>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     case 2: return launch_score32_t<8, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);

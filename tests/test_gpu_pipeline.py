@@ -107,6 +107,23 @@ def test_cost_matrix_as_a_resident_grid_equals_the_dispatched_one(engine, synth)
     assert (C0 != C0.max()).sum() > 1000
 
 
+def test_score_as_a_resident_grid_equals_the_dispatched_one_and_the_oracle(engine, synth, oracle):
+    """r04: k_score32 walked by a resident grid (mh_set_tuning key 24): the same counts as one hardware-dispatched workgroup
+    per item and as the oracle's score loop, at a size where the resident form runs."""
+    sc = synth.make_scene(20011, 4, seed=6, with_neighbours=False)
+    _load(engine, sc)
+    engine.propose_dlt4(8, 0, 12001)
+    with np.errstate(all="ignore"):
+        want = oracle.score(sc.src, sc.dst, engine.get_models(), THR2)
+    try:
+        for v in (0, 12, -1, 5):
+            engine.set_tuning(24, v)
+            assert np.array_equal(engine.score(THR2), want), v
+    finally:
+        engine.set_tuning(24, 12)
+    assert want.max() > 1000
+
+
 def _rccl(mh):
     lib = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_rccl.so"))
     lib.mhr_last_error.restype = C.c_char_p
