@@ -1739,7 +1739,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
                 return fail(MH_ERR_HIP, "greedy selection: injected rank-local failure (test hook, mh_set_tuning key 18)");
             if (Mc <= 0) return MH_OK;
             ScopedTimer t(e, MH_K_SCORE);
-            if (active == n) return score_models(e, e->pts(), Hs, Mc, thr2, e->mask.p, e->sel_counts.p);
+            if (active == n) return score_models(e, e->pts(), Hs, Mc, thr2, nullptr, e->sel_counts.p);     // every point is in the support set: no mask to read
             if (active > 0) {
                 HIPCHK(launch_sel_pack_points(e->pts(), e->mask.p, e->sel_pts[0].p, e->sel_pts[1].p, e->sel_pts[2].p, e->sel_pts[3].p,
                                               e->sel_pack_count.p, s));
