@@ -15,6 +15,7 @@
 //                                N = 1 runs the same protocol on a one-rank communicator.
 // Defaults are the harness defaults of the reference (M/main.cpp:55-59).
 #include <algorithm>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -167,6 +168,11 @@ int main(int argc, char** argv)
             if (got != MHR_ID_BYTES) { std::cerr << "[Multi-H] rank " << rank << ": no RCCL id from rank 0\n"; return finish(1); }
         }
         if (rc == 0) {
+            signal(SIGALRM, [](int) {
+                static const char msg[] = "[Multi-H] the RCCL communicator was not complete after 300 s (a rank died?): giving up\n";
+                (void)!write(2, msg, sizeof(msg) - 1);
+                _exit(1);
+            });
             alarm(300);                          // ncclCommInitRank waits for every rank: a peer that died must not hang the others
             rc = init_id(&comm, rank, std::max(ranks, 1), id, rank);
             alarm(0);
