@@ -345,8 +345,8 @@ def main():
 
         def step(i: int, last: bool = False):
             if pipelined:
-                eng.adopt_prefetched()                           # batch i (its DLT ran beside the previous sweep)
-                eng.prefetch_dlt4(a.seed, first_of(i + 1), M)    # batch i+1 on the second stream, beside this sweep
+                eng.adopt_prefetched()                           # batch i (its DLT was dispatched two sweeps ago)
+                eng.prefetch_dlt4(a.seed, first_of(i + 2), M)    # batch i+2 on the second stream (the queue holds two batches)
             else:
                 eng.propose_dlt4(a.seed, first_of(i), M)
             eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
@@ -354,6 +354,7 @@ def main():
 
         if pipelined:
             eng.prefetch_dlt4(a.seed, first_of(0), M)
+            eng.prefetch_dlt4(a.seed, first_of(1), M)
         for i in range(warmup):
             step(i)
         fence()
@@ -378,6 +379,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if pipelined:                            # the two batches still queued are not part of any step: drop them
+            eng.adopt_prefetched()
+            eng.adopt_prefetched()
         n_res, ms_res = eng.profile_get(1)       # MH_K_RESIDUAL
         n_dlt, ms_dlt = eng.profile_get(0)       # MH_K_DLT4 (on the second stream, beside the sweep)
         best, score = last
@@ -402,13 +406,14 @@ def main():
         M = sharding.shard_counts(a.models, world)[rank] if a.scaling == "strong" else a.models
         first = lambda i: i * a.models
         eng.prefetch_dlt4(a.seed, first(0), M)
+        eng.prefetch_dlt4(a.seed, first(1), M)
         i, t_gpu, per_block = 0, 0.0, []
         while keep_going() or i == 0:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(block):
                 eng.adopt_prefetched()
-                eng.prefetch_dlt4(a.seed, first(i + 1), M)
+                eng.prefetch_dlt4(a.seed, first(i + 2), M)
                 eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
                 eng.select_best(M, fetch=False)
                 i += 1
@@ -416,6 +421,7 @@ def main():
             eng.synchronize()
             per_block.append((time.perf_counter() - t0) / block * 1e3)
             t_gpu += per_block[-1] * block * 1e-3
+        eng.adopt_prefetched()
         eng.adopt_prefetched()
         return {"steps": i, "seconds": t_gpu, "hypotheses_per_s": i * float(M) / t_gpu, "ms_per_step_first_block": per_block[0],
                 "ms_per_step_last_block": per_block[-1], "ms_per_step_mean": t_gpu / i * 1e3,

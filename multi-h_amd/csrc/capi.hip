@@ -102,16 +102,20 @@ struct mh_engine {
     void* t_ctx = nullptr;
     // pipelined propose (mh_prefetch_dlt4): the spare batch and the second stream it is prepared on
     hipStream_t side_stream = nullptr;
-    hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_side_pre = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side_pre = nullptr;
     int tune_score32_resident = 12;          // key 24: the FP32 pre-test score as a resident grid with n point slices (12: 1.98 ms against 2.14 hardware-dispatched at 50k x 100k, tools/score32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_cost32_resident = 8;            // key 23: the int32 cost matrix as a resident grid with n point slices (8: 4.12 ms against 4.25 hardware-dispatched at 50k x 100k, tools/cost32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_stream_shift = 0;               // key 22 (experiment): dummy streams created in front of the second / third stream (shifts their hardware queue / pipe)
     std::vector<hipStream_t> dummy_streams;
     int tune_dlt_first = 1;                  // key 20: the sweep waits until the second stream has reached the pending DLT's dispatch (1) or not (0)
-    DevBuf<double> H_next;
-    DevBuf<int> samples_next;
-    int m_next = 0;
-    bool next_valid = false;
+    // up to two prefetched batches wait in a FIFO (r04: with the batch after next prepared too, the DLT a sweep has to wait
+    // for was dispatched a whole sweep earlier — nothing is handed from stream to stream between two sweeps)
+    static constexpr int PF_DEPTH = 2;
+    DevBuf<double> pf_H[PF_DEPTH];
+    DevBuf<int> pf_samples[PF_DEPTH];
+    int pf_m[PF_DEPTH] = { 0, 0 };
+    hipEvent_t pf_ev[PF_DEPTH] = { nullptr, nullptr };   // recorded behind the slot's DLT on the second stream
+    int pf_head = 0, pf_count = 0;                       // oldest queued slot, number of queued batches
     // best model of a scored batch (mh_select_best).  The (all-gather +) arg-max of batch i runs on a third stream behind an
     // event of sweep i, so sweep i+1 starts at once: the batch's counts buffer goes to the exchange and the next sweep
     // writes the other one (r04)
@@ -831,9 +835,9 @@ void mh_destroy(mh_engine* e)
     for (int b = 0; b < 2; ++b) { e->sel_orig[b].release(); e->sel_cand_H[b].release(); }
     e->sel_counts.release(); e->sel_rec.release(); e->sel_scores.release(); e->sel_gathered.release(); e->sel_out_H.release();
     e->sel_records.release(); e->sel_counter.release(); e->sel_keys.release();
-    e->H_next.release(); e->samples_next.release(); e->best_key.release(); e->H32.release(); e->fb_pairs.release();
+    for (int q = 0; q < mh_engine::PF_DEPTH; ++q) { e->pf_H[q].release(); e->pf_samples[q].release(); if (e->pf_ev[q]) (void)hipEventDestroy(e->pf_ev[q]); }
+    e->best_key.release(); e->H32.release(); e->fb_pairs.release();
     if (e->h_best) (void)hipHostFree(e->h_best);
-    if (e->ev_side) (void)hipEventDestroy(e->ev_side);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
     if (e->ev_side_pre) (void)hipEventDestroy(e->ev_side_pre);
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
@@ -894,8 +898,8 @@ int mh_set_correspondences(mh_engine* e, const double* src_xy, const double* dst
     // prepares belongs to the OLD point set: wait for it and drop it (r03 advisor finding).
     rc0 = quiesce(e);
     if (rc0) return rc0;
-    e->next_valid = false;
-    e->m_next = 0;
+    e->pf_count = 0;
+    e->pf_head = 0;
     // +1 element of slack: the 16-B vector loads of the residual sweep never cross the end,
     // but keep the allocation even-sized for them.
     const size_t cap = (size_t)n + 2;
@@ -1550,7 +1554,9 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     // ... and it starts behind the DLT's dispatch, not beside it: a sweep that reaches the chip first fills every
     // workgroup slot and keeps them (its queue is dispatched ahead of the other stream's whatever the priorities), and
     // the DLT then runs after the sweep instead of beside it — the next sweep waits for it (profiles/r04_timeline_*.txt).
-    if (e->next_valid && e->tune_dlt_first && e->ev_side_pre) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_side_pre, 0));
+    // (only when the pending batch is the very NEXT one: with two batches queued the DLT the next sweep waits for was dispatched
+    // a sweep ago, and the one just enqueued has a whole sweep of slack — it runs in this sweep's tail)
+    if (e->pf_count == 1 && e->tune_dlt_first && e->ev_side_pre) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_side_pre, 0));
     {
         ScopedTimer t(e, MH_K_RESIDUAL);
         HIPCHK(launch_residual(e->pts(), e->H.p, e->m, thr2, e->R.p, e->ldr, e->counts.p,
@@ -1826,7 +1832,8 @@ static int ensure_side_stream(mh_engine* e)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, hi));
     }
-    if (!e->ev_side) HIPCHK(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+    for (int q = 0; q < mh_engine::PF_DEPTH; ++q)
+        if (!e->pf_ev[q]) HIPCHK(hipEventCreateWithFlags(&e->pf_ev[q], hipEventDisableTiming));
     if (!e->ev_main) HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
     if (!e->ev_side_pre) HIPCHK(hipEventCreateWithFlags(&e->ev_side_pre, hipEventDisableTiming));
     return MH_OK;
@@ -1841,25 +1848,27 @@ int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int
     if (e->n < 4) return fail(MH_ERR_INVALID, "need at least 4 correspondences");
     rc = ensure_side_stream(e);
     if (rc) return rc;
-    if (e->H_next.cap < (size_t)m * 9 || e->samples_next.cap < (size_t)m * 4) {
+    if (e->pf_count >= mh_engine::PF_DEPTH) return fail(MH_ERR_INVALID, "two batches are already prefetched: adopt one first (mh_adopt_prefetched)");
+    const int slot = (e->pf_head + e->pf_count) % mh_engine::PF_DEPTH;
+    if (e->pf_H[slot].cap < (size_t)m * 9 || e->pf_samples[slot].cap < (size_t)m * 4) {
         // (re)allocation: nothing may still be reading the spare buffers
         HIPCHK(hipStreamSynchronize(e->side_stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        HIPCHK(e->H_next.reserve((size_t)m * 9));
-        HIPCHK(e->samples_next.reserve((size_t)m * 4));
+        HIPCHK(e->pf_H[slot].reserve((size_t)m * 9));
+        HIPCHK(e->pf_samples[slot].reserve((size_t)m * 4));
     }
-    // The spare buffers held the batch that was current before the last adoption; kernels of the main stream enqueued
-    // up to now may still read them.
+    // The slot's buffers held a batch that was current before an adoption; kernels of the main stream enqueued up to now
+    // may still read them.
     HIPCHK(hipEventRecord(e->ev_main, e->stream));
     HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_main, 0));
     HIPCHK(hipEventRecord(e->ev_side_pre, e->side_stream));      // the second stream has got as far as this batch's dispatch
     {
         ScopedTimer t(e, MH_K_DLT4, e->side_stream);           // (the kernel's span on the second stream, beside whatever the main one runs)
-        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples_next.p, e->H_next.p, e->side_stream));
+        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->pf_samples[slot].p, e->pf_H[slot].p, e->side_stream));
     }
-    HIPCHK(hipEventRecord(e->ev_side, e->side_stream));
-    e->m_next = m;
-    e->next_valid = true;
+    HIPCHK(hipEventRecord(e->pf_ev[slot], e->side_stream));
+    e->pf_m[slot] = m;
+    ++e->pf_count;
     return MH_OK;
     });
 }
@@ -1869,14 +1878,16 @@ int mh_adopt_prefetched(mh_engine* e)
     return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
-    if (!e->next_valid) return fail(MH_ERR_NOT_SET, "no prefetched batch (mh_prefetch_dlt4)");
-    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_side, 0));        // main-stream work behind this point sees the new batch
-    std::swap(e->H, e->H_next);
-    std::swap(e->samples, e->samples_next);
-    HIPCHK(reserve_counts(e, (size_t)e->m_next + 1));
-    e->m = e->m_next;
+    if (e->pf_count <= 0) return fail(MH_ERR_NOT_SET, "no prefetched batch (mh_prefetch_dlt4)");
+    const int slot = e->pf_head;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->pf_ev[slot], 0));    // main-stream work behind this point sees the new batch
+    std::swap(e->H, e->pf_H[slot]);
+    std::swap(e->samples, e->pf_samples[slot]);
+    HIPCHK(reserve_counts(e, (size_t)e->pf_m[slot] + 1));
+    e->m = e->pf_m[slot];
+    e->pf_head = (e->pf_head + 1) % mh_engine::PF_DEPTH;
+    --e->pf_count;
     e->have_samples = true;
-    e->next_valid = false;
     e->cost_L = 0;
     e->counts_fresh = false; ++e->models_seq;
     return MH_OK;

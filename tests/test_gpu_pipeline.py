@@ -390,3 +390,33 @@ def test_resident_sweep_beside_a_prefetch_equals_the_dispatched_sweep(engine, sy
             assert np.array_equal(engine.get_models().view(np.uint64), H.view(np.uint64))
     finally:
         engine.set_tuning(19, 0)
+
+
+def test_two_batches_prefetched_ahead(mh, engine, synth):
+    """r04: the prefetch queue holds two batches (the batch after next is prepared too, so the DLT a sweep waits for was
+    dispatched a whole sweep earlier).  First in, first out; a third prefetch is refused; tuples, homographies and the counts
+    of the sweeps are those of mh_propose_dlt4, bit for bit, through several turns of the three buffers and changing sizes."""
+    sc = synth.make_scene(3000, 3, seed=12, with_neighbours=False)
+    _load(engine, sc)
+    sizes = (700, 512, 1300, 700, 90, 2048, 333)
+    want = []
+    for i, m in enumerate(sizes):
+        engine.propose_dlt4(33, 10000 * i, m)
+        _, cnt = engine.residual_matrix(THR2, fetch_R=False)
+        want.append((engine.get_samples(), engine.get_models(), cnt))
+    engine.prefetch_dlt4(33, 0, sizes[0])
+    engine.prefetch_dlt4(33, 10000, sizes[1])
+    with pytest.raises(mh.MultiHError) as ei:
+        engine.prefetch_dlt4(33, 20000, sizes[2])
+    assert ei.value.code == -2
+    for i, m in enumerate(sizes):
+        engine.adopt_prefetched()
+        if i + 2 < len(sizes):
+            engine.prefetch_dlt4(33, 10000 * (i + 2), sizes[i + 2])          # beside / behind the sweep below
+        _, cnt = engine.residual_matrix(THR2, fetch_R=False)
+        engine.select_best(m, fetch=False)
+        idx, H = engine.get_samples(), engine.get_models()
+        assert np.array_equal(idx, want[i][0]) and np.array_equal(H.view(np.uint64), want[i][1].view(np.uint64)), i
+        assert np.array_equal(cnt, want[i][2]), i
+    with pytest.raises(mh.MultiHError):
+        engine.adopt_prefetched()
