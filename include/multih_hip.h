@@ -226,10 +226,14 @@ MH_API int mh_set_transport(mh_engine* e, int rank, int world, mh_allgather_stre
  * the same on every rank. */
 MH_API int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsigned char* point_mask,
                             double* H_out, long long* counters_out, int* counts_out, int* selected_out, long long total_m);
-/* Pipelined propose: mh_prefetch_dlt4 prepares the batch (seed, first .. first+m-1) in the engine's SPARE model buffer on a
- * second stream, concurrently with whatever the main stream is doing (the DLT solver is LDS-bound, the residual sweep
- * HBM/FP64-bound; csrc/dlt4.hip); mh_adopt_prefetched makes it the current model set — the main stream waits for the
- * side stream's event, the host does not wait at all.  Same hypotheses, bit for bit, as mh_propose_dlt4. */
+/* Pipelined propose: mh_prefetch_dlt4 prepares the batch (seed, first .. first+m-1) in one of the engine's spare model buffers
+ * on a second stream, concurrently with whatever the main stream is doing (csrc/dlt4.hip); mh_adopt_prefetched makes the OLDEST
+ * prepared batch the current model set — the main stream waits for the side stream's event, the host does not wait at all.
+ * Up to TWO batches may be prepared ahead (a third mh_prefetch_dlt4 answers MH_ERR_INVALID until one is adopted).  With the
+ * batch after next prepared too — adopt i, prefetch i+2, sweep i — the DLT a sweep waits for was dispatched a whole sweep
+ * earlier and nothing is handed from stream to stream between two sweeps; with one batch ahead the sweep is held until the
+ * second stream has reached the DLT's dispatch (a sweep that reaches the chip first leaves the DLT no room until it ends).
+ * Same hypotheses, bit for bit, as mh_propose_dlt4.  mh_set_correspondences drops whatever is queued. */
 MH_API int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int m);
 MH_API int mh_adopt_prefetched(mh_engine* e);
 /* Best-supported model of the scored batch (highest resident inlier count, lowest position in the whole batch on ties) by

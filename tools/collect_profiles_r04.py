@@ -31,6 +31,13 @@ strip(os.path.join(E, "shard_proxy.txt"), "r04_shard_proxy.txt", drop=r"^RCCL ve
 with open(os.path.join(P, "r04_shard_proxy.txt"), "a") as f:
     f.write("\n-- A/B: hardware dispatch (headroom -1) vs resident grid, with and without the gate that holds the sweep behind the DLT's dispatch\n")
     f.writelines(l for l in open(os.path.join(E, "shard_proxy_ab.txt"), errors="replace") if l.startswith("M ") or l.startswith("== workgroup"))
+    f.write("\n-- A/B: ONE batch prepared ahead (DEPTH=1: the sweep is held until the second stream has reached the DLT's dispatch) instead of two\n")
+    keep = False
+    for l in open(os.path.join(E, "shard_proxy_depth1.txt"), errors="replace"):
+        if l.startswith("== "): keep = True
+        if keep and not l.startswith("{") and not re.search(r"^RCCL version|^HIP version|^ROCm version|^Hostname|^Librccl|amdgpu.ids", l): f.write(l)
+    f.write("\n-- tools/enqueue_probe.py (two batches ahead, no timing events on the stream)\n")
+    f.writelines(l for l in open(os.path.join(E, "enqueue_probe.txt"), errors="replace") if l.startswith("M "))
     f.write(f"source: HEAD {sha}\n")
 for m in (12500, 100000):
     cp(os.path.join(E, f"timeline_{m}.txt"), f"r04_timeline_{m}.txt")
