@@ -120,11 +120,14 @@ struct mh_engine {
     // event of sweep i, so sweep i+1 starts at once: the batch's counts buffer goes to the exchange and the next sweep
     // writes the other one (r04)
     hipStream_t xchg_stream = nullptr;
-    hipEvent_t ev_sweep = nullptr, ev_x[2] = { nullptr, nullptr };
-    DevBuf<int> counts_alt;
+    hipEvent_t ev_sweep = nullptr, ev_x[3] = { nullptr, nullptr, nullptr };
+    // two counts buffers wait in a FIFO beside the current one: a buffer handed to exchange k comes back for sweep k + 3, so an
+    // exchange has TWO sweeps to finish in before anything waits for it (with one spare buffer it had one)
+    DevBuf<int> counts_alt[2];
+    int counts_alt_wait[2] = { -1, -1 };          // which ev_x the buffer's last exchange records (-1: none)
     long long xchg_calls = 0;                  // exchanges enqueued on xchg_stream so far (parity selects ev_x)
     long long models_seq = 0, best_models_seq = -1;   // model-set generation; the one the last mh_select_best result belongs to
-    bool counts_zeroed_alt = false;            // the same for the other buffer
+    bool counts_zeroed_alt[2] = { false, false };   // the same for the two waiting buffers
     bool counts_zeroed = false;                // the current counts buffer was cleared behind the exchange that last read it (the next sweep skips its memset)
     bool counts_fresh = false;                 // the current counts buffer holds the scores of the current model set (a scoring call wrote it)
     bool xchg_pending = false;                 // something enqueued on xchg_stream since the last host wait for it
@@ -311,7 +314,7 @@ int quiesce(mh_engine* e)
 int join_xchg(mh_engine* e)
 {
     if (e->xchg_pending && e->xchg_calls > 0)
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_x[(e->xchg_calls - 1) & 1], 0));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_x[(e->xchg_calls - 1) % 3], 0));
     return MH_OK;
 }
 
@@ -843,8 +846,8 @@ void mh_destroy(mh_engine* e)
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->xchg_stream) { (void)hipStreamSynchronize(e->xchg_stream); (void)hipStreamDestroy(e->xchg_stream); }
     if (e->ev_sweep) (void)hipEventDestroy(e->ev_sweep);
-    for (int b = 0; b < 2; ++b) if (e->ev_x[b]) (void)hipEventDestroy(e->ev_x[b]);
-    e->counts_alt.release(); e->sweep_ctl.release();
+    for (int b = 0; b < 3; ++b) if (e->ev_x[b]) (void)hipEventDestroy(e->ev_x[b]);
+    e->counts_alt[0].release(); e->counts_alt[1].release(); e->sweep_ctl.release();
     for (hipStream_t d : e->dummy_streams) (void)hipStreamDestroy(d);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -1905,7 +1908,7 @@ static int ensure_xchg_stream(mh_engine* e)
         HIPCHK(hipStreamCreateWithPriority(&e->xchg_stream, hipStreamNonBlocking, hi));
     }
     if (!e->ev_sweep) HIPCHK(hipEventCreateWithFlags(&e->ev_sweep, hipEventDisableTiming));
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 3; ++b)
         if (!e->ev_x[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_x[b], hipEventDisableTiming));
     return MH_OK;
 }
@@ -1992,7 +1995,7 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
         } else {
             HIPCHK(launch_best_fused(e->counts.p, 1, e->m, 0, 0, e->h_best_dev, clear, clear_count, x));
         }
-        const int par = (int)(e->xchg_calls & 1);
+        const int par = (int)(e->xchg_calls % 3);
         HIPCHK(hipEventRecord(e->ev_x[par], x));
         ++e->xchg_calls;
         e->xchg_pending = true;
@@ -2002,14 +2005,17 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
             HIPCHK(hipStreamSynchronize(x));
             e->xchg_pending = false;
         } else {
-            // this batch's counts stay with the exchange; the next sweep writes the other buffer — once the exchange that
-            // was given THAT one (the previous call's, a whole step ago) is through
-            std::swap(e->counts, e->counts_alt);
-            std::swap(e->counts_zeroed_alt, e->counts_zeroed);      // (this call's buffer will be clear once ev_x[par] has passed)
-            e->counts_zeroed_alt = true;
+            // this batch's counts stay with the exchange; the next sweep writes the buffer that has waited longest — once the
+            // exchange that was given THAT one (two calls ago) is through
+            DevBuf<int> mine = e->counts;
+            const int wait = e->counts_alt_wait[0];
+            e->counts = e->counts_alt[0];
+            e->counts_zeroed = e->counts_zeroed_alt[0];
+            e->counts_alt[0] = e->counts_alt[1]; e->counts_zeroed_alt[0] = e->counts_zeroed_alt[1]; e->counts_alt_wait[0] = e->counts_alt_wait[1];
+            e->counts_alt[1] = mine; e->counts_zeroed_alt[1] = true; e->counts_alt_wait[1] = par;      // (clear once ev_x[par] has passed)
             e->counts_fresh = false;
             HIPCHK(reserve_counts(e, (size_t)e->m + 1));
-            if (e->xchg_calls >= 2) HIPCHK(hipStreamWaitEvent(s, e->ev_x[par ^ 1], 0));
+            if (wait >= 0) HIPCHK(hipStreamWaitEvent(s, e->ev_x[wait], 0));
         }
     }
     if (fetch) {
