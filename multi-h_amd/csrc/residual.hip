@@ -302,12 +302,12 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
         x1, y1, x2, y2, N, H, M, thr2, R, ldr, counts, mask, psplit, bx0, bx1, by0, by1, bx, by);
 }
 
-// The same work items walked by a RESIDENT grid (r04): gridDim.x workgroups stride over the gx x psplit items, item ->
-// (model block item % gx, slice item / gx).  The launch is sized a little below what the chip holds, so the workgroup
-// slots it leaves free stay free for the whole sweep — that is where the DLT solve of the next batch runs (second
-// stream).  With one hardware-dispatched workgroup per item the sweep refills every slot the moment it frees, stream
-// priority notwithstanding: a 12 500-hypothesis DLT (60 us alone) took the whole 1.07 ms sweep and another 110 us behind
-// it, during which the next sweep waited (profiles/r04_timeline_*.txt).
+// The same work items walked by a RESIDENT grid (r04): as many workgroups as the chip holds at this kernel's occupancy
+// (81 registers, 30 scalar registers spilt into one of them -> 88 allocated: five waves per SIMD, 1 280 workgroups on 256
+// CUs) hand themselves the gx x psplit items — item -> (model block item % gx, slice item / gx) — through a counter.
+// Measured against one hardware-dispatched workgroup per item at 50k x 100k: 7.27-7.31 ms vs 7.48-7.70 (the launch and
+// retirement of 37 500 workgroups, and a dispatcher that refills every slot the moment it frees, cost more than the
+// counter).  Holding the kernel to 80 registers for a sixth wave does not work: the scalar spills need the 81st.
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
           bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW) __attribute__((amdgpu_num_vgpr(88)))      // 5 waves per SIMD and 72 registers left for k_dlt4
