@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <mutex>
 
 #include "merge_step.h"
 #include "multih_hip.h"
@@ -55,9 +56,53 @@ MultiH::MultiH(double _thr_fund_mat, double _thr_hom, double _locality, double _
 
 MultiH::~MultiH() { Release(); }
 
+// Engines are REUSED from one MultiH object to the next (r04).  The reference's harness makes a new MultiH per image pair
+// (M/main.cpp:262); creating and destroying an engine — streams, a few dozen device buffers, their release with the device
+// synchronisations that implies — costs 2.5 ms, a third of a whole Process() on a scene of 500 correspondences.  An engine
+// carries no result from one call to the next: every Process() sets parameters, transport and correspondences anew, and
+// mh_set_correspondences drops everything derived from the previous point set.  Engines that were given tuning knobs, or
+// whose stream does not drain cleanly, are destroyed instead.  MULTIH_ENGINE_POOL=0 switches the reuse off.
+namespace {
+struct EnginePool {
+    std::mutex mu;
+    std::vector<std::pair<int, mh_engine*>> idle;      // (device, engine), at most two
+};
+EnginePool& engine_pool()
+{
+    static EnginePool* p = new EnginePool();           // never destroyed: the HIP runtime may be gone by the time statics are
+    return *p;
+}
+bool engine_pool_enabled()
+{
+    const char* v = std::getenv("MULTIH_ENGINE_POOL");
+    return !(v && v[0] == '0');
+}
+} // namespace
+
+extern "C" __attribute__((visibility("default")))
+void mhh_release_engine_pool()
+{
+    EnginePool& p = engine_pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    for (auto& de : p.idle) mh_destroy(de.second);
+    p.idle.clear();
+}
+
 void MultiH::Release()
 {
-    if (engine) { mh_destroy(engine); engine = nullptr; }
+    if (!engine) return;
+    if (engine_tuning.empty() && engine_pool_enabled() && mh_synchronize(engine) == MH_OK &&
+        mh_set_transport(engine, 0, 1, nullptr, nullptr, nullptr) == MH_OK) {
+        EnginePool& p = engine_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        if (p.idle.size() < 2) {
+            p.idle.emplace_back(device, engine);
+            engine = nullptr;
+            return;
+        }
+    }
+    mh_destroy(engine);
+    engine = nullptr;
 }
 
 void MultiH::SetEpipolarGeometry(const double F[9], const double e2[2])
@@ -95,6 +140,12 @@ bool MultiH::Process(std::vector<cv::Point2d> _srcPoints, std::vector<cv::Point2
 
 bool MultiH::EnsureEngine()
 {
+    if (!engine && engine_tuning.empty() && engine_pool_enabled()) {
+        EnginePool& p = engine_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        for (size_t i = 0; i < p.idle.size(); ++i)
+            if (p.idle[i].first == device) { engine = p.idle[i].second; p.idle.erase(p.idle.begin() + (long)i); break; }
+    }
     if (!engine) {
         if (!Check(mh_create(&engine, device), "mh_create")) return false;
         for (const auto& kv : engine_tuning)

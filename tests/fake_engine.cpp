@@ -23,6 +23,7 @@ const char* mh_last_error(void) { return "fake engine"; }
 int mh_create(mh_engine** out, int) { *out = new mh_engine(); (*out)->mode = g_mode; return MH_OK; }
 void mh_destroy(mh_engine* e) { delete e; }
 int mh_set_params(mh_engine*, double, double, double, double, int) { return MH_OK; }
+int mh_synchronize(mh_engine*) { return MH_OK; }
 int mh_set_correspondences(mh_engine* e, const double* s, const double* d, const double* a, int n)
 {
     e->n = n;

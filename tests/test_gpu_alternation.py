@@ -249,3 +249,33 @@ def test_process_from_raw_correspondences_equals_the_oracle(mh, engine, synth, o
     assert np.all(labels[kept:] == -7), "labels cover the kept correspondences only"
     _assert_same_result((k, labels[:kept], H, it, en), want)
     assert k >= 2
+
+
+def test_engines_reused_between_multih_objects_carry_nothing_over(mh, engine_lib, synth):
+    """r04: the host class hands its engine to the next MultiH object instead of destroying it (2.5 ms of a 7 ms Process() on a
+    small scene).  Nothing of one call may show in the next: scene A, then B (another size, another F), then A again — with
+    the DLT route, the reference's own route and given initial models — gives A's first result bit for bit, and the same as
+    with the reuse switched off."""
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    A = synth.make_scene(1500, 3, seed=71, with_neighbours=False)
+    B = synth.make_scene(2600, 4, seed=72, with_neighbours=False)
+    H0 = _initial_models(A, 71, 2, 1)
+
+    def runs():
+        out = []
+        for sc, kw in ((A, dict(hypotheses=3000, max_models=8)), (B, dict(hypotheses=2000, max_models=8)), (A, dict(stable_sets=True)),
+                       (B, dict(hypotheses=2500, max_models=6)), (A, dict(H0=H0)), (A, dict(hypotheses=3000, max_models=8))):
+            k, labels, H, it, en = _run_process(mh, sc, 5, **kw)
+            out.append((k, labels.tobytes(), H.tobytes(), it, en))
+        return out
+
+    host.mhh_release_engine_pool()
+    first = runs()
+    assert first[0] == first[5], "the same call after other scenes went through the same engine"
+    os.environ["MULTIH_ENGINE_POOL"] = "0"
+    try:
+        fresh = runs()
+    finally:
+        del os.environ["MULTIH_ENGINE_POOL"]
+    assert first == fresh
+    host.mhh_release_engine_pool()

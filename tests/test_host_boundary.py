@@ -28,7 +28,8 @@ def test_apply_multih_sequence_is_memory_clean_under_opencv_ownership_rules(tmp_
     if b.returncode != 0 and ("cannot find" in b.stderr or "unrecognized" in b.stderr):
         pytest.skip("sanitizer runtime not installed")
     assert b.returncode == 0, b.stderr[-4000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    # (the stand-in engine takes its behaviour at creation, so engines are not reused from one MultiH to the next here)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", MULTIH_ENGINE_POOL="0")
     r = subprocess.run([str(tmp_path / "caller")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "apply_multih_caller ok" in r.stdout
