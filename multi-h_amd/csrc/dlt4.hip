@@ -142,10 +142,12 @@ __device__ __forceinline__ void null9_vector(double (*W)[HPW], int hs, double g[
 #undef WE
 }
 
+// The r01-r04 form of the proposer: W staged in LDS (78 KB per workgroup, two workgroups per compute unit).  Kept as
+// variant 1 of launch_dlt4 (tuning key 25) for the comparison with the register-resident form below; same bits.
 // At most 72 VGPRs: that is what the resident residual sweep leaves free on every SIMD (5 waves of 88 registers), so a
 // workgroup of this kernel fits beside it on any compute unit (residual.hip, k_residual_resident).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(72)))
-k_dlt4(const double* __restrict__ x1, const double* __restrict__ y1,
+k_dlt4_lds(const double* __restrict__ x1, const double* __restrict__ y1,
        const double* __restrict__ x2, const double* __restrict__ y2, int N,
        unsigned long long seed, long long first, int M, int* __restrict__ idx_out,
        double* __restrict__ H_out)
@@ -243,6 +245,243 @@ k_dlt4(const double* __restrict__ x1, const double* __restrict__ y1,
         for (int j = 0; j < 9; ++j) out[j] = Hh[j] * sc;
     }
 #undef WE
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident form (r04).  The same rotations in the same order, but W never touches LDS: the four lanes of a
+// hypothesis hold the nine columns of W (17 doubles each) in registers and hand them round with DPP row shifts.
+//
+// Lane layout inside a row of 16 lanes: lane = 4 * slot + j, so the four slots of hypothesis j sit in the four BANKS
+// (groups of 4 lanes) of the row, a row shift by 4 lanes moves a column to the neighbouring slot, and DPP's bank mask
+// lets one slot keep what it has.  Round r of the circle schedule pairs positions (k, 9 - k), k = 1..4, where position
+// j holds column (r + j) % 9 and position 0 sits out; slot k - 1 keeps position k in its "A" registers and position
+// 9 - k in its "B" registers, slot 0 also the idle position in "C".  After a round every column moves down one position:
+//      A[slot] <- A[slot + 1]   (slot 3: its own B)        one DPP move per dword, written INTO the old B registers
+//      B[slot] <- B[slot - 1]   (slot 0: the idle column)  one DPP move per dword, written INTO the old C registers
+//      idle    <- A[slot 0]                                nothing to do: the old A registers now play C
+// so the three register sets swap roles with period 3 and a sweep is three times three rounds.  68 DPP moves per round
+// stand where the LDS form had 84 LDS instructions and their latency; no LDS, any number of workgroups per compute unit.
+//
+// A slot may hold the higher-numbered column of its pair in "A" (the schedule's p < q is by column number).  Swapping
+// the roles of the two columns negates zeta, t and s exactly and leaves c, gamma, alpha * beta unchanged; the updated
+// columns are then the same sums with the operands in the other order, i.e. the same bits — except for zeta == 0, where
+// the reference order takes t = +1; `swapped` picks the sign there.
+// ---------------------------------------------------------------------------
+struct Col { double v[WROWS]; };
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_merge(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+// one step of the circle: a -> (plays idle), b <- a shifted down (plays A), c <- b shifted up (plays B)
+__device__ __forceinline__ void shift_columns(Col& a, Col& b, Col& c)
+{
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+        c.v[i] = dpp_merge<0x114 /* row_shr:4 */, 0xE>(c.v[i], b.v[i]);   // slots 1..3 take B of the slot below; slot 0 keeps the idle column
+        b.v[i] = dpp_merge<0x104 /* row_shl:4 */, 0x7>(b.v[i], a.v[i]);   // slots 0..2 take A of the slot above; slot 3 keeps its own B
+    }
+}
+
+__device__ __forceinline__ int rotate_pair(Col& P, Col& Q, bool swapped, bool live)
+{
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double wp = P.v[i], wq = Q.v[i];
+        alpha = alpha + wp * wp;
+        beta = beta + wq * wq;
+        gamma = gamma + wp * wq;
+    }
+    const bool rot = live && (gamma != 0.0) && (gamma * gamma > 1e-30 * (alpha * beta)) &&
+                     (alpha >= 1e-28) && (beta >= 1e-28);
+    if (rot) {
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const bool pos = swapped ? (zeta > 0.0) : (zeta >= 0.0);
+        const double sg = pos ? 1.0 : -1.0;
+        const double t = sg / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t);
+        const double s = c * t;
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const double wp = P.v[i], wq = Q.v[i];
+            P.v[i] = c * wp - s * wq;
+            Q.v[i] = s * wp + c * wq;
+        }
+    }
+    return rot ? 1 : 0;
+}
+
+// bit r set: in round r slot s holds the higher-numbered column of its pair in the position-k registers
+__host__ __device__ constexpr unsigned swapped_rounds(int s)
+{
+    unsigned m = 0;
+    for (int r = 0; r < 9; ++r) {
+        const int k = s + 1, a = (r + k) % 9, b = (r + 9 - k) % 9;
+        if (a > b) m |= 1u << r;
+    }
+    return m;
+}
+
+// column c of the 8 x 9 design matrix over the identity, c a per-lane value
+__device__ __forceinline__ void dlt_column(int c, const double* x, const double* y, const double* u, const double* v, Col& out)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double e0[9] = { -x[k], -y[k], -1.0, 0.0, 0.0, 0.0, u[k] * x[k], u[k] * y[k], u[k] };
+        const double e1[9] = { 0.0, 0.0, 0.0, -x[k], -y[k], -1.0, v[k] * x[k], v[k] * y[k], v[k] };
+        double r0 = e0[0], r1 = e1[0];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) {
+            r0 = (c == j) ? e0[j] : r0;
+            r1 = (c == j) ? e1[j] : r1;
+        }
+        out.v[2 * k] = r0;
+        out.v[2 * k + 1] = r1;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.v[8 + i] = (i == c) ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ double column_norm(const Col& a)
+{
+    double n = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) n = n + a.v[i] * a.v[i];
+    return n;
+}
+
+__global__ void __launch_bounds__(256)
+k_dlt4(const double* __restrict__ x1, const double* __restrict__ y1,
+       const double* __restrict__ x2, const double* __restrict__ y2, int N,
+       unsigned long long seed, long long first, int M, int* __restrict__ idx_out,
+       double* __restrict__ H_out)
+{
+    __builtin_amdgcn_s_setprio(3);           // see k_dlt4_lds
+    __shared__ double sN[4][9][HPW];         // column norms, then the null vector: 1.1 KB per wave
+    __shared__ double sK[4][6][HPW];         // the normalisation, parked while the sweeps need the registers
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int slot = (lane >> 2) & 3;
+    const int hs = (lane >> 4) * 4 + (lane & 3);
+    const int m = (blockIdx.x * 4 + wave) * HPW + hs;
+    const bool live = m < M;
+
+    Col A, B, C;
+    {
+        int id[4] = { 0, 0, 0, 0 };
+        double sx[4], sy[4], dx[4], dy[4];
+        if (live) sample4(seed, (unsigned long long)(first + m), (unsigned int)N, id);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sx[k] = x1[id[k]]; sy[k] = y1[id[k]]; dx[k] = x2[id[k]]; dy[k] = y2[id[k]];
+        }
+        if (live && slot == 0 && idx_out) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) idx_out[4 * (size_t)m + k] = id[k];
+        }
+        double cx1 = ((sx[0] + sx[1]) + sx[2]) + sx[3], cy1 = ((sy[0] + sy[1]) + sy[2]) + sy[3];
+        double cx2 = ((dx[0] + dx[1]) + dx[2]) + dx[3], cy2 = ((dy[0] + dy[1]) + dy[2]) + dy[3];
+        cx1 = cx1 * 0.25; cy1 = cy1 * 0.25; cx2 = cx2 * 0.25; cy2 = cy2 * 0.25;
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double ax = sx[k] - cx1, ay = sy[k] - cy1, bx = dx[k] - cx2, by = dy[k] - cy2;
+            d1 = d1 + sqrt(ax * ax + ay * ay);
+            d2 = d2 + sqrt(bx * bx + by * by);
+        }
+        const double s1 = sqrt(2.0) / (d1 * 0.25), s2 = sqrt(2.0) / (d2 * 0.25);
+        if (slot == 0) {
+            sK[wave][0][hs] = s1; sK[wave][1][hs] = s2; sK[wave][2][hs] = cx1;
+            sK[wave][3][hs] = cy1; sK[wave][4][hs] = cx2; sK[wave][5][hs] = cy2;
+        }
+        double x[4], y[4], u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = (sx[k] - cx1) * s1; y[k] = (sy[k] - cy1) * s1;
+            u[k] = (dx[k] - cx2) * s2; v[k] = (dy[k] - cy2) * s2;
+        }
+        dlt_column(slot + 1, x, y, u, v, A);
+        dlt_column(8 - slot, x, y, u, v, B);
+        dlt_column(0, x, y, u, v, C);
+    }
+
+    const unsigned sw = slot == 0 ? swapped_rounds(0) : slot == 1 ? swapped_rounds(1) : slot == 2 ? swapped_rounds(2) : swapped_rounds(3);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        unsigned long long rotated = 0;                               // lanes that rotated in this sweep (wave-uniform)
+#pragma unroll 1
+        for (int r = 0; r < 9; r += 3) {
+            rotated |= __ballot(rotate_pair(A, B, (sw >> r) & 1u, live));
+            shift_columns(A, B, C);                                   // roles now: A <- B, B <- C, idle <- A
+            rotated |= __ballot(rotate_pair(B, C, (sw >> (r + 1)) & 1u, live));
+            shift_columns(B, C, A);                                   // A <- C, B <- A, idle <- B
+            rotated |= __ballot(rotate_pair(C, A, (sw >> (r + 2)) & 1u, live));
+            shift_columns(C, A, B);                                   // back to A, B, idle = C
+        }
+        if (rotated == 0) break;                                      // per wave: its 16 hypotheses are done
+    }
+
+    // after whole sweeps the columns are back where they started: A = column slot + 1, B = column 8 - slot, C = column 0
+    sN[wave][slot + 1][hs] = column_norm(A);
+    sN[wave][8 - slot][hs] = column_norm(B);
+    if (slot == 0) sN[wave][0][hs] = column_norm(C);
+    wave_sync();
+    int jm = 0;
+    {
+        double best = 0.0;
+        for (int j = 0; j < 9; ++j) {
+            const double a = sN[wave][j][hs];
+            if (j == 0 || a < best) { best = a; jm = j; }
+        }
+    }
+    wave_sync();
+    if (jm == slot + 1) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sN[wave][j][hs] = A.v[8 + j];
+    } else if (jm == 8 - slot) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sN[wave][j][hs] = B.v[8 + j];
+    } else if (jm == 0 && slot == 0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sN[wave][j][hs] = C.v[8 + j];
+    }
+    wave_sync();
+
+    if (live && slot == 0) {
+        double g[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) g[j] = sN[wave][j][hs];
+        const double s1 = sK[wave][0][hs], s2 = sK[wave][1][hs], cx1 = sK[wave][2][hs];
+        const double cy1 = sK[wave][3][hs], cx2 = sK[wave][4][hs], cy2 = sK[wave][5][hs];
+        double A1[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double a = g[3 * r], b = g[3 * r + 1], c = g[3 * r + 2];
+            A1[3 * r] = a * s1;
+            A1[3 * r + 1] = b * s1;
+            A1[3 * r + 2] = (c - (a * s1) * cx1) - (b * s1) * cy1;
+        }
+        const double is2 = 1.0 / s2;
+        double Hh[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Hh[j] = A1[j] * is2 + cx2 * A1[6 + j];
+            Hh[3 + j] = A1[3 + j] * is2 + cy2 * A1[6 + j];
+            Hh[6 + j] = A1[6 + j];
+        }
+        double fro = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) fro = fro + Hh[j] * Hh[j];
+        double sc = 1.0 / sqrt(fro);
+        if (Hh[8] < 0.0) sc = -sc;
+        double* out = H_out + 9 * (size_t)m;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) out[j] = Hh[j] * sc;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -365,12 +604,16 @@ hipError_t launch_fund8(const Points& p, unsigned long long seed, long long firs
 }
 
 hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,
-                       int* idx_out, double* H_out, hipStream_t s)
+                       int* idx_out, double* H_out, hipStream_t s, int variant)
 {
     if (M <= 0) return hipSuccess;
     const int per_block = 4 * HPW;
-    hipLaunchKernelGGL(k_dlt4, dim3((M + per_block - 1) / per_block), dim3(256), 0, s, p.x1, p.y1,
-                       p.x2, p.y2, p.n, seed, first, M, idx_out, H_out);
+    if (variant == 1)
+        hipLaunchKernelGGL(k_dlt4_lds, dim3((M + per_block - 1) / per_block), dim3(256), 0, s, p.x1, p.y1,
+                           p.x2, p.y2, p.n, seed, first, M, idx_out, H_out);
+    else
+        hipLaunchKernelGGL(k_dlt4, dim3((M + per_block - 1) / per_block), dim3(256), 0, s, p.x1, p.y1,
+                           p.x2, p.y2, p.n, seed, first, M, idx_out, H_out);
     return hipGetLastError();
 }
 

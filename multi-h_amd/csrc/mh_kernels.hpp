@@ -64,7 +64,7 @@ hipError_t launch_compat_select(const double* pts /* total x 4 */, const int* be
 
 // --- dlt4.hip ---------------------------------------------------------------
 hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,
-                       int* idx_out, double* H_out, hipStream_t s);
+                       int* idx_out, double* H_out, hipStream_t s, int variant = 0 /* 1: the LDS-staged form */);
 
 hipError_t launch_fund8(const Points& p, unsigned long long seed, long long first, int M,
                         int* idx_out /* M x 8 */, double* F_out, hipStream_t s);

@@ -124,6 +124,34 @@ def test_sampling_and_dlt4(engine, synth, oracle, n, m, seed):
         assert np.max(np.abs(p - sc.dst[idx[t]])) < 1e-6 * 1000
 
 
+def test_dlt4_register_form_equals_lds_form(engine, synth, oracle):
+    """The proposer keeps W in registers and hands the columns round with DPP row shifts (dlt4.hip, k_dlt4); the
+    LDS-staged form of r01-r04 is still there behind tuning key 25.  Same rotations in the same order: every model
+    bit-identical, on a scene with degenerate samples among them, and both equal to the oracle."""
+    sc = synth.make_scene(300, 2, seed=21, with_neighbours=False)
+    rng = np.random.default_rng(21)
+    line = rng.permutation(sc.n)[:120]
+    t = rng.uniform(0, 1000, size=line.size)
+    sc.src[line] = np.stack([t, 0.25 * t + 50.0], axis=1)
+    _load(engine, sc, neighbours=False)
+    M = 8192 + 37                                  # a ragged last workgroup
+    out = {}
+    try:
+        for form in (1, 0):
+            engine.set_tuning(25, form)
+            engine.propose_dlt4(77, 5, M)
+            out[form] = (engine.get_samples().copy(), engine.get_models().copy())
+    finally:
+        engine.set_tuning(25, 0)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].view(np.uint64), out[1][1].view(np.uint64))
+    with np.errstate(all="ignore"):
+        H_ref, _, _ = oracle.dlt4(sc.src, sc.dst, out[0][0])
+    assert np.array_equal(np.isnan(out[0][1]), np.isnan(H_ref))
+    fin = ~np.isnan(H_ref).any(axis=1)
+    assert np.array_equal(out[0][1][fin].view(np.uint64), H_ref[fin].view(np.uint64))
+
+
 def test_dlt4_on_degenerate_samples(engine, synth, oracle):
     """Hypotheses from degenerate 4-tuples — three or four collinear points, repeated correspondences, a point set
     squeezed onto a line — are scored like any other in the bench and in Process(), so the GPU must treat them like the
