@@ -149,7 +149,7 @@ struct mh_engine {
 
     // reference-style initialisation
     DevBuf<double> loc_H, loc_feat, ms_data, ms_mean;
-    DevBuf<int> ms_votes, ms_out, ms_list, ms_pcnt;
+    DevBuf<int> ms_votes, ms_out, ms_list, ms_pcnt, ms_heads, ms_tickets;
     DevBuf<double> ms_partial;
 
     // labeling
@@ -175,7 +175,7 @@ struct mh_engine {
     int* h_flags = nullptr;
     MeanShiftResultBlock* h_ms = nullptr;      // mapped pinned result block of the mean-shift climbs
     MeanShiftResultBlock* h_ms_dev = nullptr;
-    int* h_ms_list = nullptr;                  // pinned staging for the first MS_LIST_PREFIX (row, votes) pairs
+    int* h_ms_list = nullptr;                  // pinned staging for the first MS_LIST_PREFIX (row, votes) pairs of every climb of a batch
     long long* h_acc = nullptr;
     int* h_flags_dev = nullptr;
     long long* h_acc_dev = nullptr;
@@ -820,7 +820,7 @@ void mh_destroy(mh_engine* e)
     e->fund.release(); e->fund_one.release(); e->fund_samples.release(); e->fund_counts.release();
     e->fund_inl.release(); e->fund_mask.release(); e->ref_keep.release(); e->ref_in.release(); e->ref_out.release();
     e->loc_H.release(); e->loc_feat.release(); e->ms_data.release(); e->ms_mean.release();
-    e->ms_votes.release(); e->ms_out.release(); e->ms_list.release(); e->ms_pcnt.release(); e->ms_partial.release();
+    e->ms_votes.release(); e->ms_out.release(); e->ms_list.release(); e->ms_pcnt.release(); e->ms_heads.release(); e->ms_tickets.release(); e->ms_partial.release();
     e->cost.release(); e->labels_in.release(); e->labels_pts.release(); e->label_counts.release();
     e->ew_label.release(); e->ew_cur.release(); e->ew_cap.release(); e->ew_excess.release();
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
@@ -1276,12 +1276,15 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                      e->ms_partial.p, e->ms_pcnt.p };
     const double band_sq = band_width * band_width;                 // MeanShiftClustering.h:31
     const double stop_thresh = 1e-3 * band_width;                   // :48
-    constexpr int MS_LIST_PREFIX = 2048;
+    constexpr int MS_LIST_PREFIX = 2048;      // pairs per climb that can travel in the batch's one copy; longer lists fetch their rest
     if (!e->h_ms) {                                                 // B result blocks, then the B seed rows
         HIPCHK(hipHostMalloc((void**)&e->h_ms, sizeof(MeanShiftResultBlock) * B + sizeof(int) * B, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_ms_dev, e->h_ms, 0));
     }
     if (!e->h_ms_list) HIPCHK(hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * MS_LIST_PREFIX * B, hipHostMallocDefault));
+    HIPCHK(e->ms_heads.reserve((size_t)B * 2 * MS_LIST_PREFIX));
+    HIPCHK(e->ms_tickets.reserve((size_t)B));
+    HIPCHK(hipMemsetAsync(e->ms_tickets.p, 0, sizeof(int) * (size_t)B, e->stream));
     int* const starts = reinterpret_cast<int*>(e->h_ms + B);
     const int* const starts_dev = reinterpret_cast<const int*>(e->h_ms_dev + B);
 
@@ -1319,31 +1322,37 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             const double rnd = (double)(z >> 11) * (1.0 / 9007199254740992.0);
             starts[b] = kth_unvisited((int)std::round(rnd * (double)(unvisited - 1)));
         }
-        auto all_ended = [&]() {
-            for (int b = 0; b < climbs; ++b) if (!e->h_ms[b].out[1] && !e->h_ms[b].out[3]) return false;
-            return true;
-        };
-        bool ended = false;
-        for (int round = 0; round < 20000 && !ended; ++round) {     // rounds of device-side iterations
-            HIPCHK(launch_ms_climb(w, climbs, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
-                                   e->h_ms_dev, e->stream));
+        // a round works on the climbs that have not ended yet (the batch drains: most climbs end within a round or two,
+        // a few take dozens); the result block of a climb that has ended keeps what its last round published
+        MeanShiftActive active{};
+        int n_active = climbs;
+        for (int b = 0; b < climbs; ++b) active.climb[b] = (unsigned char)b;
+        for (int round = 0; round < 20000 && n_active > 0; ++round) {     // rounds of device-side iterations
+            HIPCHK(launch_ms_climb(w, active, n_active, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
+                                   e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->ms_tickets.p, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
-            ended = all_ended();
+            int still = 0;
+            for (int a = 0; a < n_active; ++a) {
+                const int b = active.climb[a];
+                if (!e->h_ms[b].out[1] && !e->h_ms[b].out[3]) active.climb[still++] = (unsigned char)b;
+            }
+            n_active = still;
         }
-        if (!ended) {
+        if (n_active > 0) {
             // a climb neither converged nor died within the cap: compact and clear the votes (they would leak into the
             // next call's membership lists) and give up loudly
             HIPCHK(launch_ms_collect(w, climbs, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             return fail(MH_ERR_INVALID, "mean shift: a climb did not converge within 20000 rounds of iterations");
         }
-        for (int b = 0; b < climbs; ++b) {
-            const int head = std::min(e->h_ms[b].out[2], MS_LIST_PREFIX);
-            if (head > 0)
-                HIPCHK(hipMemcpyAsync(e->h_ms_list + (size_t)b * 2 * MS_LIST_PREFIX, e->ms_list.p + (size_t)b * 2 * n,
-                                      sizeof(int) * 2 * (size_t)head, hipMemcpyDeviceToHost, e->stream));
+        // the heads of all lists in one copy: staged as [position][climb], so the first `longest` pairs of every climb are
+        // one contiguous range
+        int longest = 0;
+        for (int b = 0; b < climbs; ++b) longest = std::max(longest, std::min(e->h_ms[b].out[2], MS_LIST_PREFIX));
+        if (longest > 0) {
+            HIPCHK(hipMemcpyAsync(e->h_ms_list, e->ms_heads.p, sizeof(int) * 2 * (size_t)B * longest, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
         }
-        HIPCHK(hipStreamSynchronize(e->stream));
         // apply the climbs in draw order; one whose seed an earlier climb of the batch has visited never started in
         // the reference's terms and is dropped
         for (int b = 0; b < climbs; ++b) {
@@ -1354,8 +1363,11 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             const int len = out[2];
             list.resize(2 * (size_t)len);
             const int head = std::min(len, MS_LIST_PREFIX);
-            const int* staged = e->h_ms_list + (size_t)b * 2 * MS_LIST_PREFIX;
-            std::copy(staged, staged + 2 * (size_t)head, list.begin());
+            for (int k = 0; k < head; ++k) {
+                const int* pr = e->h_ms_list + ((size_t)k * B + b) * 2;
+                list[2 * k] = pr[0];
+                list[2 * k + 1] = pr[1];
+            }
             if (len > head) {
                 HIPCHK(hipMemcpyAsync(list.data() + 2 * (size_t)head, e->ms_list.p + (size_t)b * 2 * n + 2 * (size_t)head,
                                       sizeof(int) * 2 * (size_t)(len - head), hipMemcpyDeviceToHost, e->stream));

@@ -5,11 +5,12 @@
 // quirk A-8), new mean = (sum of members) * (1/count), every member gets a vote and is marked
 // visited, stop when ||mean - old|| < 1e-3*bandwidth.  The reference allocates an N x D repmat per
 // iteration; at N = 50k (EstablishStablePointSets, M/MultiH.cpp:604-694) that inner loop is the
-// cost.  Here an iteration is two launches that never return to the host:
-//   k_ms_partial  MS_GROUPS workgroups sweep the rows (global thread g takes rows g, g+T, g+2T, ...),
-//                 members vote, each workgroup reduces its member sums with a binary tree;
-//   k_ms_update   one wave adds the MS_GROUPS partials in order, forms the new mean, tests
-//                 convergence and raises the `done` word that turns the rest of the batch into no-ops.
+// cost.  Here an iteration is ONE launch that never returns to the host (k_ms_iterate):
+//   up to MS_GROUPS workgroups per climb sweep the rows (global thread g takes rows g, g+T, g+2T, ...; workgroups beyond
+//   the rows are not launched), members vote, each workgroup reduces its member sums with a binary tree (skipped when it
+//   has no member: the tree would add zeros); the LAST workgroup of the climb to finish (a ticket) adds the partials in
+//   group order, forms the new mean, tests convergence and raises the `done` word that turns the rest of the batch into
+//   no-ops.  (r01-r04: two launches per iteration, k_ms_partial + k_ms_update.)
 // The summation order (strided, tree inside a group, groups in sequence) is fixed — it does not
 // depend on the device — and is mirrored by the oracle (mho_mean_shift), so modes and assignments
 // are bit-identical.  The seed order, vote merging and final assignment stay on the host (they are
@@ -20,6 +21,8 @@
 // A climb depends only on the data and its seed, so the batch costs the host round trips of its longest climb
 // instead of the sum.  The batch size is part of the definition (the oracle draws the same way).
 #include "mh_kernels.hpp"
+
+#include <algorithm>
 
 namespace mh {
 
@@ -39,15 +42,22 @@ __device__ __forceinline__ MeanShiftWork ms_climb(const MeanShiftWork& a, int b)
     return w;
 }
 
+// One climb iteration in ONE launch: `groups` workgroups per climb form the partial sums, and the last of them to
+// finish (a ticket per climb) adds the partials in group order, forms the new mean and tests convergence — the work of
+// the former k_ms_update, without a launch of its own.  tickets: one int per climb, zero between launches.
 __global__ void __launch_bounds__(256)
-k_ms_partial(MeanShiftWork all, double band_sq)
+k_ms_iterate(MeanShiftWork all, MeanShiftActive active, int groups, double band_sq, double stop_thresh, int* __restrict__ tickets)
 {
-    const MeanShiftWork w = ms_climb(all, blockIdx.y);
-    if (w.out[1] || w.out[3]) return;                       // converged or dead end: rest of the batch idles
+    const int climb = active.climb[blockIdx.y];
+    const MeanShiftWork w = ms_climb(all, climb);
+    // converged or dead end: rest of the batch idles.  (The words are written by the climb's LAST workgroup of a launch, and
+    // every workgroup of the climb has read them before that one can know it is the last.)
+    if (w.out[1] || w.out[3]) return;
     const int t = threadIdx.x;
     const int D = w.d;
     const int T = MS_GROUPS * 256;
-    __shared__ double sv[256][MS_MAXD];
+    __shared__ double sv[MS_MAXD][256];                     // [component][thread]: a wave's lanes read consecutive words (the
+                                                            // [thread][component] layout put all 64 lanes on one bank)
     __shared__ int sc[256];
     double old[MS_MAXD], acc[MS_MAXD];
 #pragma unroll
@@ -56,49 +66,96 @@ k_ms_partial(MeanShiftWork all, double band_sq)
     for (int i = blockIdx.x * 256 + t; i < w.n; i += T) {
         const double* row = w.data + (size_t)i * D;
         double dist = 0.0;
-        for (int j = 0; j < D; ++j) { const double r = old[j] - row[j]; dist += sqrt(r * r); }   // :78-83
+        // :78-83 takes sqrt(r * r) per component.  In binary floating point with correctly rounded operations that IS |r|
+        // whenever r * r neither overflows nor underflows (radix-2 property; tests/test_oracle_cpu.py checks it on 10^7 values
+        // and on the neighbours of every power of two), so the square root is only formed outside 2^-500 <= |r| <= 2^500.
+        bool plain = true;
+        double a[MS_MAXD];
+#pragma unroll
+        for (int j = 0; j < MS_MAXD; ++j) {
+            a[j] = j < D ? fabs(old[j] - row[j]) : 0.0;
+            plain = plain && (a[j] <= 0x1p500) && (a[j] >= 0x1p-500 || a[j] == 0.0);
+        }
+        if (__builtin_expect(plain, 1)) {
+#pragma unroll
+            for (int j = 0; j < MS_MAXD; ++j) if (j < D) dist += a[j];
+        } else {
+            asm volatile("; mean shift: sqrt path");         // (keeps the compiler from computing both and selecting)
+            for (int j = 0; j < D; ++j) { const double r = old[j] - row[j]; dist += sqrt(r * r); }
+        }
         if (dist < band_sq) {                                                                    // :85
             for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
             ++cnt;
             w.votes[i] += 1;                               // row i belongs to this thread only
         }
     }
-    for (int j = 0; j < MS_MAXD; ++j) sv[t][j] = acc[j];
-    sc[t] = cnt;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if (t < s) {
-            for (int j = 0; j < D; ++j) sv[t][j] = sv[t][j] + sv[t + s][j];
-            sc[t] += sc[t + s];
-        }
+    // Partials are written with device-scope stores and drained (s_waitcnt) before the ticket, and read back with
+    // device-scope loads: no cache maintenance (a __threadfence here writes the XCD's L2 back, per workgroup: 3 x slower).
+    auto put_sum = [&](int j, double v) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(w.partial) + (size_t)blockIdx.x * MS_MAXD + j,
+                           (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto put_cnt = [&](int c) { __hip_atomic_store(w.partial_cnt + blockIdx.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (__syncthreads_or(cnt) == 0) {
+        // no member among this workgroup's rows (the usual case: a ball holds a few rows): the tree below would add zeros
+        if (t < D) put_sum(t, 0.0);
+        if (t == 0) put_cnt(0);
+    } else {
+        for (int j = 0; j < MS_MAXD; ++j) sv[j][t] = acc[j];
+        sc[t] = cnt;
         __syncthreads();
+        for (int s = 128; s >= 1; s >>= 1) {
+            if (t < s) {
+                for (int j = 0; j < D; ++j) sv[j][t] = sv[j][t] + sv[j][t + s];
+                sc[t] += sc[t + s];
+            }
+            __syncthreads();
+        }
+        if (t < D) put_sum(t, sv[t][0]);
+        if (t == 0) put_cnt(sc[0]);
     }
-    if (t < D) w.partial[(size_t)blockIdx.x * MS_MAXD + t] = sv[0][t];
-    if (t == 0) w.partial_cnt[blockIdx.x] = sc[0];
-}
 
-__global__ void __launch_bounds__(64)
-k_ms_update(MeanShiftWork all, double stop_thresh)
-{
-    const MeanShiftWork w = ms_climb(all, blockIdx.x);
-    if (w.out[1] || w.out[3]) return;
-    const int j = threadIdx.x;
-    const int D = w.d;
-    __shared__ double s_move[MS_MAXD];
-    int in = 0;
-    for (int b = 0; b < MS_GROUPS; ++b) in += w.partial_cnt[b];
-    if (in == 0) { if (j == 0) w.out[3] = 1; return; }      // the reference would spin on a NaN mean
-    double m = 0.0, dd = 0.0;
-    if (j < D) {
-        double s = 0.0;
-        for (int b = 0; b < MS_GROUPS; ++b) s = s + w.partial[(size_t)b * MS_MAXD + j];
-        m = s * (1.0 / (double)in);                         // cv::Mat / scalar scales by 1/s (:96)
-        dd = m - w.mean[j];
-        s_move[j] = dd * dd;
+    // ---- the climb's last workgroup forms the new mean -------------------------------------------------------------
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my partials have landed before my ticket
+    __syncthreads();
+    if (t == 0) {
+        const int k = atomicAdd(&tickets[climb], 1);
+        s_last = (k == groups - 1);
+        if (s_last) __hip_atomic_store(&tickets[climb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody else touches it before the next launch)
     }
     __syncthreads();
-    if (j < D) w.mean[j] = m;
-    if (j == 0) {
+    if (!s_last) return;
+    // the other workgroups' partials come from other compute units, other XCDs: device-scope loads (relaxed: all of them
+    // in flight at once), not whatever this XCD's L2 holds of those lines
+    auto cnt_of = [&](int b) { return __hip_atomic_load(w.partial_cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto sum_of = [&](int b, int j) {
+        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(w.partial) + (size_t)b * MS_MAXD + j,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    __shared__ double s_move[MS_MAXD];
+    __shared__ int s_in;
+    if (t < 64) {
+        int in = 0;
+#pragma unroll
+        for (int b = 0; b < MS_GROUPS; ++b) { const int c = b < groups ? cnt_of(b) : 0; in += c; }
+        if (t == 0) s_in = in;
+        if (t < D && in != 0) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < MS_GROUPS; ++b) {           // groups in sequence (a group that was not launched: +0, and s is never -0)
+                const double v = b < groups ? sum_of(b, t) : 0.0;
+                s = s + v;
+            }
+            const double m = s * (1.0 / (double)in);        // cv::Mat / scalar scales by 1/s (:96)
+            const double dd = m - w.mean[t];                // (still the mean this iteration started from: this is its only writer)
+            s_move[t] = dd * dd;
+            w.mean[t] = m;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (s_in == 0) { w.out[3] = 1; return; }            // the reference would spin on a NaN mean
         double move = 0.0;
         for (int q = 0; q < D; ++q) move = move + s_move[q];
         w.out[0] += 1;
@@ -124,20 +181,24 @@ k_ms_collect(MeanShiftWork all)
 
 // starts: the batch's seed rows (mapped pinned memory written by the host)
 __global__ void __launch_bounds__(64)
-k_ms_seed(MeanShiftWork all, const int* __restrict__ starts)
+k_ms_seed(MeanShiftWork all, MeanShiftActive active, const int* __restrict__ starts)
 {
-    const MeanShiftWork w = ms_climb(all, blockIdx.x);
-    const int start = starts[blockIdx.x];
+    const int b = active.climb[blockIdx.x];
+    const MeanShiftWork w = ms_climb(all, b);
+    const int start = starts[b];
     const int j = threadIdx.x;
     if (j < w.d) w.mean[j] = w.data[(size_t)start * w.d + j];        // :58  myMean = data.row(stInd)
     if (j < 4) w.out[j] = 0;
 }
 
-// k_ms_collect, run only once the climb has ended (converged or dead end)
+// k_ms_collect, run only once the climb has ended (converged or dead end); the head of the list also goes into a staging
+// array laid out [position][climb], so that the first k pairs of ALL climbs are one contiguous range: the host fetches
+// them with ONE copy per batch (k = the longest head) instead of one per climb
 __global__ void __launch_bounds__(256)
-k_ms_collect_if_done(MeanShiftWork all)
+k_ms_collect_if_done(MeanShiftWork all, MeanShiftActive active, int* __restrict__ heads, int prefix)
 {
-    const MeanShiftWork w = ms_climb(all, blockIdx.y);
+    const int b = active.climb[blockIdx.y];
+    const MeanShiftWork w = ms_climb(all, b);
     if (!(w.out[1] || w.out[3])) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w.n) return;
@@ -146,31 +207,38 @@ k_ms_collect_if_done(MeanShiftWork all)
         const int pos = atomicAdd(&w.out[2], 1);
         w.list[2 * pos] = i;
         w.list[2 * pos + 1] = v;
+        if (pos < prefix) {
+            int* h = heads + ((size_t)pos * MS_BATCH + b) * 2;
+            h[0] = i;
+            h[1] = v;
+        }
         w.votes[i] = 0;
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_ms_publish(MeanShiftWork all, MeanShiftResultBlock* results)
+k_ms_publish(MeanShiftWork all, MeanShiftActive active, MeanShiftResultBlock* results)
 {
-    const MeanShiftWork w = ms_climb(all, blockIdx.x);
-    MeanShiftResultBlock* r = results + blockIdx.x;
+    const int b = active.climb[blockIdx.x];
+    const MeanShiftWork w = ms_climb(all, b);
+    MeanShiftResultBlock* r = results + b;
     const int j = threadIdx.x;
     if (j < 4) r->out[j] = w.out[j];
     if (j < MS_MAXD) r->mean[j] = j < w.d ? w.mean[j] : 0.0;
 }
 
-hipError_t launch_ms_climb(const MeanShiftWork& w, int climbs, const int* starts_dev, double band_sq, double stop_thresh,
-                           int iterations, MeanShiftResultBlock* result_dev, hipStream_t s)
+hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev, double band_sq,
+                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix,
+                           int* tickets, hipStream_t s)
 {
-    if (w.d > MS_MAXD || climbs < 1) return hipErrorInvalidValue;
-    if (starts_dev) hipLaunchKernelGGL(k_ms_seed, dim3(climbs), dim3(64), 0, s, w, starts_dev);
+    if (w.d > MS_MAXD || n_active < 1 || n_active > MS_BATCH) return hipErrorInvalidValue;
+    const int groups = std::min(MS_GROUPS, (w.n + 255) / 256);
+    if (starts_dev) hipLaunchKernelGGL(k_ms_seed, dim3(n_active), dim3(64), 0, s, w, active, starts_dev);
     for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(k_ms_partial, dim3(MS_GROUPS, climbs), dim3(256), 0, s, w, band_sq);
-        hipLaunchKernelGGL(k_ms_update, dim3(climbs), dim3(64), 0, s, w, stop_thresh);
+        hipLaunchKernelGGL(k_ms_iterate, dim3(groups, n_active), dim3(256), 0, s, w, active, groups, band_sq, stop_thresh, tickets);
     }
-    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, climbs), dim3(256), 0, s, w);
-    hipLaunchKernelGGL(k_ms_publish, dim3(climbs), dim3(64), 0, s, w, result_dev);
+    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
+    hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
     return hipGetLastError();
 }
 

@@ -110,12 +110,17 @@ struct MeanShiftWork {      // every per-climb array holds MS_BATCH slices
     int* partial_cnt;        // [climb] MS_GROUPS
 };
 struct MeanShiftResultBlock { int out[4]; double mean[16]; };
-// `climbs` climbs side by side without host round trips in between: seed the means with the rows starts_dev[0..climbs)
-// (null: continue the running climbs), `iterations` climb iterations (no-ops for a climb that has ended), compact the
-// votes of the climbs that have ended, then publish every climb's control words and mean to result_dev[climb]
-// (device address of a mapped pinned array).
-hipError_t launch_ms_climb(const MeanShiftWork& w, int climbs, const int* starts_dev, double band_sq, double stop_thresh,
-                           int iterations, MeanShiftResultBlock* result_dev, hipStream_t s);
+struct MeanShiftActive { unsigned char climb[MS_BATCH]; };       // the climbs a round still works on, passed by value
+// The climbs active[0..n_active) side by side without host round trips in between: seed the means with the rows
+// starts_dev[climb] (null: continue the running climbs), `iterations` climb iterations (no-ops for a climb that has
+// ended), compact the votes of the climbs that have ended — the first `list_prefix` (row, votes) pairs of each also into
+// heads_dev[position][climb] (pairs of ints, MS_BATCH climbs per position: the first k pairs of all climbs are one
+// contiguous range the host fetches once per batch) — then publish
+// every active climb's control words and mean to result_dev[climb] (mapped pinned).  Workgroups beyond the rows
+// (n < 256 * MS_GROUPS) are not launched: their partial sums are +0, which the running sum never notices.
+hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev, double band_sq,
+                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix,
+                           int* tickets /* MS_BATCH ints, zero */, hipStream_t s);
 // compacts and clears the votes of all `climbs` climbs, ended or not
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s);
 

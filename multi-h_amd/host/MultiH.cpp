@@ -391,9 +391,15 @@ bool MultiH::DownloadModels(int count)
 bool MultiH::EstablishStablePointSets()
 {
     const int N = static_cast<int>(src_points.size());
+    const bool timing = std::getenv("MULTIH_TIMING") != nullptr;          // diagnostic: where the initialisation's time goes
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     std::vector<double> feat(10 * (size_t)N);
     if (!Check(mh_local_homographies(engine, locality_lambda, nullptr, feat.data()), "mh_local_homographies"))
         return false;
+    const double ms_local = ms_since(t0);
     // a degenerate per-point solve (NaN features) would poison the L1 ball test; park such rows far away
     for (double& f : feat) if (!std::isfinite(f)) f = 1e300;
     std::vector<int> assign(N);
@@ -402,6 +408,7 @@ bool MultiH::EstablishStablePointSets()
                              nullptr, 0, assign.data(), &k),
                "mh_mean_shift"))
         return false;
+    const double ms_shift = ms_since(t0) - ms_local;
     std::vector<std::vector<int>> members(k);
     for (int i = 0; i < N; ++i) if (assign[i] >= 0) members[assign[i]].push_back(i);
     for (int c = 0; c < k; ++c) {
@@ -417,6 +424,9 @@ bool MultiH::EstablishStablePointSets()
         if (multih::Homography3PT(p1.data(), p2.data(), ni, fundamental_matrix, H, true))  // :685
             cluster_homographies.push_back(MatFrom9(H));
     }
+    if (timing)
+        printf("[Multi-H] stable sets: per-point homographies %.2f ms, mean shift %.2f ms (%d modes), 3-point fits %.2f ms\n",
+               ms_local, ms_shift, k, ms_since(t0) - ms_local - ms_shift);
     if (log_to_console)
         printf("[Multi-H] Number of stable, local clusters = %d\n", (int)cluster_homographies.size());   // :693
     return true;

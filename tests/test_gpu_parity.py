@@ -1206,6 +1206,27 @@ def test_gpu_mean_shift_matches_oracle(engine, oracle, n, d, seed):
     assert (assign >= 0).all()
 
 
+def test_gpu_mean_shift_outside_the_plain_range(engine, oracle):
+    """k_ms_partial forms |r| for sqrt(r * r) only where that is exact (2^-500 <= |r| <= 2^500 or r == 0); rows parked at
+    1e300 (what EstablishStablePointSets does with a degenerate per-point solve), components that differ by 1e-170 and by
+    exactly 0, and a whole cluster scaled to 1e-160 take the reference's form.  Same modes, same assignment."""
+    rng = np.random.default_rng(11)
+    d = 10
+    centres = rng.uniform(-40, 40, size=(12, d))
+    data = np.concatenate([c + rng.normal(0, 0.2, size=(30, d)) for c in centres])
+    data[5:25] = data[5]                                   # exact duplicates: r == 0 in every component
+    data[40:60] = data[40] + rng.uniform(-1e-170, 1e-170, size=(20, d))      # below 2^-500
+    data[100:120] = 1e300                                  # parked rows: r * r overflows
+    data[200:230] = rng.uniform(-1e-160, 1e-160, size=(30, d))              # a cluster whose own spread underflows when squared
+    data[300:305, 3] = -1e300
+    modes, assign, k = engine.mean_shift(data, 2.2, 9)
+    with np.errstate(all="ignore"):
+        modes_o, assign_o, k_o = oracle.mean_shift(data, 2.2, 9)
+    assert k == k_o
+    assert np.array_equal(assign, assign_o)
+    assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64))
+
+
 def test_process_with_reference_style_initialisation(mh, engine_lib, synth):
     """INIT_STABLE_SETS: per-point HAF -> mean shift -> 3-point LSQ per cluster (the reference's own
     ComputeLocalHomographies + EstablishStablePointSets), then the usual merge/label loop."""

@@ -310,3 +310,30 @@ def test_mean_shift_oracle_vs_sequential_sums(oracle):
     assert sorted(perm.tolist()) == list(range(6))
     assert np.allclose(modes, cent[perm], rtol=1e-9, atol=1e-9)
     assert np.array_equal(perm[assign], best)
+
+
+def test_sqrt_of_square_is_the_magnitude_in_binary64():
+    """k_ms_partial (csrc/meanshift.hip) forms |r| where the reference takes sqrt(r * r) (MeanShiftClustering.h:78-83)
+    whenever 2^-500 <= |r| <= 2^500 or r == 0.  That rests on a property of radix-2 arithmetic with correctly rounded
+    multiplication and square root: RN(sqrt(RN(r^2))) == |r| as long as r^2 neither overflows nor underflows.  Checked
+    here on 10^7 random binary64 values of that range, on the neighbours of 1 +- 2^-k at every scale, and — the other way
+    round — that the guard is needed: it fails below 2^-511."""
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        m = rng.integers(0, 1 << 52, size=2_000_000, dtype=np.uint64)
+        e = rng.integers(1023 - 500, 1023 + 500, size=2_000_000, dtype=np.uint64)
+        x = ((e << np.uint64(52)) | m).view(np.float64)
+        assert np.array_equal(np.sqrt(x * x), x)
+    edge = []
+    for e in range(-500, 500):
+        for k in range(1, 53):
+            for s in (1.0, -1.0):
+                v = np.ldexp(1.0 + s * np.ldexp(1.0, -k), e)
+                edge += [v, np.nextafter(v, np.inf), np.nextafter(v, -np.inf)]
+    x = np.asarray(edge, dtype=np.float64)
+    x = x[(np.abs(x) >= 2.0 ** -500) & (np.abs(x) <= 2.0 ** 500)]
+    assert np.array_equal(np.sqrt(x * x), np.abs(x))
+    for v in (2.0 ** -500, 2.0 ** 500, -2.0 ** 500, 0.0):
+        assert np.sqrt(np.float64(v) * np.float64(v)) == abs(v)
+    tiny = np.float64(2.0 ** -540) * np.float64(1.0 + 2.0 ** -30)
+    assert np.sqrt(tiny * tiny) != tiny
