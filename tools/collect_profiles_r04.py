@@ -54,6 +54,13 @@ with open(os.path.join(P, "r04_small_scenes.txt"), "w") as f:
     f.writelines(l[l.index("== N="):] for l in open(os.path.join(E, "small_scenes.txt"), errors="replace") if "== N=" in l)
 
 
+for a, b, key in (("dlt_probe.txt", "r04_dlt_probe.txt", "M ="), ("meanshift_probe.txt", "r04_meanshift_session.txt", "N =")):
+    if os.path.exists(os.path.join(E, a)):
+        with open(os.path.join(P, b), "w") as f:
+            f.writelines(l for l in open(os.path.join(E, a), errors="replace") if key in l)
+            f.write(f"source: HEAD {sha}\n")
+
+
 def last(path, pattern):
     hits = [m.group(0).strip() for l in open(path, errors="replace") for m in [re.search(pattern, l)] if m]
     return hits[-1] if hits else "(missing)"

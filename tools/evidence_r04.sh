@@ -12,6 +12,8 @@ python tools/shard_proxy.py > gpurun_out/ev4/shard_proxy.txt 2>&1
 HEADROOM=-1,0,64 SIZES=100000,12500 python tools/shard_proxy.py > gpurun_out/ev4/shard_proxy_ab.txt 2>&1
 DEPTH=1 python tools/shard_proxy.py > gpurun_out/ev4/shard_proxy_depth1.txt 2>&1
 python tools/enqueue_probe.py > gpurun_out/ev4/enqueue_probe.txt 2>&1
+timeout 120 python tools/dlt_probe.py > gpurun_out/ev4/dlt_probe.txt 2>&1
+timeout 200 python tools/meanshift_probe.py > gpurun_out/ev4/meanshift_probe.txt 2>&1
 for M in 12500 100000; do
   SIZES=$M STEPS=20 WARM=3 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ev4/tl_$M -- python3 tools/shard_proxy.py > gpurun_out/ev4/tl_$M.log 2>&1
   python3 tools/timeline.py $(find gpurun_out/ev4/tl_$M -name "*kernel_trace.csv" | head -1) 8 3 > gpurun_out/ev4/timeline_$M.txt
