@@ -526,7 +526,10 @@ void ParallelFor(int count, size_t cost, Fn work)
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
     if (nthreads > 32) nthreads = 32;
-    if (cost < 200000) nthreads = 1;
+    // a thread costs some tens of microseconds to start and join: one per ~150 000 units of work (a 3-point fit is ~400),
+    // so the post-filter of a two-plane scene (1 002 fits) runs on three threads, not on thirty-two
+    const size_t useful = cost / 150000;
+    if (useful < nthreads) nthreads = useful < 1 ? 1 : (unsigned)useful;
     std::atomic<int> next(0);
     auto loop = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= count) break; work(i); } };
     if (nthreads == 1) { loop(); return; }
