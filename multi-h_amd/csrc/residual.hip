@@ -413,6 +413,12 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant >= 700)         // 700 + psplit: store-only calibration with nt stores (the product's store instruction) and a forced point split
+        return launch_rs<4, 16, true, false, true, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 700);
+    if (variant >= 600)         // 600 + psplit: fused multiply-adds (NOT bit-exact) with a forced point split
+        return launch_rs<4, 16, true, false, false, true, false, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 600);
+    if (variant >= 500)         // 500 + psplit: store-only calibration (plain stores) with a forced point split
+        return launch_rs<4, 16, true, false, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 500);
     if (variant >= 400)         // 400 + psplit: the product kernel with a forced point split (tools/shard_proxy.py)
         return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 400);
     if (variant >= 300)         // 300 + s: s interleaved slices with the slice index as the fastest grid dimension

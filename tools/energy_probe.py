@@ -176,11 +176,20 @@ for v in VARIANTS:
         print(f"variant {v}: not in this library ({ex})", flush=True)
         continue
     measure(f"residual {v}: {names.get(v, '')}", lambda: e.residual_matrix(thr2, fetch_R=False, fetch_counts=False), 1, 8.0 * N * M)
+    if v == "0":
+        e.set_tuning(19, -1)
+        measure("residual 0 with one hardware-dispatched workgroup per item (the r01-r03 launch; the product is a resident grid)",
+                lambda: e.residual_matrix(thr2, fetch_R=False, fetch_counts=False), 1, 8.0 * N * M)
+        e.set_tuning(19, 0)
 e.set_tuning(0, 0)
 e.set_tuning(15, 0)
 measure("fused score, FP64 sweep (no stores)", lambda: e.score(thr2, fetch=False), 2, 8.0 * N * M)
 e.set_tuning(15, 1)
 measure("fused score, FP32 pre-test (no stores)", lambda: e.score(thr2, fetch=False), 2, 8.0 * N * M)
+for form, what in ((1, "k_dlt4_lds: W staged in LDS (r01-r04)"), (0, "k_dlt4: W in registers, DPP column hand-over (product)")):
+    e.set_tuning(25, form)
+    measure(f"DLT proposer, {M} hypotheses, {what}", lambda: e.propose_dlt4(1234, 0, M), 0, 88.0 * M)
+e.set_tuning(25, 0)
 out["reading"] = ("Every variant that does the arithmetic runs AT the board's power cap (power_W_mean = power_cap_W) with the shader clock pulled "
                   "down to 1.5-1.75 GHz; its time per launch is its energy per launch divided by the cap.  Variants that do less work per pair "
                   "(fused multiply-adds) finish sooner at the same power, variants that do more (compiler division) later; the store stream alone and "
