@@ -324,7 +324,9 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * created in front of the engine's second stream (before its first use), 23 the int32 cost matrix as a resident grid (n point slices,
  * default 8; 0 = one hardware-dispatched workgroup per item; -1 = about 37 500 items), 24 the same for the FP32 pre-test score
  * (default 12) — schedule only, 25 the DLT proposer's form (0, default: columns in registers handed round with DPP; 1: the
- * LDS-staged form of r01-r04; same bits).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * LDS-staged form of r01-r04; same bits), 26 experiment: the resident residual sweep takes its items slice-major with this
+ * many point slices (0, default: model block fastest, ~37 500 items), 27 the same order for the resident cost-matrix kernel
+ * — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

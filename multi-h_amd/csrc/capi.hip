@@ -104,6 +104,8 @@ struct mh_engine {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side_pre = nullptr;
     int tune_score32_resident = 12;          // key 24: the FP32 pre-test score as a resident grid with n point slices (12: 1.98 ms against 2.14 hardware-dispatched at 50k x 100k, tools/score32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
+    int tune_cost32_slice_major = 0;         // key 27: the resident cost-matrix kernel takes its items slice-major (experiment)
+    int tune_sweep_slices = 0;               // key 26: > 0 = the resident sweep takes its items slice-major with this many point slices (experiment)
     int tune_dlt_variant = 0;                // key 25: 0 = the register-resident proposer (DPP column hand-over), 1 = the LDS-staged form of r01-r04 (same bits)
     int tune_cost32_resident = 8;            // key 23: the int32 cost matrix as a resident grid with n point slices (8: 4.12 ms against 4.25 hardware-dispatched at 50k x 100k, tools/cost32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_stream_shift = 0;               // key 22 (experiment): dummy streams created in front of the second / third stream (shifts their hardware queue / pipe)
@@ -1577,7 +1579,7 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
         ScopedTimer t(e, MH_K_RESIDUAL);
         HIPCHK(launch_residual(e->pts(), e->H.p, e->m, thr2, e->R.p, e->ldr, e->counts.p,
                                e->residual_mode == MH_RESIDUAL_SYMMETRIC ? -1 : e->tune_residual_variant,
-                               e->stream, e->counts_zeroed, resident, e->sweep_ctl.p));
+                               e->stream, e->counts_zeroed, resident, e->sweep_ctl.p, e->tune_sweep_slices, e->tune_sweep_slices > 0 ? 1 : 0));
     }
     e->counts_zeroed = false;
     e->counts_fresh = true;
@@ -1614,7 +1616,7 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
                 ctl = e->sweep_ctl.p;
             }
             HIPCHK(launch_cost32(e->pts(), e->H.p, e->H32.p, e->m, e->lambda, thr2, e->absmax_dst, e->C.p, e->ldc, e->counts.p, e->stream,
-                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0));
+                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0, e->tune_cost32_slice_major));
         } else
             HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, thr2, e->C.p, e->ldc, e->counts.p, e->stream));
     }
@@ -2405,6 +2407,8 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 23 && value >= -1 && value <= 64) { e->tune_cost32_resident = value; return MH_OK; }
     if (key == 24 && value >= -1 && value <= 64) { e->tune_score32_resident = value; return MH_OK; }
     if (key == 25 && (value == 0 || value == 1)) { e->tune_dlt_variant = value; return MH_OK; }
+    if (key == 26 && value >= 0 && value <= 4096) { e->tune_sweep_slices = value; return MH_OK; }
+    if (key == 27 && (value == 0 || value == 1)) { e->tune_cost32_slice_major = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

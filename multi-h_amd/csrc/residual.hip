@@ -315,7 +315,7 @@ k_residual_resident(const double* __restrict__ x1, const double* __restrict__ y1
                     const double* __restrict__ x2, const double* __restrict__ y2, int N,
                     const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
                     long long ldr, int* __restrict__ counts, const unsigned char* __restrict__ mask,
-                    int psplit, int gx, int nitems, int* __restrict__ ctl, double bx0, double bx1, double by0, double by1)
+                    int psplit, int gx, int nitems, int* __restrict__ ctl, double bx0, double bx1, double by0, double by1, int slice_major)
 {
     // Items are handed out through one counter, first come first served — the workgroups of a resident grid do not run at
     // one speed (a compute unit that holds six of them serves each more slowly than one that holds five, and the memory
@@ -328,7 +328,12 @@ k_residual_resident(const double* __restrict__ x1, const double* __restrict__ y1
         __syncthreads();
         const int item = s_item;
         if (item >= nitems) break;
-        const int by = item / gx, bx = item - by * gx;
+        // slice_major: consecutive items are the point slices of ONE model block, so the workgroups at work at any moment
+        // write a compact window of R (a few dozen model blocks, every row of them along its whole length) instead of one
+        // slice of every block in turn
+        int bx, by;
+        if (slice_major) { bx = item / psplit; by = item - bx * psplit; }
+        else { by = item / gx; bx = item - by * gx; }
         residual_wg<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI>(
             x1, y1, x2, y2, N, H, M, thr2, R, ldr, counts, mask, psplit, bx0, bx1, by0, by1, bx, by);
         __syncthreads();                        // the item's LDS (coefficients, flags, counts) and s_item are rewritten by the next one
@@ -344,7 +349,7 @@ template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST = true, b
 static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2, double* R,
                             long long ldr, int* counts, const unsigned char* mask, hipStream_t s,
                             int force_psplit = 0, int swapxy = 0, bool counts_zeroed = false, int resident_grid = 0,
-                            int* resident_ctl = nullptr)
+                            int* resident_ctl = nullptr, int slice_major = 0)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     const int gx = (M + MC - 1) / MC;
@@ -384,7 +389,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
     if (resident_grid > 0 && resident_ctl && !contiguous && !swapxy && gx * psplit > resident_grid) {
         hipLaunchKernelGGL((k_residual_resident<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI, MINW>),
                            dim3(resident_grid), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, M, thr2, R, ldr, counts, mask, psplit, gx,
-                           gx * psplit, resident_ctl, p.xmin, p.xmax, p.ymin, p.ymax);
+                           gx * psplit, resident_ctl, p.xmin, p.xmax, p.ymin, p.ymax, slice_major);
         return hipGetLastError();
     }
     dim3 grid(gx, psplit);
@@ -401,14 +406,14 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
 // exists only in libraries compiled with -DMH_TUNING (multi-h_amd/build.py --tuning) for tools/kernel_sweep.py.
 hipError_t launch_residual(const Points& p, const double* H, int M, double thr2, double* R,
                            long long ldr, int* counts, int variant, hipStream_t s, bool counts_zeroed, int resident_grid,
-                           int* resident_ctl)
+                           int* resident_ctl, int slices, int slice_major)
 {
     // PPL 4, MC 16, the lean sweep wherever a tile and a model allow it, non-temporal 16-B stores (r03: the kernel runs at
     // the board's power cap, its time is its energy; nt stores — nothing of R is ever re-read — cost 2.7 % less energy
     // per launch than plain ones, profiles/r03_energy.json)
     // ... and the nine coefficients of the current model through the scalar unit (s_load from H, uniform address) instead
     // of LDS broadcasts into VGPRs: the twelve linear-form operations then read one operand from SGPRs; 2.5 % less energy.
-    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, 0, 0, counts_zeroed, resident_grid, resident_ctl);
+    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
     if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)

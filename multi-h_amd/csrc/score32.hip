@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64 * WAVES)
 k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
                   const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
                   double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit,
-                  int gx, int nitems, int* __restrict__ ctl)
+                  int gx, int nitems, int* __restrict__ ctl, int slice_major)
 {
     __shared__ int s_item;
 #pragma unroll 1
@@ -427,7 +427,11 @@ k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, 
         __syncthreads();
         const int item = s_item;
         if (item >= nitems) break;
-        const int by = item / gx, bx = item - by * gx;
+        // slice_major: consecutive items are the point slices of one model block — the workgroups at work write a compact
+        // window of C (tools/ubench/store_order.hip: the store stream alone gains 9 % from that order)
+        int bx, by;
+        if (slice_major) { bx = item / psplit; by = item - bx * psplit; }
+        else { by = item / gx; bx = item - by * gx; }
         cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, bx, by);
         __syncthreads();
     }
@@ -439,7 +443,7 @@ k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, 
 
 // H32: the table launch_model32 made for these models with the same Cmax.  thr2 in [2^-40, 2^40], coordinates below 2^20.
 hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
-                         int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override)
+                         int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     constexpr int MC = 32;
@@ -468,7 +472,7 @@ hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int
             hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((k_cost32_resident<MC, WAVES>), dim3(grid), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M,
-                               100.0 / lambda, thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, ps, gx, gx * ps, resident_ctl);
+                               100.0 / lambda, thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, ps, gx, gx * ps, resident_ctl, slice_major);
             return hipGetLastError();
         }
     }
