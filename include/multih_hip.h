@@ -323,8 +323,9 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * dispatch (1, default) or not (0) — schedule only, 21 moves whose core components are diagnosed (mh_get_core_components; 0 = off), 22 experiment: dummy streams
  * created in front of the engine's second stream (before its first use), 23 the int32 cost matrix as a resident grid (n point slices,
  * default 8; 0 = one hardware-dispatched workgroup per item; -1 = about 37 500 items), 24 the same for the FP32 pre-test score
- * (default 12) — schedule only, 25 the DLT proposer's form (0, default: columns in registers handed round with DPP; 1: the
- * LDS-staged form of r01-r04; same bits), 26 experiment: the resident residual sweep takes its items slice-major with this
+ * (default 12) — schedule only, 25 the DLT proposer's form (0, default: by context — columns in registers handed round with
+ * DPP for mh_propose_dlt4, the LDS-staged form, whose 72 registers fit beside a resident sweep, for mh_prefetch_dlt4; 1: the
+ * LDS-staged form everywhere; 2: the register form everywhere; same bits), 26 experiment: the resident residual sweep takes its items slice-major with this
  * many point slices (0, default: model block fastest, ~37 500 items), 27 the same order for the resident cost-matrix kernel
  * — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING

@@ -106,7 +106,7 @@ struct mh_engine {
     int tune_score32_resident = 12;          // key 24: the FP32 pre-test score as a resident grid with n point slices (12: 1.98 ms against 2.14 hardware-dispatched at 50k x 100k, tools/score32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_cost32_slice_major = 0;         // key 27: the resident cost-matrix kernel takes its items slice-major (experiment)
     int tune_sweep_slices = 0;               // key 26: > 0 = the resident sweep takes its items slice-major with this many point slices (experiment)
-    int tune_dlt_variant = 0;                // key 25: 0 = the register-resident proposer (DPP column hand-over), 1 = the LDS-staged form of r01-r04 (same bits)
+    int tune_dlt_variant = 0;                // key 25: 0 = by context (below), 1 = the LDS-staged proposer everywhere, 2 = the register-resident one everywhere (same bits)
     int tune_cost32_resident = 8;            // key 23: the int32 cost matrix as a resident grid with n point slices (8: 4.12 ms against 4.25 hardware-dispatched at 50k x 100k, tools/cost32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
     int tune_stream_shift = 0;               // key 22 (experiment): dummy streams created in front of the second / third stream (shifts their hardware queue / pipe)
     std::vector<hipStream_t> dummy_streams;
@@ -1439,7 +1439,7 @@ int mh_propose_dlt4(mh_engine* e, unsigned long long seed, long long first, int 
     HIPCHK(reserve_counts(e, (size_t)m + 1));
     {
         ScopedTimer t(e, MH_K_DLT4);
-        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples.p, e->H.p, e->stream, e->tune_dlt_variant));
+        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->samples.p, e->H.p, e->stream, e->tune_dlt_variant == 1 ? 1 : 0));   // alone on the device: the register form (0.26 against 0.40 ms per 100k)
     }
     e->m = m;
     e->have_samples = true;
@@ -1882,7 +1882,11 @@ int mh_prefetch_dlt4(mh_engine* e, unsigned long long seed, long long first, int
     HIPCHK(hipEventRecord(e->ev_side_pre, e->side_stream));      // the second stream has got as far as this batch's dispatch
     {
         ScopedTimer t(e, MH_K_DLT4, e->side_stream);           // (the kernel's span on the second stream, beside whatever the main one runs)
-        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->pf_samples[slot].p, e->pf_H[slot].p, e->side_stream, e->tune_dlt_variant));
+        // Beside a resident sweep the LDS-staged form is the better one although it is 1.5 x slower alone: its 72 registers
+        // fit next to the sweep's five waves per SIMD, so it shares the compute units with the sweep's head, while the
+        // register form (128) has to displace sweep workgroups and its run time is added to the step: 0.964 against 0.994 ms
+        // per step at the 12 500-hypothesis shard, 1.891 / 1.928 at 25 000, 7.41 / 7.41 at 100 000 (tools/shard_proxy.py DLTFORM=1).
+        HIPCHK(launch_dlt4(e->pts(), seed, first, m, e->pf_samples[slot].p, e->pf_H[slot].p, e->side_stream, e->tune_dlt_variant == 2 ? 0 : 1));
     }
     HIPCHK(hipEventRecord(e->pf_ev[slot], e->side_stream));
     e->pf_m[slot] = m;
@@ -2406,7 +2410,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 22 && value >= 0 && value <= 16 && !e->side_stream) { e->tune_stream_shift = value; return MH_OK; }
     if (key == 23 && value >= -1 && value <= 64) { e->tune_cost32_resident = value; return MH_OK; }
     if (key == 24 && value >= -1 && value <= 64) { e->tune_score32_resident = value; return MH_OK; }
-    if (key == 25 && (value == 0 || value == 1)) { e->tune_dlt_variant = value; return MH_OK; }
+    if (key == 25 && value >= 0 && value <= 2) { e->tune_dlt_variant = value; return MH_OK; }
     if (key == 26 && value >= 0 && value <= 4096) { e->tune_sweep_slices = value; return MH_OK; }
     if (key == 27 && (value == 0 || value == 1)) { e->tune_cost32_slice_major = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");

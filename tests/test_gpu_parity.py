@@ -126,7 +126,7 @@ def test_sampling_and_dlt4(engine, synth, oracle, n, m, seed):
 
 def test_dlt4_register_form_equals_lds_form(engine, synth, oracle):
     """The proposer keeps W in registers and hands the columns round with DPP row shifts (dlt4.hip, k_dlt4); the
-    LDS-staged form of r01-r04 is still there behind tuning key 25.  Same rotations in the same order: every model
+    LDS-staged form of r01-r04 is what mh_prefetch_dlt4 launches beside a resident sweep (tuning key 25 forces either).  Same rotations in the same order: every model
     bit-identical, on a scene with degenerate samples among them, and both equal to the oracle."""
     sc = synth.make_scene(300, 2, seed=21, with_neighbours=False)
     rng = np.random.default_rng(21)
@@ -137,10 +137,10 @@ def test_dlt4_register_form_equals_lds_form(engine, synth, oracle):
     M = 8192 + 37                                  # a ragged last workgroup
     out = {}
     try:
-        for form in (1, 0):
+        for form in (1, 2):
             engine.set_tuning(25, form)
             engine.propose_dlt4(77, 5, M)
-            out[form] = (engine.get_samples().copy(), engine.get_models().copy())
+            out[0 if form == 2 else 1] = (engine.get_samples().copy(), engine.get_models().copy())
     finally:
         engine.set_tuning(25, 0)
     assert np.array_equal(out[0][0], out[1][0])

@@ -186,7 +186,7 @@ e.set_tuning(15, 0)
 measure("fused score, FP64 sweep (no stores)", lambda: e.score(thr2, fetch=False), 2, 8.0 * N * M)
 e.set_tuning(15, 1)
 measure("fused score, FP32 pre-test (no stores)", lambda: e.score(thr2, fetch=False), 2, 8.0 * N * M)
-for form, what in ((1, "k_dlt4_lds: W staged in LDS (r01-r04)"), (0, "k_dlt4: W in registers, DPP column hand-over (product)")):
+for form, what in ((1, "k_dlt4_lds: W staged in LDS (the prefetch path)"), (2, "k_dlt4: W in registers, DPP column hand-over (mh_propose_dlt4)")):
     e.set_tuning(25, form)
     measure(f"DLT proposer, {M} hypotheses, {what}", lambda: e.propose_dlt4(1234, 0, M), 0, 88.0 * M)
 e.set_tuning(25, 0)

@@ -116,6 +116,14 @@ if HEADROOM:
             print(f"M {M:7d} dlt-first {first} headroom {h:4d}: step {r['step_ms']:.4f} ms (min {r['step_min']:.4f})  k_residual {r['k_residual_ms']:.4f} ms", flush=True)
         eng.set_tuning(19, 0)
         eng.set_tuning(20, 1)
+if os.environ.get("DLTFORM"):
+    print("== the prefetched DLT's form (mh_set_tuning key 25): 1 = LDS-staged, 72 registers (fits beside five sweep waves per SIMD); 2 = columns in registers, 128 registers")
+    for M in SIZES:
+        for form in (1, 2, 1, 2):
+            eng.set_tuning(25, form)
+            r = run(M, f"dlt form {form}")
+            print(f"M {M:7d} DLT form {form}: step {r['step_ms']:.4f} ms (min {r['step_min']:.4f})  k_residual {r['k_residual_ms']:.4f} ms", flush=True)
+    eng.set_tuning(25, 0)
 if PSPLIT:
     print("== forced point splits of k_residual (tuning library)")
     for M in SIZES:
