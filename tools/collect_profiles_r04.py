@@ -36,6 +36,9 @@ with open(os.path.join(P, "r04_shard_proxy.txt"), "a") as f:
     for l in open(os.path.join(E, "shard_proxy_depth1.txt"), errors="replace"):
         if l.startswith("== "): keep = True
         if keep and not l.startswith("{") and not re.search(r"^RCCL version|^HIP version|^ROCm version|^Hostname|^Librccl|amdgpu.ids", l): f.write(l)
+    if os.path.exists(os.path.join(E, "shard_proxy_dltform.txt")):
+        f.write("\n-- A/B: which form of the DLT proposer is prefetched beside the sweep (tools/shard_proxy.py DLTFORM=1)\n")
+        f.writelines(open(os.path.join(E, "shard_proxy_dltform.txt"), errors="replace"))
     f.write("\n-- tools/enqueue_probe.py (two batches ahead, no timing events on the stream)\n")
     f.writelines(l for l in open(os.path.join(E, "enqueue_probe.txt"), errors="replace") if l.startswith("M "))
     f.write(f"source: HEAD {sha}\n")

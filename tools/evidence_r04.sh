@@ -12,6 +12,7 @@ python tools/shard_proxy.py > gpurun_out/ev4/shard_proxy.txt 2>&1
 HEADROOM=-1,0,64 SIZES=100000,12500 python tools/shard_proxy.py > gpurun_out/ev4/shard_proxy_ab.txt 2>&1
 DEPTH=1 python tools/shard_proxy.py > gpurun_out/ev4/shard_proxy_depth1.txt 2>&1
 python tools/enqueue_probe.py > gpurun_out/ev4/enqueue_probe.txt 2>&1
+DLTFORM=1 SIZES=100000,25000,12500 timeout 300 python tools/shard_proxy.py 2>&1 | grep -a 'DLT form\|^== the prefetched' > gpurun_out/ev4/shard_proxy_dltform.txt
 timeout 120 python tools/dlt_probe.py > gpurun_out/ev4/dlt_probe.txt 2>&1
 timeout 200 python tools/meanshift_probe.py > gpurun_out/ev4/meanshift_probe.txt 2>&1
 for M in 12500 100000; do
