@@ -392,6 +392,36 @@ def test_resident_sweep_beside_a_prefetch_equals_the_dispatched_sweep(engine, sy
         engine.set_tuning(19, 0)
 
 
+def test_slice_major_item_order_changes_nothing(engine, synth):
+    """r04 experiment knobs (mh_set_tuning keys 26 / 27): the resident sweep and the resident cost-matrix kernel hand out
+    their items slice-major (consecutive items = the point slices of one model block).  A schedule, not a result: the
+    same matrices and counts as the default order, for slice counts that do and do not divide the number of tiles."""
+    sc = synth.make_scene(20011, 4, seed=29, with_neighbours=False)
+    _load(engine, sc)
+    M = 6007
+    engine.propose_dlt4(43, 0, M)
+    rows = [0, 15, 16, 2999, M - 1]
+    _, cnt_ref = engine.residual_matrix(THR2, fetch_R=False)
+    R_ref = np.stack([engine.get_residual_rows(r, 1)[0] for r in rows])
+    C_ref, ccnt_ref = engine.cost_matrix()
+    try:
+        for slices in (3, 7, 20, 4096):
+            engine.set_tuning(26, slices)
+            _, cnt = engine.residual_matrix(THR2, fetch_R=False)
+            R = np.stack([engine.get_residual_rows(r, 1)[0] for r in rows])
+            assert np.array_equal(cnt, cnt_ref), slices
+            assert np.array_equal(R.view(np.uint64), R_ref.view(np.uint64)), slices
+        engine.set_tuning(27, 1)
+        for v in (8, 3):
+            engine.set_tuning(23, v)
+            C1, ccnt = engine.cost_matrix()
+            assert np.array_equal(ccnt, ccnt_ref) and np.array_equal(C1, C_ref), v
+    finally:
+        engine.set_tuning(26, 0)
+        engine.set_tuning(27, 0)
+        engine.set_tuning(23, 8)
+
+
 def test_two_batches_prefetched_ahead(mh, engine, synth):
     """r04: the prefetch queue holds two batches (the batch after next is prepared too, so the DLT a sweep waits for was
     dispatched a whole sweep earlier).  First in, first out; a third prefetch is refused; tuples, homographies and the counts
