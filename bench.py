@@ -329,19 +329,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(scaling: str, steps: int, warmup: int, pipelined: bool = False, profile: bool = True):
-        """`warmup` untimed steps, then exactly `steps` timed ones between two fences; max over ranks."""
+    def run_mode(scaling: str, steps: int, warmup: int, pipelined: bool = False, profile: bool = True, models: int = 0,
+                 mark_steps: bool = True):
+        """`warmup` untimed steps, then exactly `steps` timed ones between two fences; max over ranks.
+        models: batch size instead of --models (the one-GPU rehearsal of a strong split's per-rank shard)."""
+        batch = models if models > 0 else a.models
         if scaling == "weak":
-            sizes = [a.models] * world                       # every GPU scores its own batch of M
+            sizes = [batch] * world                          # every GPU scores its own batch of M
         else:
-            sizes = sharding.shard_counts(a.models, world)   # one batch of M split across the GPUs (configs[3])
+            sizes = sharding.shard_counts(batch, world)      # one batch of M split across the GPUs (configs[3])
         M = sizes[rank]
         total = sum(sizes)
 
         def first_of(i: int) -> int:
             if scaling == "weak":
                 return sharding.batch_first(i, world, rank, M)     # disjoint RNG counters per (step, rank)
-            return i * a.models + sharding.shard_range(a.models, world, rank)[0]
+            return i * batch + sharding.shard_range(batch, world, rank)[0]
 
         def step(i: int, last: bool = False):
             if pipelined:
@@ -363,7 +366,7 @@ def main():
         # A timing event at every step boundary is a marker packet on the engine's stream: about 25 us per step
         # (tools/enqueue_probe.py: 0.970 ms per 12 500-hypothesis step without them, 0.995-1.005 with).  Nothing at the 7.4 ms
         # steps of one GPU, 2.5 % at the 1 ms steps of an 8-GPU strong split — so with several ranks only the ends are marked.
-        every = 1 if world == 1 else steps
+        every = 1 if world == 1 and mark_steps else steps
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps // every + 1)]
         t0 = time.perf_counter()
         marks[0].record()
@@ -442,6 +445,19 @@ def main():
         other["res_ms"], other["dlt_ms"] = ko["res_ms"], ko["dlt_ms"]
     seq = run_mode(a.scaling, a.steps, a.warmup, pipelined=False)
     M, sizes, dt = head["M"], head["sizes"], head["dt"]
+    # One GPU only: the per-rank shards a strong split of this batch over 2 / 4 / 8 GPUs would hand a rank, stepped the same
+    # way (no timing markers inside, 40 steps) — what the split can reach at best before any exchange between real ranks.
+    shard_rehearsal = None
+    if world == 1 and a.models >= 8 * 1024:
+        ref = run_mode("strong", 20, 3, pipelined=True, profile=False, mark_steps=False)
+        shard_rehearsal = {"what": "the same pipelined step on 1 GPU with this batch's per-rank shard of a 2 / 4 / 8-GPU strong split (no timing "
+                                   "markers inside the timed steps); efficiency = (ms per step of the whole batch / ranks) / ms per step of the shard",
+                           "whole_batch_ms_per_step": ref["dt"] / 20 * 1e3, "shards": []}
+        for ranks in (2, 4, 8):
+            r = run_mode("strong", 40, 5, pipelined=True, profile=False, models=a.models // ranks, mark_steps=False)
+            ms = r["dt"] / 40 * 1e3
+            shard_rehearsal["shards"].append({"ranks": ranks, "hypotheses": a.models // ranks, "ms_per_step": ms,
+                                              "efficiency": ref["dt"] / 20 * 1e3 / ranks / ms})
 
     # Outside the timed region: the store-free fused score kernel on the last batch (SURVEY §8(d)
     # "fused score kernel: not HBM-bound"), reported next to the headline for context.
@@ -538,6 +554,7 @@ def main():
                                 "k_residual_frac_of_hbm_peak": alg_bytes / (seq["res_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "scores_identical": seq["scores_sha256"] == head["scores_sha256"]},
             "transport": transport_kind,
+            "strong_split_rehearsal_on_one_gpu": shard_rehearsal,
             "fused_score_hypotheses_per_s_per_gpu": M / (pretest_ms * 1e-3),
             "fused_score": {"what": "mh_score on the same batch, no matrix written: FP32 pre-test with a rigorous error bound, FP64 formula only for the "
                                     "pairs it cannot decide (csrc/score32.hip); counts identical to the FP64 sweep's",
