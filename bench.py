@@ -62,6 +62,8 @@ def parse():
                          "configs[3]); weak = --models per rank.  The other mode is timed too and reported alongside.")
     ap.add_argument("--cpu-sample", type=int, default=150000, help="hypotheses in the CPU baseline sample (about 13 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rehearsal", action="store_true", help="skip the one-GPU rehearsal of the strong split's shards (keeps a "
+                    "profiler's per-kernel statistics to the full-size launches)")
     return ap.parse_args()
 
 
@@ -448,7 +450,7 @@ def main():
     # One GPU only: the per-rank shards a strong split of this batch over 2 / 4 / 8 GPUs would hand a rank, stepped the same
     # way (no timing markers inside, 40 steps) — what the split can reach at best before any exchange between real ranks.
     shard_rehearsal = None
-    if world == 1 and a.models >= 8 * 1024:
+    if world == 1 and a.models >= 8 * 1024 and not a.no_rehearsal:
         ref = run_mode("strong", 20, 3, pipelined=True, profile=False, mark_steps=False)
         shard_rehearsal = {"what": "the same pipelined step on 1 GPU with this batch's per-rank shard of a 2 / 4 / 8-GPU strong split (no timing "
                                    "markers inside the timed steps); efficiency = (ms per step of the whole batch / ranks) / ms per step of the shard",
