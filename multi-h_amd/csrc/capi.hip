@@ -104,6 +104,7 @@ struct mh_engine {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side_pre = nullptr;
     int tune_score32_resident = 12;          // key 24: the FP32 pre-test score as a resident grid with n point slices (12: 1.98 ms against 2.14 hardware-dispatched at 50k x 100k, tools/score32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
+    int tune_cost32_batched = 0;             // key 28: 1 = experiment: k_cost32 evaluates the near pairs of several models together (score32.hip, cost32_wg_batched; slower: 4.45 vs 4.10 ms)
     int tune_cost32_slice_major = 0;         // key 27: the resident cost-matrix kernel takes its items slice-major (experiment)
     int tune_sweep_slices = 0;               // key 26: > 0 = the resident sweep takes its items slice-major with this many point slices (experiment)
     int tune_dlt_variant = 0;                // key 25: 0 = by context (below), 1 = the LDS-staged proposer everywhere, 2 = the register-resident one everywhere (same bits)
@@ -1616,7 +1617,7 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
                 ctl = e->sweep_ctl.p;
             }
             HIPCHK(launch_cost32(e->pts(), e->H.p, e->H32.p, e->m, e->lambda, thr2, e->absmax_dst, e->C.p, e->ldc, e->counts.p, e->stream,
-                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0, e->tune_cost32_slice_major));
+                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0, e->tune_cost32_slice_major, e->tune_cost32_batched));
         } else
             HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, thr2, e->C.p, e->ldc, e->counts.p, e->stream));
     }
@@ -2413,6 +2414,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 25 && value >= 0 && value <= 2) { e->tune_dlt_variant = value; return MH_OK; }
     if (key == 26 && value >= 0 && value <= 4096) { e->tune_sweep_slices = value; return MH_OK; }
     if (key == 27 && (value == 0 || value == 1)) { e->tune_cost32_slice_major = value; return MH_OK; }
+    if (key == 28 && (value == 0 || value == 1)) { e->tune_cost32_batched = value; return MH_OK; }
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

@@ -52,7 +52,7 @@ hipError_t launch_score32(const Points& p, const double* H, const float* H32, in
 // the materialised int32 cost matrix (launch_cost_matrix, datacost.hip) through the same pre-test; H32 made with the same Cmax
 hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
                          int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl = nullptr, int cu_count = 256,
-                         int psplit_override = 0, int slice_major = 0);
+                         int psplit_override = 0, int slice_major = 0, int batched = 0);
 hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
                                    int label_value, int* labels, hipStream_t s);
 hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,

@@ -403,17 +403,156 @@ cost32_wg(const double* __restrict__ x1, const double* __restrict__ y1, const do
     }
 }
 
+// cost32_wg_batched (r04 EXPERIMENT, mh_set_tuning key 28 = 1; not the default): the same matrix with the near pairs of
+// SEVERAL models evaluated together.  Measured at 50k x 100k: the arithmetic side gains what was expected (4.13 -> 3.56 ms
+// when the near pairs' costs are computed but not delivered), the delivery loses more: 4.45 ms with plain stores of the
+// constant and 5.95 ms with non-temporal ones — a 4-byte store into a line that has already left L2 is a read-modify-write
+// in memory, 150 million of them per launch.  Delivering through LDS to the owning lane before ITS store (the default
+// form) needs the costs of all pending models in LDS, which the 64 KB of FP64 point copies leave no room for.  In cost32_wg every
+// wave x model iteration that contains a near pair (42 % of them on a DLT batch) pays a pass through the IEEE formula with,
+// typically, a few dozen of its 64 lanes at work.  Here a wave writes the constant row segment at once, appends its near
+// pairs — (model, point slot, lane) — to a list in LDS, and runs the formula only when 64 entries have gathered (and once at
+// the end of a tile): full lanes, one eighth of the passes.  The cost of a near pair then goes straight to C[m][n], over
+// the constant written before: the wave drains its stores (s_waitcnt vmcnt(0)) before the first such store of a batch, so
+// the two writes of an address arrive in order.  Inlier counts go through an LDS counter per (wave, model).
 template <int MC, int WAVES>
+__device__ __forceinline__ void
+cost32_wg_batched(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+                  const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
+                  double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit,
+                  const int bx, const int by)
+{
+    constexpr int PPL = 4, WAVE_PTS = 64 * PPL, TILE = WAVES * WAVE_PTS, THREADS = 64 * WAVES, LCAP = 64 + 64 * PPL;
+    static_assert(MC <= 64, "a list entry carries the model in 6 bits");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = bx * MC;
+    __shared__ float4 s_m[MC * 4];
+    __shared__ double s_h[MC * 9];
+    __shared__ double s_p[WAVES * PPL * 4 * 64];          // [wave][point of the lane][x1 y1 x2 y2][lane]
+    __shared__ unsigned short s_list[WAVES * LCAP];       // per wave: (model << 8 | point slot << 6 | lane) of the pending near pairs
+    __shared__ int s_cnt[WAVES][MC];
+    for (int i = threadIdx.x; i < MC * 4; i += THREADS) {
+        const size_t g = (size_t)m0 * 4 + i;
+        s_m[i] = g < (size_t)M * 4 ? reinterpret_cast<const float4*>(H32)[g] : make_float4(0.f, 0.f, 0.f, NAN);
+    }
+    for (int i = threadIdx.x; i < MC * 9; i += THREADS) {
+        const size_t g = (size_t)m0 * 9 + i;
+        s_h[i] = g < (size_t)M * 9 ? H[g] : 0.0;
+    }
+    for (int i = threadIdx.x; i < WAVES * MC; i += THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    double* wave_p = s_p + (size_t)wave * (PPL * 4 * 64);
+    double* my_p = wave_p + lane;
+    unsigned short* my_list = s_list + wave * LCAP;
+    float vk1;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vk1) : "s"(k1));
+    const int beyond = 2 * (int)round(lam * T);
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    const i4v vbeyond = { beyond, beyond, beyond, beyond };
+    for (int base = by * TILE; base < N; base += psplit * TILE) {
+        const int base_n = base + wave * WAVE_PTS;
+        const int n0 = base_n + lane * PPL;
+        float fx[PPL], fy[PPL], gx[PPL], gy[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int n = n0 + q;
+            const bool ok = n < N;
+            const double px = ok ? x1[n] : 1.0, py = ok ? y1[n] : 1.0, qx = ok ? x2[n] : 1.0, qy = ok ? y2[n] : 1.0;
+            my_p[(q * 4 + 0) * 64] = px; my_p[(q * 4 + 1) * 64] = py; my_p[(q * 4 + 2) * 64] = qx; my_p[(q * 4 + 3) * 64] = qy;
+            fx[q] = (float)px; fy[q] = (float)py; gx[q] = (float)qx; gy[q] = (float)qy;
+        }
+        wave_lds_handover();                     // the FP64 copies are read by OTHER lanes of this wave below
+        // One pass of the IEEE formula over the list entries [first, first + 64) (those below `count`).
+        auto evaluate = [&](int first, int count) {
+            if (first + lane < count) {
+                const int id = my_list[first + lane], mi2 = id >> 8, q2 = (id >> 6) & 3, l2 = id & 63;
+                const double* h = s_h + 9 * mi2;
+                const double* pp = wave_p + (q2 * 4) * 64 + l2;
+                const double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], pp[0], pp[64], pp[128], pp[192]);
+                const int cost = d2 < T ? (int)round(lam * (1.0 - (d2 / T))) : beyond;
+                const int n = base_n + l2 * PPL + q2;
+                if (n < N) {
+                    C[(size_t)(m0 + mi2) * ldc + n] = cost;
+                    if (d2 < thr2) atomicAdd(&s_cnt[wave][mi2], 1);
+                }
+            }
+        };
+        int nlist = 0;                           // wave-uniform
+#pragma unroll 1
+        for (int mi = 0; mi < MC; ++mi) {
+            const int m = m0 + mi;
+            if (m >= M) break;
+            const float4 ma = s_m[4 * mi], mb = s_m[4 * mi + 1], mc = s_m[4 * mi + 2], md = s_m[4 * mi + 3];
+            const float h0 = ma.x, h1 = ma.y, h2 = ma.z, h3 = ma.w, h4 = mb.x, h5 = mb.y, h6 = mb.z, h7 = mb.w, h8 = mc.x;
+            const float tau = mc.w, a25 = md.x;
+            unsigned long long nearq[PPL], any_near = 0ull;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const float s = __builtin_fmaf(h6, fx[q], __builtin_fmaf(h7, fy[q], h8));
+                const float nx = __builtin_fmaf(h0, fx[q], __builtin_fmaf(h1, fy[q], h2));
+                const float ny = __builtin_fmaf(h3, fx[q], __builtin_fmaf(h4, fy[q], h5));
+                const float wx = __builtin_fmaf(gx[q], s, -nx), wy = __builtin_fmaf(gy[q], s, -ny);
+                const float W = fmaxf(fabsf(wx), fabsf(wy));
+                nearq[q] = ~(__builtin_amdgcn_ballot_w64(fabsf(s) >= tau) &
+                             __builtin_amdgcn_ballot_w64(W >= fmaxf(vk1 * fabsf(s), a25)));
+                any_near |= nearq[q];
+            }
+            int* dst = C + (size_t)m * ldc + n0;
+            if (n0 + 3 < N) *reinterpret_cast<i4v*>(dst) = vbeyond;      // (a plain store: the line stays in L2 for the near pairs' costs)
+            else
+                for (int q = 0; q < PPL; ++q) if (n0 + q < N) dst[q] = beyond;
+            if (any_near) {
+                asm volatile("; cost32: near pairs to the list");
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if ((nearq[q] >> lane) & 1ull) {
+                        const int pos = nlist + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nearq[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nearq[q], 0u));
+                        my_list[pos] = (unsigned short)((mi << 8) | (q << 6) | lane);
+                    }
+                    nlist += __builtin_popcountll(nearq[q]);
+                }
+                if (nlist >= 64) {
+                    wave_lds_handover();         // the list is read across lanes
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the constants these pairs overwrite have landed
+                    do {
+                        nlist -= 64;
+                        evaluate(nlist, nlist + 64);
+                    } while (nlist >= 64);
+                    wave_lds_handover();         // (the next entries overwrite what was just read)
+                }
+            }
+        }
+        if (nlist > 0) {
+            wave_lds_handover();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int p0 = 0; p0 < nlist; p0 += 64) evaluate(p0, nlist);
+        }
+        wave_lds_handover();                     // (the next tile's points and list overwrite these)
+    }
+    __syncthreads();
+    if (threadIdx.x < MC && m0 + (int)threadIdx.x < M) {
+        const int t = threadIdx.x;
+        int cc = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) cc += s_cnt[w][t];
+        if (psplit == 1) counts[m0 + t] = cc;
+        else atomicAdd(&counts[m0 + t], cc);
+    }
+}
+
+template <int MC, int WAVES, bool BATCH>
 __global__ void __launch_bounds__(64 * WAVES)
 k_cost32(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
          const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
          double lam, double T, double thr2, float k1, int* __restrict__ C, long long ldc, int* __restrict__ counts, int psplit)
 {
-    cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, blockIdx.x, blockIdx.y);
+    if (BATCH) cost32_wg_batched<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, blockIdx.x, blockIdx.y);
+    else cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, blockIdx.x, blockIdx.y);
 }
 
 // The same work items walked by a resident grid that hands them out through a counter (as k_residual_resident, residual.hip).
-template <int MC, int WAVES>
+template <int MC, int WAVES, bool BATCH>
 __global__ void __launch_bounds__(64 * WAVES)
 k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
                   const double* __restrict__ y2, int N, const double* __restrict__ H, const float* __restrict__ H32, int M,
@@ -432,7 +571,8 @@ k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, 
         int bx, by;
         if (slice_major) { bx = item / psplit; by = item - bx * psplit; }
         else { by = item / gx; bx = item - by * gx; }
-        cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, bx, by);
+        if (BATCH) cost32_wg_batched<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, bx, by);
+        else cost32_wg<MC, WAVES>(x1, y1, x2, y2, N, H, H32, M, lam, T, thr2, k1, C, ldc, counts, psplit, bx, by);
         __syncthreads();
     }
     if (threadIdx.x == 0 && atomicAdd(&ctl[1], 1) == (int)gridDim.x - 1) {
@@ -442,8 +582,9 @@ k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, 
 }
 
 // H32: the table launch_model32 made for these models with the same Cmax.  thr2 in [2^-40, 2^40], coordinates below 2^20.
-hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
-                         int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major)
+template <bool BATCH>
+static hipError_t launch_cost32_t(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
+                                  int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     constexpr int MC = 32;
@@ -463,7 +604,7 @@ hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int
     if (resident_ctl) {
         // resident grid: as many workgroups as the chip holds, ~37 500 items (r04 experiment: mh_set_tuning key 23)
         static int per_cu = -1;
-        if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cost32_resident<MC, WAVES>, 64 * WAVES, 0) != hipSuccess) per_cu = 0;
+        if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cost32_resident<MC, WAVES, BATCH>, 64 * WAVES, 0) != hipSuccess) per_cu = 0;
         const int grid = per_cu * cu_count;
         int ps = psplit_override > 0 ? psplit_override : (37500 + gx - 1) / gx;
         if (ps > ntiles) ps = ntiles;
@@ -471,14 +612,24 @@ hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int
         if (grid > 0 && gx * ps > grid) {
             hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_cost32_resident<MC, WAVES>), dim3(grid), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M,
+            hipLaunchKernelGGL((k_cost32_resident<MC, WAVES, BATCH>), dim3(grid), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M,
                                100.0 / lambda, thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, ps, gx, gx * ps, resident_ctl, slice_major);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((k_cost32<MC, WAVES>), dim3(gx, psplit), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, 100.0 / lambda,
+    hipLaunchKernelGGL((k_cost32<MC, WAVES, BATCH>), dim3(gx, psplit), dim3(64 * WAVES), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, H, H32, M, 100.0 / lambda,
                        thr2 * 81.0 / 16.0, thr2, k1, C, ldc, counts, psplit);
     return hipGetLastError();
+}
+
+hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
+                         int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major,
+                         int batched)
+{
+    // batched: the experiment above (mh_set_tuning key 28) instead of the default form, in which every wave x model iteration
+    // with a near pair runs the IEEE formula at once and hands the costs to the owning lanes through LDS
+    return batched ? launch_cost32_t<true>(p, H, H32, M, lambda, thr2, Cmax, C, ldc, counts, s, resident_ctl, cu_count, psplit_override, slice_major)
+                   : launch_cost32_t<false>(p, H, H32, M, lambda, thr2, Cmax, C, ldc, counts, s, resident_ctl, cu_count, psplit_override, slice_major);
 }
 
 hipError_t launch_model32(const double* H, int M, double X, double Y, double Cmax, float* H32, hipStream_t s)

@@ -393,7 +393,7 @@ def test_resident_sweep_beside_a_prefetch_equals_the_dispatched_sweep(engine, sy
 
 
 def test_slice_major_item_order_changes_nothing(engine, synth):
-    """r04 experiment knobs (mh_set_tuning keys 26 / 27): the resident sweep and the resident cost-matrix kernel hand out
+    """r04 experiment knobs (mh_set_tuning keys 26 / 27 / 28): the resident sweep and the resident cost-matrix kernel hand out
     their items slice-major (consecutive items = the point slices of one model block).  A schedule, not a result: the
     same matrices and counts as the default order, for slice counts that do and do not divide the number of tiles."""
     sc = synth.make_scene(20011, 4, seed=29, with_neighbours=False)
@@ -416,9 +416,16 @@ def test_slice_major_item_order_changes_nothing(engine, synth):
             engine.set_tuning(23, v)
             C1, ccnt = engine.cost_matrix()
             assert np.array_equal(ccnt, ccnt_ref) and np.array_equal(C1, C_ref), v
+        engine.set_tuning(27, 0)
+        engine.set_tuning(28, 1)                   # the batched near-pair experiment: the same matrix again
+        for v in (8, 0):
+            engine.set_tuning(23, v)
+            C1, ccnt = engine.cost_matrix()
+            assert np.array_equal(ccnt, ccnt_ref) and np.array_equal(C1, C_ref), ("batched", v)
     finally:
         engine.set_tuning(26, 0)
         engine.set_tuning(27, 0)
+        engine.set_tuning(28, 0)
         engine.set_tuning(23, 8)
 
 

@@ -11,14 +11,15 @@ e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff)
 e.propose_dlt4(1234, 0, M)
 ref = None
-for v, sm in ((0, 0), (8, 0), (8, 1), (4, 1), (12, 1), (16, 1), (25, 1), (8, 0), (25, 0), (12, 1)):
+for v, sm, pm in ((8, 0, 0), (8, 0, 1), (8, 0, 0), (8, 0, 1), (0, 0, 0), (4, 0, 0), (12, 0, 0), (25, 0, 0), (8, 1, 0)):
     e.set_tuning(23, v)
     e.set_tuning(27, sm)
+    e.set_tuning(28, pm)
     _, cnt = e.cost_matrix(fetch_C=False)
     e.profile_reset(); e.profile_enable(True)
     for _ in range(6):
         e.cost_matrix(fetch_C=False, fetch_counts=False)
     e.synchronize(); n, ms = e.profile_get(6); e.profile_enable(False)
     if ref is None: ref = cnt
-    print(f"key 23 = {v:3d} key 27 (slice-major) = {sm}: {ms / n:.4f} ms  = {(4.0 * N * M) / (ms / n) / 1e6 / 8000:.4f} of the HBM peak; counts {'equal' if np.array_equal(cnt, ref) else 'DIFFERENT'}", flush=True)
+    print(f"key 23 = {v:3d} key 27 (slice-major) = {sm} key 28 (near pairs of several models batched) = {pm}: {ms / n:.4f} ms  = {(4.0 * N * M) / (ms / n) / 1e6 / 8000:.4f} of the HBM peak; counts {'equal' if np.array_equal(cnt, ref) else 'DIFFERENT'}", flush=True)
 e.close()
