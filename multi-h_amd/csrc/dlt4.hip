@@ -142,8 +142,9 @@ __device__ __forceinline__ void null9_vector(double (*W)[HPW], int hs, double g[
 #undef WE
 }
 
-// The r01-r04 form of the proposer: W staged in LDS (78 KB per workgroup, two workgroups per compute unit).  Kept as
-// variant 1 of launch_dlt4 (tuning key 25) for the comparison with the register-resident form below; same bits.
+// The r01-r04 form of the proposer: W staged in LDS (78 KB per workgroup, two workgroups per compute unit).  It is what
+// mh_prefetch_dlt4 launches (variant 1 of launch_dlt4): slower alone than the register-resident form below (0.40 against
+// 0.26 ms per 100 000 hypotheses, same bits), but the one of the two that fits beside a resident sweep (capi.hip).
 // At most 72 VGPRs: that is what the resident residual sweep leaves free on every SIMD (5 waves of 88 registers), so a
 // workgroup of this kernel fits beside it on any compute unit (residual.hip, k_residual_resident).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(72)))
@@ -361,7 +362,7 @@ k_dlt4(const double* __restrict__ x1, const double* __restrict__ y1,
        unsigned long long seed, long long first, int M, int* __restrict__ idx_out,
        double* __restrict__ H_out)
 {
-    __builtin_amdgcn_s_setprio(3);           // see k_dlt4_lds
+    __builtin_amdgcn_s_setprio(3);           // (as k_dlt4_lds; this form runs alone on the device, where it changes nothing)
     __shared__ double sN[4][9][HPW];         // column norms, then the null vector: 1.1 KB per wave
     __shared__ double sK[4][6][HPW];         // the normalisation, parked while the sweeps need the registers
     const int lane = threadIdx.x & 63;

@@ -310,7 +310,7 @@ k_residual(const double* __restrict__ x1, const double* __restrict__ y1,
 // counter).  Holding the kernel to 80 registers for a sixth wave does not work: the scalar spills need the 81st.
 template <int PPL, int MC, bool WRITE_R, bool MASK, bool NT, bool FAST, bool CALIB = false, bool HSGPR = false,
           bool SYM = false, bool CONTRACT = false, bool LEAN = false, bool TILED = false, int SF = 0, bool SEMI = true, int MINW = 1>
-__global__ void __launch_bounds__(256, MINW) __attribute__((amdgpu_num_vgpr(88)))      // 5 waves per SIMD and 72 registers left for k_dlt4
+__global__ void __launch_bounds__(256, MINW) __attribute__((amdgpu_num_vgpr(88)))      // 5 waves per SIMD and 72 registers left for k_dlt4_lds
 k_residual_resident(const double* __restrict__ x1, const double* __restrict__ y1,
                     const double* __restrict__ x2, const double* __restrict__ y2, int N,
                     const double* __restrict__ H, int M, double thr2, double* __restrict__ R,
