@@ -414,7 +414,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     // ... and the nine coefficients of the current model through the scalar unit (s_load from H, uniform address) instead
     // of LDS broadcasts into VGPRs: the twelve linear-form operations then read one operand from SGPRs; 2.5 % less energy.
     if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
-    if (variant == -1) return launch_rs<4, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
+    if (variant == -1) return launch_rs<4, 16, true, false, true, true, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // nt stores, forward coefficients through the scalar unit
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
         return launch_rs<2, 16, true, false, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);
