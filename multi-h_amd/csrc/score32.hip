@@ -408,7 +408,10 @@ cost32_wg(const double* __restrict__ x1, const double* __restrict__ y1, const do
 // when the near pairs' costs are computed but not delivered), the delivery loses more: 4.45 ms with plain stores of the
 // constant and 5.95 ms with non-temporal ones — a 4-byte store into a line that has already left L2 is a read-modify-write
 // in memory, 150 million of them per launch.  Delivering through LDS to the owning lane before ITS store (the default
-// form) needs the costs of all pending models in LDS, which the 64 KB of FP64 point copies leave no room for.  In cost32_wg every
+// form) needs the costs of all pending models in LDS, which the 64 KB of FP64 point copies leave hardly any room for: a
+// second version (up to eight models pending, their lane masks and 272 list entries in the 1 376 bytes per wave that two
+// workgroups per compute unit leave, rows written once with the costs fetched by rank in the mask) ran 4.36 ms — the
+// bookkeeping of the pending rows costs what the fuller passes save.  In cost32_wg every
 // wave x model iteration that contains a near pair (42 % of them on a DLT batch) pays a pass through the IEEE formula with,
 // typically, a few dozen of its 64 lanes at work.  Here a wave writes the constant row segment at once, appends its near
 // pairs — (model, point slot, lane) — to a list in LDS, and runs the formula only when 64 entries have gathered (and once at
