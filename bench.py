@@ -62,6 +62,8 @@ def parse():
                          "configs[3]); weak = --models per rank.  The other mode is timed too and reported alongside.")
     ap.add_argument("--cpu-sample", type=int, default=150000, help="hypotheses in the CPU baseline sample (about 13 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="N > 1: time the headline scaling mode only (a rehearsal of 8 ranks on ONE GPU "
+                    "cannot hold eight weak-scaling batches of 40 GB each)")
     ap.add_argument("--no-rehearsal", action="store_true", help="skip the one-GPU rehearsal of the strong split's shards (keeps a "
                     "profiler's per-kernel statistics to the full-size launches)")
     return ap.parse_args()
@@ -78,37 +80,46 @@ class _DevView:
 def cpu_baseline(sc, thr2: float, sample: int, seed: int, beside=None):
     """Oracle score loop (restatement of M/MultiH.cpp:430-443) on the host cores.
     Checker code used as a *reported baseline only*; never on the product path.
-    beside (optional): called in this thread while the one-core loop runs in another (the C call releases the
-    interpreter lock) — bench.py keeps the GPU stepping meanwhile and reports that as the sustained rate."""
+    The one-core figure is timed on an otherwise idle host (nothing enqueued on the GPU, no second thread).
+    beside (optional): called in this thread while a SECOND one-core pass runs in another thread (the C call releases
+    the interpreter lock) — bench.py keeps the GPU stepping meanwhile and reports that as the sustained rate; the
+    second pass's time is reported as `one_core_beside_the_gpu_loop`, never as the baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     import threading
 
     idx = O.sample4(seed, 0, sample, sc.n)
     H, _, _ = O.dlt4(sc.src, sc.dst, idx)
+    t0 = time.perf_counter()
+    c1 = O.score(sc.src, sc.dst, H, thr2)
+    t1 = time.perf_counter() - t0
     box = {}
 
-    def one_core():
+    def one_core_again():
         t0 = time.perf_counter()
-        box["c1"] = O.score(sc.src, sc.dst, H, thr2)
-        box["t1"] = time.perf_counter() - t0
+        box["c"] = O.score(sc.src, sc.dst, H, thr2)
+        box["t"] = time.perf_counter() - t0
 
-    th = threading.Thread(target=one_core)
-    th.start()
     if beside is not None:
+        th = threading.Thread(target=one_core_again)
+        th.start()
         beside(th.is_alive)
-    th.join()
-    c1, t1 = box["c1"], box["t1"]
+        th.join()
+        assert (box["c"] == c1).all()
     t0 = time.perf_counter()
     c2, threads = O.score_mt(sc.src, sc.dst, H, thr2)
     t2 = time.perf_counter() - t0
     assert (c1 == c2).all()
-    return {
+    out = {
         "value": sample / t1, "unit": "hypotheses/s", "cores": 1, "kind": "port",
         "sample": f"{sample} DLT hypotheses x {sc.n} points, oracle score loop "
-                  f"(restates M/MultiH.cpp:430-443), g++ -O2 -ffp-contract=off, {t1:.1f} s",
+                  f"(restates M/MultiH.cpp:430-443), g++ -O2 -ffp-contract=off, {t1:.1f} s on an idle host",
         "all_cores": {"value": sample / t2, "cores": threads, "seconds": t2},
-    }, H, c1
+    }
+    if "t" in box:
+        out["one_core_beside_the_gpu_loop"] = {"value": sample / box["t"], "seconds": box["t"],
+                                               "what": "the same one-core pass repeated while the GPU loop of `sustained` ran (context only)"}
+    return out, H, c1
 
 
 def labeling_extra(mh, eng, a, thr2, lam):
@@ -179,6 +190,10 @@ def full_loop_extra(a):
            "fixed_iterations": 20, "iterations_reported_by_the_class": rec["iterations"],
            "iterations_note": "GetIterationNumber() is the reference's iteration_number - 1 (M/MultiH.cpp:311): 19 after 20 LabelingSteps",
            "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
+           "ground_truth": {"what": "agreement of the labels with the generator's ground truth: a plane is recovered when one label holds >= 80 % of "
+                                    "its inlier correspondences; ARI over all correspondences (outliers a class of their own)",
+                            "planes_recovered": rec.get("planes_recovered"), "planes": rec.get("planes"), "ari": rec.get("ari"),
+                            "outliers_labelled": rec.get("outliers_labelled"), "outliers_generated": rec.get("outliers_generated")},
            "process_s": rec["total_s"], "process_s_second_call": rec.get("total_s_second_call"),
            "note": "process_s is the first Process() of a fresh process (it also pays for the HIP runtime and the code objects); "
                    "process_s_second_call is the same call repeated in that process, identical result",
@@ -186,7 +201,8 @@ def full_loop_extra(a):
     # the same with a fresh batch of proposals in EVERY iteration (PEARL re-proposal on the points left unexplained)
     rec2, err2 = run(a.models)
     out["with_reproposal"] = ({"iter_hypotheses": a.models, "clusters": rec2["clusters"], "energy": rec2["energy"],
-                               "loop_s": rec2["loop_s"], "process_s": rec2["total_s"], "digest": rec2["digest"]}
+                               "loop_s": rec2["loop_s"], "process_s": rec2["total_s"], "digest": rec2["digest"],
+                               "planes_recovered": rec2.get("planes_recovered"), "ari": rec2.get("ari")}
                               if rec2 is not None else {"error": err2})
     return out
 
@@ -408,8 +424,10 @@ def main():
     def run_sustained(keep_going, block: int = 100):
         """The pipelined step over and over while keep_going() — tens of seconds, the board in its thermal and power steady
         state — in blocks of `block` steps between host waits.  Reported beside the headline, never instead of it."""
-        M = sharding.shard_counts(a.models, world)[rank] if a.scaling == "strong" else a.models
-        first = lambda i: i * a.models
+        strong = a.scaling == "strong"
+        M = sharding.shard_counts(a.models, world)[rank] if strong else a.models
+        # this rank's RNG counters of step i (the same rule as run_mode's first_of)
+        first = lambda i: (i * a.models + sharding.shard_range(a.models, world, rank)[0]) if strong else sharding.batch_first(i, world, rank, M)
         eng.prefetch_dlt4(a.seed, first(0), M)
         eng.prefetch_dlt4(a.seed, first(1), M)
         i, t_gpu, per_block = 0, 0.0, []
@@ -441,12 +459,13 @@ def main():
         kernel_pass = run_mode(a.scaling, min(a.steps, 8), 1, pipelined=True, profile=True)
         head["res_ms"], head["dlt_ms"] = kernel_pass["res_ms"], kernel_pass["dlt_ms"]
     other = None
-    if world > 1:
+    if world > 1 and not a.no_other_mode:
         other = run_mode("weak" if a.scaling == "strong" else "strong", a.steps, a.warmup, pipelined=True, profile=False)
         ko = run_mode("weak" if a.scaling == "strong" else "strong", min(a.steps, 8), 1, pipelined=True, profile=True)
         other["res_ms"], other["dlt_ms"] = ko["res_ms"], ko["dlt_ms"]
     seq = run_mode(a.scaling, a.steps, a.warmup, pipelined=False)
     M, sizes, dt = head["M"], head["sizes"], head["dt"]
+    head_first = (sharding.shard_range(a.models, world, rank)[0] if a.scaling == "strong" else sharding.batch_first(0, world, rank, M))
     # One GPU only: the per-rank shards a strong split of this batch over 2 / 4 / 8 GPUs would hand a rank, stepped the same
     # way (no timing markers inside, 40 steps) — what the split can reach at best before any exchange between real ranks.
     shard_rehearsal = None
@@ -461,8 +480,15 @@ def main():
             shard_rehearsal["shards"].append({"ranks": ranks, "hypotheses": a.models // ranks, "ms_per_step": ms,
                                               "efficiency": ref["dt"] / 20 * 1e3 / ranks / ms})
 
-    # Outside the timed region: the store-free fused score kernel on the last batch (SURVEY §8(d)
-    # "fused score kernel: not HBM-bound"), reported next to the headline for context.
+    # Outside the timed region: the store-free fused score kernel and the s = 4 matrix (SURVEY §8(d) "fused score
+    # kernel: not HBM-bound", "also report s = 4"), reported next to the headline for context.  They are timed on a
+    # FULL batch proposed here — whatever ran last (the rehearsal's 12 500-hypothesis shard, for one) is not what
+    # stays resident — and every figure below divides by the model count READ BACK from the engine.
+    eng.propose_dlt4(a.seed, head_first, M)
+    M_res = eng.model_count
+    if M_res != M:
+        raise SystemExit(f"bench.py: {M_res} models resident where the side metrics expect this rank's batch of {M}")
+
     def time_score():
         eng.score(thr2, fetch=False)
         eng.profile_reset()
@@ -472,6 +498,7 @@ def main():
         eng.synchronize()
         n_sc, ms_sc = eng.profile_get(2)     # MH_K_SCORE
         eng.profile_enable(False)
+        assert eng.model_count == M_res
         return ms_sc / max(n_sc, 1)
 
     eng.set_tuning(15, 0)                    # the FP64 sweep for every pair (k_residual without the stores)
@@ -500,11 +527,22 @@ def main():
         eng.profile_enable(False)
     finally:
         eng.set_tuning(15, 1)
+    assert eng.model_count == M_res
     cost64_ms = ms_c64 / max(n_c64, 1)
-    cost_bytes = 4.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
+    cost_bytes = 4.0 * N * M_res + 32.0 * N + 72.0 * M_res + 4.0 * M_res
     avg_res_ms = head["res_ms"]
     alg_bytes = 8.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
     achieved = alg_bytes / (avg_res_ms * 1e-3) / 1e9
+
+    fractions = {}
+
+    def frac(name: str, value: float) -> float:
+        """Every fraction of a peak the line prints goes through here: above 1 the timed kernel did not do the work the
+        numerator states (a stale batch, a skipped launch) and the run fails instead of printing it."""
+        fractions[name] = value
+        if not (0.0 < value <= 1.0):
+            raise SystemExit(f"bench.py: {name} = {value:.4f} is not a fraction of a peak: the timed region did not do the stated work")
+        return value
 
     if rank == 0:
         total_hyp = float(sum(sizes)) * a.steps
@@ -553,31 +591,33 @@ def main():
             "sequential_form": {"what": "the same steps with the four stages in sequence on one stream (no second stream)",
                                 "value": float(sum(seq["sizes"])) * a.steps / seq["dt"], "ms_per_step": seq["dt"] / a.steps * 1e3,
                                 "step_ms_median": seq["step_ms_median"], "k_residual_ms": seq["res_ms"], "k_dlt4_ms": seq["dlt_ms"],
-                                "k_residual_frac_of_hbm_peak": alg_bytes / (seq["res_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "k_residual_frac_of_hbm_peak": frac("sequential_form.k_residual_frac_of_hbm_peak", alg_bytes / (seq["res_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS),
                                 "scores_identical": seq["scores_sha256"] == head["scores_sha256"]},
             "transport": transport_kind,
             "strong_split_rehearsal_on_one_gpu": shard_rehearsal,
-            "fused_score_hypotheses_per_s_per_gpu": M / (pretest_ms * 1e-3),
+            "fused_score_hypotheses_per_s_per_gpu": M_res / (pretest_ms * 1e-3),
             "fused_score": {"what": "mh_score on the same batch, no matrix written: FP32 pre-test with a rigorous error bound, FP64 formula only for the "
                                     "pairs it cannot decide (csrc/score32.hip); counts identical to the FP64 sweep's",
-                            "ms": pretest_ms, "ms_fp64_sweep": fused_ms, "pairs_decided_in_fp64": pre_fp64 / max(pre_pairs, 1)},
+                            "models_resident": M_res, "ms": pretest_ms, "ms_fp64_sweep": fused_ms, "pairs_decided_in_fp64": pre_fp64 / max(pre_pairs, 1)},
             # fused score kernel, FP64 sweep: FP64-issue bound.  28 rounded FP64 operations per pair (M/MultiH.cpp:434-441 with two IEEE
             # divisions sharing one refined reciprocal) against the chip's FP64 vector issue rate at its 2.4 GHz maximum
             # (256 CUs x 4 SIMDs x 16 lanes per clock = 39.3 T operations/s, i.e. the 78.6 TFLOP/s spec counting an FMA as two)
-            "fused_score_fp64": {"ops_per_pair": 28, "ops_per_s": 28.0 * N * M / (fused_ms * 1e-3),
+            "fused_score_fp64": {"models_resident": M_res, "ops_per_pair": 28, "ops_per_s": 28.0 * N * M_res / (fused_ms * 1e-3),
                                  "peak_ops_per_s_at_2.4GHz": 256 * 4 * 16 * 2.4e9,
-                                 "utilisation_vs_2.4GHz_peak": 28.0 * N * M / (fused_ms * 1e-3) / (256 * 4 * 16 * 2.4e9)},
+                                 "utilisation_vs_2.4GHz_peak": frac("fused_score_fp64.utilisation_vs_2.4GHz_peak", 28.0 * N * M_res / (fused_ms * 1e-3) / (256 * 4 * 16 * 2.4e9))},
             "cost_matrix_s4": {"what": "int32 PEARL data cost of every hypothesis against every point, materialised (mh_cost_matrix): "
                                        "the s = 4 variant of SURVEY 8(d), through the FP32 pre-test (csrc/score32.hip k_cost32: the constant for pairs "
                                        "proved beyond the truncation threshold, the reference's FP64 formula for the rest); ms_fp64_everywhere = "
                                        "the FP64 formula for every pair (k_cost_matrix: FP64-issue bound, a second IEEE division per pair)",
-                               "ms": cost_ms, "ms_fp64_everywhere": cost64_ms, "algorithmic_bytes_per_launch": cost_bytes, "GBps": cost_bytes / (cost_ms * 1e-3) / 1e9,
-                               "frac_of_hbm_peak": cost_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                               "models_resident": M_res, "ms": cost_ms, "ms_fp64_everywhere": cost64_ms, "algorithmic_bytes_per_launch": cost_bytes, "GBps": cost_bytes / (cost_ms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": frac("cost_matrix_s4.frac_of_hbm_peak", cost_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS),
+                               "frac_of_hbm_peak_fp64_everywhere": frac("cost_matrix_s4.frac_of_hbm_peak_fp64_everywhere", cost_bytes / (cost64_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": frac("roofline.frac", achieved / HBM_PEAK_GBPS), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_write_ceiling_GBps": HBM_WRITE_CEILING_GBPS,
-                         "frac_of_measured_write_ceiling": achieved / HBM_WRITE_CEILING_GBPS},
+                         "frac_of_measured_write_ceiling": achieved / HBM_WRITE_CEILING_GBPS,
+                         "models_per_launch": M},
             "best_model": head["best_model"], "best_score": head["best_score"], "scores_sha256": head["scores_sha256"],
         }
         if other is not None:

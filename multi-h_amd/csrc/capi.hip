@@ -171,6 +171,7 @@ struct mh_engine {
     int solve_grid_max = 0;                  // workgroups of the solver launch that can be resident at once (0 = not queried yet)
     double longest_barrier_wait_ms = 0.0;    // longest wait at a grid barrier any completed expansion of this engine has seen
     int last_expand_retries = 0;             // restarts of the last expansion after a barrier timeout (shared GPU)
+    long long expand_retries_total = 0;      // ... of all expansions of this engine (mh_get_expand_stats word 22)
     int last_solve_grid = 0;                 // workgroups of the solver launch in the attempt that completed
     int inject_select_failure = 0;           // test hook (key 18): the n-th scoring round of the coming greedy selections fails on this rank
     int inject_barrier_timeouts = 0;         // test hook: the next n expansions' first attempts count as timed out
@@ -290,6 +291,20 @@ int require_models(mh_engine* e)
 {
     int rc = require_points(e);
     if (rc) return rc;
+    if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
+    return MH_OK;
+}
+
+// The scoring entry points on a rank whose shard of a batch is EMPTY (a transport is installed, more ranks than
+// hypotheses): nothing to score, but the call counts — mh_select_best decides "is this a new exchange" from what has been
+// scored since the last one, and that has to come out the same on every rank (r04 advisor finding).  *empty = the call is
+// done (outputs untouched).
+int require_models_or_empty_shard(mh_engine* e, bool* empty)
+{
+    *empty = false;
+    int rc = require_points(e);
+    if (rc) return rc;
+    if (e->m <= 0 && (e->t_stream_fn || e->t_host_fn)) { *empty = true; e->counts_fresh = true; return MH_OK; }
     if (e->m <= 0) return fail(MH_ERR_NOT_SET, "model set is empty");
     return MH_OK;
 }
@@ -653,13 +668,17 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         e->last_expand_retries = 0;
         for (int attempt = 0; attempt < 5; ++attempt) {
             w.solve_grid = solve_grid;
-            // How long a barrier may wait before the launch gives up and the expansion restarts with half the workgroups: a
-            // healthy barrier takes about 8 us, so max(20 ms, 50 x the longest wait this engine has seen) tells "a workgroup
-            // is not resident" from "slow" within tens of milliseconds instead of the fixed 3 s of r03; only the last
-            // attempt (or a launch already down to one workgroup) waits the full 3 s before the call fails.
+            // How long a barrier may wait before the launch gives up and the expansion restarts: a healthy barrier takes
+            // about 8 us, so max(20 ms, 50 x the longest steady-state wait this engine has seen) tells "a workgroup is not
+            // resident" from "slow" within tens of milliseconds.  The FIRST barrier of a launch is the one that waits for
+            // every workgroup to be dispatched — on a GPU shared with another engine's 7 ms sweeps that is a matter of the
+            // other work's length, not of this launch's size: it gets 250 ms (ten times the steady limit if that is more).
+            // A timed-out attempt is repeated ONCE with the same grid before the grid is halved; only the last attempt (or
+            // a launch already down to one workgroup) waits the full 3 s before the call fails.
             const bool last_attempt = attempt == 4 || solve_grid == 1;
-            w.barrier_timeout_ticks = last_attempt ? 300000000ll
-                                                   : (long long)(std::max(20.0, 50.0 * e->longest_barrier_wait_ms) * 1e5);
+            const double steady_ms = std::max(20.0, 50.0 * e->longest_barrier_wait_ms);
+            w.barrier_timeout_ticks = last_attempt ? 300000000ll : (long long)(steady_ms * 1e5);
+            w.barrier_first_timeout_ticks = last_attempt ? 300000000ll : (long long)(std::max(250.0, 10.0 * steady_ms) * 1e5);
             if (w.saved_flow) HIPCHK(hipMemsetAsync(e->ew_saved.p, 0, sizeof(int) * recycle_words, e->stream));
             HIPCHK(launch_init_labeling(e->cost.p, e->cost_L, e->n, init_dev, w.label, w.cur_cost, e->stream));
             he = run_expansion(g, e->cost.p, e->cost_L, potts, w, 1000, &st, e->stream);
@@ -672,8 +691,9 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
             }
             e->last_solve_grid = solve_grid;
             if (!timed_out || solve_grid == 1 || attempt == 4) break;
-            solve_grid = std::max(1, solve_grid / 2);
+            if (attempt >= 1) solve_grid = std::max(1, solve_grid / 2);      // (the first retry keeps the grid)
             ++e->last_expand_retries;
+            ++e->expand_retries_total;
         }
         if (he == hipErrorOutOfMemory)
             return fail(MH_ERR_INVALID, "alpha-expansion: more sites than the solver's per-row state holds (about 1.3 million at 256 workgroups)");
@@ -1514,8 +1534,9 @@ int mh_set_residual_mode(mh_engine* e, int mode)
 int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* counts)
 {
     return guarded([&]() -> int {
-    int rc = require_models(e);
-    if (rc) return rc;
+    bool empty_shard = false;
+    int rc = require_models_or_empty_shard(e, &empty_shard);
+    if (rc || empty_shard) return rc;
     HIPCHK(reserve_counts(e, (size_t)e->m + 1));
     const unsigned char* dmask = nullptr;
     if (point_mask) {
@@ -1541,8 +1562,9 @@ int mh_score(mh_engine* e, double thr2, const unsigned char* point_mask, int* co
 int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
 {
     return guarded([&]() -> int {
-    int rc = require_models(e);
-    if (rc) return rc;
+    bool empty_shard = false;
+    int rc = require_models_or_empty_shard(e, &empty_shard);
+    if (rc || empty_shard) return rc;
     e->ldr = residual_ld(e->n);
     size_t r_elems = (size_t)e->m * (size_t)e->ldr;
 #ifdef MH_TUNING
@@ -1597,8 +1619,9 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
 int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
 {
     return guarded([&]() -> int {
-    int rc = require_models(e);
-    if (rc) return rc;
+    bool empty_shard = false;
+    int rc = require_models_or_empty_shard(e, &empty_shard);
+    if (rc || empty_shard) return rc;
     e->ldc = cost_ld(e->n);
     HIPCHK(e->C.reserve((size_t)e->m * (size_t)e->ldc));
     HIPCHK(reserve_counts(e, (size_t)e->m + 1));
@@ -1952,43 +1975,62 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
     if (total_m <= 0) total_m = e->m;
     const int base = (int)(total_m / world), rem = (int)(total_m % world);
     const int longest = base + (rem ? 1 : 0);
-    if (e->m != base + (rank < rem ? 1 : 0)) return fail(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
     HIPCHK(e->best_key.reserve(1));
     if (!e->h_best) {
         HIPCHK(hipHostMalloc((void**)&e->h_best, sizeof(int) * 4, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_best_dev, e->h_best, 0));
-        e->h_best[0] = e->h_best[1] = e->h_best[2] = 0;
+        e->h_best[0] = e->h_best[1] = e->h_best[2] = e->h_best[3] = 0;
         HIPCHK(hipMemsetAsync(e->best_key.p, 0, sizeof(unsigned long long), e->stream));
     }
     hipStream_t s = e->stream;
     const bool fetch = best_index || best_count;
-    if (!e->counts_fresh && e->m > 0) {
-        // nothing has been scored since the last call: that call's result is the answer ("a later call with outputs
-        // completes it"); without one there is nothing to select from
-        if (e->best_seq == 0 || e->best_models_seq != e->models_seq) return fail(MH_ERR_NOT_SET, "the batch has not been scored (mh_residual_matrix / mh_score / mh_cost_matrix)");
-        if (fetch) {
-            rc = quiesce(e);
-            if (rc) return rc;
-            if (e->h_best[2] != e->best_seq) return fail(MH_ERR_HIP, "best-model result is stale");
-            if (best_index) *best_index = e->h_best[1];
-            if (best_count) *best_count = e->h_best[0];
-        }
+    auto result = [&]() -> int {
+        if (e->h_best[2] != e->best_seq) return fail(MH_ERR_HIP, "best-model result is stale");
+        if (e->h_best[3] != 0) return fail(MH_ERR_HIP, "mh_select_best: a rank reported an error");     // (every rank reads the same word)
+        if (best_index) *best_index = e->h_best[1];
+        if (best_count) *best_count = e->h_best[0];
         return MH_OK;
+    };
+    // Is this call a NEW exchange?  Decided from state that is the same on every rank (r04 advisor finding: a rank with an
+    // empty shard must not run a collective its peers skip): the model-set generation the last exchange belongs to, and
+    // whether anything has been scored since — a scoring call on an empty shard is a no-op that still counts
+    // (require_models_or_empty_shard), so ranks that make the same calls agree.
+    const bool same_generation = e->best_seq != 0 && e->best_models_seq == e->models_seq;
+    if (same_generation && !e->counts_fresh) {
+        // nothing has been scored since the last call: that call's result is the answer ("a later call with outputs
+        // completes it")
+        if (!fetch) return MH_OK;
+        rc = quiesce(e);
+        if (rc) return rc;
+        return result();
     }
+    // Rank-local failures do not leave before the collective (their peers would wait in it for ever): the rank sends error
+    // markers instead of scores — every rank's arg-max launch sees them and every rank's fetch fails.
+    int local_rc = MH_OK;
+    const char* local_msg = "";
+    if (e->m != base + (rank < rem ? 1 : 0)) { local_rc = MH_ERR_INVALID; local_msg = "the resident model set is not this rank's shard of total_m hypotheses"; }
+    else if (e->m > 0 && !e->counts_fresh) { local_rc = MH_ERR_NOT_SET; local_msg = "the batch has not been scored (mh_residual_matrix / mh_score / mh_cost_matrix)"; }
+    if (local_rc != MH_OK && !sharded) return fail(local_rc, local_msg);
+    if (local_rc != MH_OK) {
+        HIPCHK(reserve_counts(e, (size_t)std::max(longest, e->m) + 1));
+        if (longest > 0) HIPCHK(hipMemsetAsync(e->counts.p, 0xfe, sizeof(int) * (size_t)longest, s));     // 0xfefefefe < -1: the error marker
+        e->counts_zeroed = false;
+    }
+    const int mine = local_rc != MH_OK ? longest : e->m;           // valid entries at the head of this rank's send buffer
     if (e->t_host_fn) {
-        // host-synchronised transport: the r03 sequence on the main stream
+        // host-synchronised transport: everything on the main stream
         rc = join_xchg(e);
         if (rc) return rc;
-        HIPCHK(e->sel_scores.reserve((size_t)longest));
-        HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
-        HIPCHK(launch_pad_scores(e->counts.p, e->m, longest, e->sel_scores.p, s));
+        HIPCHK(e->sel_scores.reserve((size_t)std::max(longest, 1)));
+        HIPCHK(e->sel_gathered.reserve((size_t)world * std::max(longest, 1)));
+        HIPCHK(launch_pad_scores(e->counts.p, mine, longest, e->sel_scores.p, s));
         rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, s);     // north_star's all-gather
         if (rc) return rc;
-        HIPCHK(launch_sel_argmax_gathered(e->sel_gathered.p, world, longest, base, rem, e->best_key.p, s));
-        HIPCHK(launch_best_publish(e->best_key.p, e->h_best_dev, s));
+        HIPCHK(launch_best_fused(e->sel_gathered.p, world, longest, base, rem, e->h_best_dev, nullptr, 0, s));
         ++e->best_seq;
         e->best_models_seq = e->models_seq;
-        if (fetch) HIPCHK(hipStreamSynchronize(s));
+        e->counts_fresh = false;                                   // (a later call without a scoring call in between is a completion, on every rank)
+        if (fetch || local_rc != MH_OK) HIPCHK(hipStreamSynchronize(s));
     } else {
         rc = ensure_xchg_stream(e);
         if (rc) return rc;
@@ -1999,15 +2041,16 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
                 if (rc) return rc;
                 HIPCHK(e->sel_gathered.reserve((size_t)world * longest));
             }
-            if (longest > e->m)                                    // a shard one shorter than the longest: its padding element (every
-                HIPCHK(hipMemsetAsync(e->counts.p + e->m, 0xff, sizeof(int) * (size_t)(longest - e->m), s));   // counts buffer holds m + 1 ints)
+            if (longest > mine)                                    // a shard one shorter than the longest: its padding element (every
+                HIPCHK(hipMemsetAsync(e->counts.p + mine, 0xff, sizeof(int) * (size_t)(longest - mine), s));   // counts buffer holds m + 1 ints)
         }
         HIPCHK(hipEventRecord(e->ev_sweep, s));                    // the sweep (and whatever else the main stream holds) up to here
         HIPCHK(hipStreamWaitEvent(x, e->ev_sweep, 0));
         // enqueue-only: this batch's counts buffer comes back to the main stream two calls from now — cleared by the same
         // launch that reads it, so that the sweep that then writes it needs no memset of its own on the main stream
-        int* clear = fetch ? nullptr : e->counts.p;
-        const int clear_count = fetch ? 0 : (int)e->counts.cap;       // (all of it: the next batch it serves may be larger)
+        const bool rotate = !fetch && local_rc == MH_OK;
+        int* clear = rotate ? e->counts.p : nullptr;
+        const int clear_count = rotate ? (int)e->counts.cap : 0;     // (all of it: the next batch it serves may be larger)
         if (sharded) {
             rc = exchange(e, e->counts.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, x);      // north_star's all-gather
             if (rc) return rc;
@@ -2021,28 +2064,26 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
         e->xchg_pending = true;
         ++e->best_seq;
         e->best_models_seq = e->models_seq;
-        if (fetch) {
+        if (!rotate) {
             HIPCHK(hipStreamSynchronize(x));
             e->xchg_pending = false;
+            e->counts_fresh = false;                               // this exchange is done; without a new scoring call the next call returns its result
         } else {
             // this batch's counts stay with the exchange; the next sweep writes the buffer that has waited longest — once the
             // exchange that was given THAT one (two calls ago) is through
-            DevBuf<int> mine = e->counts;
+            DevBuf<int> given = e->counts;
             const int wait = e->counts_alt_wait[0];
             e->counts = e->counts_alt[0];
             e->counts_zeroed = e->counts_zeroed_alt[0];
             e->counts_alt[0] = e->counts_alt[1]; e->counts_zeroed_alt[0] = e->counts_zeroed_alt[1]; e->counts_alt_wait[0] = e->counts_alt_wait[1];
-            e->counts_alt[1] = mine; e->counts_zeroed_alt[1] = true; e->counts_alt_wait[1] = par;      // (clear once ev_x[par] has passed)
+            e->counts_alt[1] = given; e->counts_zeroed_alt[1] = true; e->counts_alt_wait[1] = par;      // (clear once ev_x[par] has passed)
             e->counts_fresh = false;
             HIPCHK(reserve_counts(e, (size_t)e->m + 1));
             if (wait >= 0) HIPCHK(hipStreamWaitEvent(s, e->ev_x[wait], 0));
         }
     }
-    if (fetch) {
-        if (e->h_best[2] != e->best_seq) return fail(MH_ERR_HIP, "best-model result is stale");
-        if (best_index) *best_index = e->h_best[1];
-        if (best_count) *best_count = e->h_best[0];
-    }
+    if (local_rc != MH_OK) return fail(local_rc, local_msg);       // (the peers have this rank's markers by now)
+    if (fetch) return result();
     return MH_OK;
     });
 }
@@ -2226,7 +2267,7 @@ int mh_get_expand_stats(mh_engine* e, long long stats[24])
     stats[19] = (long long)(x.tail_ms * 1000.0);
     stats[20] = e->last_expand_retries;
     stats[21] = e->last_solve_grid;
-    stats[22] = 0;
+    stats[22] = e->expand_retries_total;
     stats[23] = (long long)(e->last_expand.max_barrier_wait_ms * 1e3);
     return MH_OK;
     });

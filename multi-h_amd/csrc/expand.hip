@@ -436,7 +436,7 @@ constexpr int SOLVE_THREADS = 512;
 constexpr int SOLVE_ROWS = SOLVE_THREADS / SLPN;
 constexpr int H_SHIFT = 24, H_MASK = (1 << H_SHIFT) - 1, H_EPOCHS = 126;   // height word = (H_EPOCHS - epoch) << 24 | height
 
-struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer, cascade_iters; unsigned long long barrier_timeout; };
+struct SolveParams { int reduce_rounds, relax_rounds, push_cycles, push_phases, push_mult, max_outer, cascade_iters; unsigned long long barrier_timeout, barrier_first_timeout; };
 
 // Grid barrier with reductions, two levels: the workgroups of one XCD meet on a line of their own, the last
 // arriver of each XCD carries the XCD's reductions to the top line and arrives there, everybody polls the top
@@ -450,6 +450,8 @@ struct GridBarrier {
     unsigned seq;        // barriers passed on the two-level counters
     unsigned long long ticks;
     unsigned long long timeout;      // 100 MHz ticks a poll may last before the launch gives up (a workgroup is not resident)
+    unsigned long long timeout_first;   // ... at the FIRST barrier of a launch, which waits for every workgroup to become resident: on a
+                                        // shared GPU a delayed dispatch is not a missing workgroup (r04 advisor finding)
     unsigned long long max_wait;     // longest poll of this workgroup's leader so far
 };
 
@@ -479,7 +481,7 @@ __device__ __forceinline__ bool grid_sync_first(GridBarrier& b)
         atomicAdd(&b.flags[C_XCD + b.xcd * C_LINE], 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         atomicAdd(&b.flags[C_ARRIVE], 1);
-        if (!spin_until(&b.flags[C_ARRIVE], b.P, b.flags, b.timeout)) b.s_red[6] = 1;
+        if (!spin_until(&b.flags[C_ARRIVE], b.P, b.flags, b.timeout_first)) b.s_red[6] = 1;
         int used = 0;
         for (int x = 0; x < 8; ++x) used += LD(&b.flags[C_XCD + x * C_LINE]) > 0 ? 1 : 0;
         b.s_red[3] = used;
@@ -542,19 +544,20 @@ __device__ __forceinline__ bool grid_sync(GridBarrier& b, bool c_changed, bool c
         u64 v = 0;
         int hm = 0;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        const u64 limit = b.seq == 0 ? b.timeout_first : b.timeout;          // (launches of at most 32 workgroups meet here first)
         int abort = 0;
         for (;;) {
             v = LD(&ts[slot]);
             hm = LD(&top[10 + slot]);
             if ((int)(v & 0xffffull) >= target) break;
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > b.timeout) {         // a workgroup of this launch is not resident
+            if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {             // a workgroup of this launch is not resident
                 atomicExch(&b.flags[C_ERROR], ERR_BARRIER_TIMEOUT);
                 abort = 1;
                 break;
             }
         }
-        { const u64 waited = __builtin_amdgcn_s_memrealtime() - t0; if (waited > b.max_wait) b.max_wait = waited; }
+        { const u64 waited = __builtin_amdgcn_s_memrealtime() - t0; if (b.seq != 0 && waited > b.max_wait) b.max_wait = waited; }    // (steady-state waits only)
         b.s_red[3] = (int)((v >> 16) & 0xffffull);
         b.s_red[4] = (int)(v >> 32);
         b.s_red[5] = hm;
@@ -597,7 +600,7 @@ solve_body(const Graph& g, int t, int* cap, int* sent, int* excess, int* sink_ca
     const int INF = K + 1;                           // no residual path in the core is longer than K
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
-    GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull, sp.barrier_timeout, 0ull };
+    GridBarrier bar{ flags, s_red, P, xcc, 1, 1, 0u, 0ull, sp.barrier_timeout, sp.barrier_first_timeout, 0ull };
     long long st_outer = 0, st_relax = 0, st_push = 0;
     unsigned long long tk_relax = 0, tk_push = 0, tk_tail = 0;
     long long st_tail = 0;                           // relabel/push rounds that began with fewer than 64 active rows
@@ -1359,7 +1362,8 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     energy = w.h_acc[A_ENERGY];
 
     SolveParams sp{ w.reduce_rounds, w.relax_rounds, w.push_cycles, w.push_phases, w.push_mult > 0 ? w.push_mult : 1, 1 << 20, w.cascade_iters,
-                    w.barrier_timeout_ticks > 0 ? (unsigned long long)w.barrier_timeout_ticks : 300000000ull };
+                    w.barrier_timeout_ticks > 0 ? (unsigned long long)w.barrier_timeout_ticks : 300000000ull,
+                    w.barrier_first_timeout_ticks > 0 ? (unsigned long long)w.barrier_first_timeout_ticks : 300000000ull };
     int solve_grid = w.solve_grid > 0 ? w.solve_grid : 128;
     // slots per solver row for a core of all n sites, and the LDS that holds their scalars
     const int mslots = std::max(1, (g.n + solve_grid * SOLVE_ROWS - 1) / (solve_grid * SOLVE_ROWS));

@@ -171,6 +171,7 @@ struct ExpandWork {         // scratch owned by the engine
     // 100 MHz ticks a poll at a grid barrier may last before the launch gives up (a workgroup of it is not resident: a GPU
     // shared with other persistent launches); 0 = 3 s
     long long barrier_timeout_ticks = 0;
+    long long barrier_first_timeout_ticks = 0;     // the launch's first barrier (residency of all its workgroups)
     // diagnostic (expand.hip, k_core_components): 16 ints per move for the first comp_moves moves; scratch 2 n ints
     int* comp_out = nullptr;
     int* comp_scratch = nullptr;
@@ -229,7 +230,7 @@ hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world
                             hipStream_t s);
 hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_record, int need, int* h_rec_dev, hipStream_t s);
 hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s);
-hipError_t launch_best_fused(const int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,
+hipError_t launch_best_fused(int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,
                              int clear_count, hipStream_t s);
 hipError_t launch_pad_scores(const int* counts, int m, int longest, int* scores, hipStream_t s);
 

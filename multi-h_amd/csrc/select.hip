@@ -201,28 +201,35 @@ __global__ void k_best_publish(unsigned long long* __restrict__ key, int* __rest
 // hypothesis r * base + min(r, rem) + j) —, the three words for the host, then `clear` (nullable; may be `scores` itself)
 // is zeroed for the sweep after next.
 __global__ void __launch_bounds__(1024)
-k_best_fused(const int* __restrict__ scores, int world, int longest, int base, int rem, int* __restrict__ h_best,
-             int* __restrict__ clear, int clear_count)
+k_best_fused(int* scores, int world, int longest, int base, int rem, int* __restrict__ h_best, int* clear, int clear_count)
 {
+    // (`scores` and `clear` may be the same buffer — no __restrict__ on either; every score is read before the barrier,
+    // nothing is cleared before it.)  An entry below -1 is a rank's ERROR MARKER (mh_select_best: a rank-local failure
+    // travels through the collective instead of leaving it): word 3 tells every rank's host.
     const int total = world * longest;
     unsigned long long k = 0;
+    int err = 0;
     for (int c = threadIdx.x; c < total; c += 1024) {
         const int v = scores[c];
-        if (v < 0) continue;
+        if (v < 0) { err |= v < -1 ? 1 : 0; continue; }
         const int r = world > 1 ? c / longest : 0, j = c - r * longest;
         const unsigned long long kk = sel_key(v, (unsigned int)(r * base + (r < rem ? r : rem) + j));
         k = kk > k ? kk : k;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(k, m, 64); k = o > k ? o : k; }
+    err = __ballot(err != 0) != 0ull ? 1 : 0;
     __shared__ unsigned long long s_k[16];
-    if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = k;
+    __shared__ int s_err[16];
+    if ((threadIdx.x & 63) == 0) { s_k[threadIdx.x >> 6] = k; s_err[threadIdx.x >> 6] = err; }
     __syncthreads();                                  // (also: every score has been read before anything is cleared)
     if (threadIdx.x == 0) {
         unsigned long long b = 0;
-        for (int w = 0; w < 16; ++w) b = s_k[w] > b ? s_k[w] : b;
+        int any = 0;
+        for (int w = 0; w < 16; ++w) { b = s_k[w] > b ? s_k[w] : b; any |= s_err[w]; }
         h_best[0] = b ? (int)(b >> 32) : -1;
         h_best[1] = (int)(0xffffffffu - (unsigned int)(b & 0xffffffffull));
+        h_best[3] = any;
         h_best[2] += 1;                               // sequence number: the host can tell a fresh result from an old one
     }
     if (clear) for (int c = threadIdx.x; c < clear_count; c += 1024) clear[c] = 0;
@@ -321,7 +328,7 @@ hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_best_fused(const int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,
+hipError_t launch_best_fused(int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,
                              int clear_count, hipStream_t s)
 {
     hipLaunchKernelGGL(k_best_fused, dim3(1), dim3(1024), 0, s, scores, world, longest, base, rem, h_best_dev, clear, clear_count);

@@ -585,6 +585,14 @@ void MultiH::ClusterMergingAndLabeling()
                                mv, tr[8 * mv], tr[8 * mv + 1], tr[8 * mv + 2], tr[8 * mv + 3], tr[8 * mv + 4], tr[8 * mv + 5],
                                tr[8 * mv + 6] * 1e-5);
         }
+        {
+            // a labeling that ran on a cut-down solver grid (barrier timeouts on a shared GPU) is not silent: same
+            // labels, but slower — say so whenever it happens
+            long long st[24] = {};
+            if (labelled && mh_get_expand_stats(engine, st) == MH_OK && st[20] > 0)
+                printf("[Multi-H] iteration %d: the alpha-expansion's solver launch was restarted %lld time(s) after a grid-barrier "
+                       "timeout and ran on %lld workgroups (is the GPU shared?)\n", iteration_number, st[20], st[21]);
+        }
         if (!labelled) break;
         if (log_to_console)
             printf("Iteration %d.   Number of clusters = %d   Energy = %f\n", iteration_number,

@@ -90,9 +90,91 @@ def knn_hits(src: np.ndarray, dst: np.ndarray, k: int, symmetric: bool) -> tuple
     return rowptr, cols.astype(np.int32)
 
 
+_PLANE_CACHE: dict = {}
+
+
+def _plane_homography(K, Kinv, R, t, nrm, d):
+    Hk = K @ (R + np.outer(t, nrm) / d) @ Kinv
+    return (Hk / Hk[2, 2]).reshape(9)
+
+
+def _feature6(H9: np.ndarray) -> np.ndarray:
+    """The reference's 6-D merge feature: the images of (0,0), (1,0), (0,1) (M/MultiH.cpp:364-390)."""
+    h = H9
+    return np.array([h[2] / h[8], h[5] / h[8], (h[0] + h[2]) / (h[6] + h[8]), (h[3] + h[5]) / (h[6] + h[8]),
+                     (h[1] + h[2]) / (h[7] + h[8]), (h[4] + h[5]) / (h[7] + h[8])])
+
+
+def _separated_planes(rng, n_planes: int, seeds: np.ndarray, K, Kinv, R, t, sep: float, feat_sep: float) -> np.ndarray:
+    """K plane homographies of ONE relative pose that are distinguishable where they are observed: every point of the
+    Voronoi cell of plane k is transferred at least `sep` pixels away by every other plane's homography (and the other
+    way round), and the 6-D merge features of any two planes differ by at least `feat_sep` in L1.  Without this the
+    scene is K planes in name only: with normals and depths drawn independently, 40-90 % of a plane's correspondences
+    lie within the reference's truncation threshold (4.95 px) of ANOTHER plane's homography, and PEARL's labeling
+    cannot (and, with the reference's data cost growing towards the threshold, M/MultiH.cpp:501-502, will not) keep the
+    planes apart — tools/plane_trace.py, profiles/r05_plane_trace_*.txt.  Rejection sampling on a 41 x 41 grid of image 1;
+    deterministic in rng."""
+    g = np.stack(np.meshgrid(np.linspace(0.0, IMG, 41), np.linspace(0.0, IMG, 41)), -1).reshape(-1, 2)
+    reg = np.argmin(((g[:, None, :] - seeds[None, :, :]) ** 2).sum(-1), axis=1)
+    gh = np.concatenate([g, np.ones((g.shape[0], 1))], axis=1)
+    B = 128                                               # candidates per draw
+
+    def transfer(Hs):                                     # [b, 9] -> [b, G, 2]
+        p = np.einsum("bij,gj->bgi", Hs.reshape(-1, 3, 3), gh)
+        return p[..., :2] / p[..., 2:3]
+
+    def features(Hs):                                     # [b, 9] -> [b, 6]
+        return np.stack([_feature6(h) for h in Hs])
+
+    def draw(b):
+        nrm = np.stack([rng.uniform(-0.6, 0.6, b), rng.uniform(-0.6, 0.6, b), np.ones(b)], axis=1)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        d = 1.0 / rng.uniform(1.0 / 12.0, 1.0 / 2.5, b)  # uniform in inverse depth = uniform in parallax
+        return np.stack([_plane_homography(K, Kinv, R, t, nrm[i], d[i]) for i in range(b)])
+
+    def conflicts(k, ct, cf, H_t, H_f):
+        """[b, n_planes] — does candidate i for slot k collide with plane l?"""
+        out = np.zeros((ct.shape[0], n_planes), dtype=bool)
+        for l in range(n_planes):
+            if l == k:
+                continue
+            bad = np.abs(cf - H_f[l]).sum(1) < feat_sep
+            m = (reg == k) | (reg == l)
+            if m.any():
+                bad |= np.sqrt(((ct[:, m, :] - H_t[l][m]) ** 2).sum(-1)).min(axis=1) < sep
+            out[:, l] = bad
+        return out
+
+    # min-conflicts search: start from any K planes, then redraw one colliding plane at a time, keeping the candidate
+    # that collides with the fewest others (a greedy one-after-the-other placement gets stuck on the last planes)
+    H = draw(n_planes)
+    H_t, H_f = transfer(H), features(H)
+    C = np.zeros((n_planes, n_planes), dtype=bool)
+    for k in range(n_planes):
+        C[k] = conflicts(k, H_t[k:k + 1], H_f[k:k + 1], H_t, H_f)[0]
+    C |= C.T
+    for _ in range(4000):
+        bad = np.flatnonzero(C.any(axis=1))
+        if bad.size == 0:
+            return H
+        k = int(bad[rng.integers(bad.size)])
+        cand = draw(B)
+        ct, cf = transfer(cand), features(cand)
+        cc = conflicts(k, ct, cf, H_t, H_f)
+        i = int(np.argmin(cc.sum(axis=1)))
+        if cc[i].sum() <= C[k].sum():
+            H[k], H_t[k], H_f[k] = cand[i], ct[i], cf[i]
+            C[k, :] = cc[i]
+            C[:, k] = cc[i]
+    raise RuntimeError(f"make_scene: no set of {n_planes} planes {sep} px apart found")
+
+
 def make_scene(n_points: int, n_planes: int, seed: int = 1234, outlier_frac: float = 0.25,
                noise: float = 0.5, knn: int = 16, symmetric: bool = True,
-               with_neighbours: bool = True) -> Scene:
+               with_neighbours: bool = True, legacy_r04: bool = False,
+               plane_separation: float = 8.0, feature_separation: float = 15.0) -> Scene:
+    """legacy_r04: the generator as it stood until round 4 (normals and depths of the planes drawn independently of
+    each other — planes that cannot be told apart inside the truncation threshold, see _separated_planes)."""
     rng = np.random.default_rng(seed)
     K = np.array([[1000.0, 0, 500.0], [0, 1000.0, 500.0], [0, 0, 1.0]])
     Kinv = np.linalg.inv(K)
@@ -104,16 +186,26 @@ def make_scene(n_points: int, n_planes: int, seed: int = 1234, outlier_frac: flo
     e2h = K @ t
     e2 = e2h[:2] / e2h[2]
 
-    H_true = np.zeros((n_planes, 9))
-    for k in range(n_planes):
-        nrm = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), 1.0])
-        nrm /= np.linalg.norm(nrm)
-        d = rng.uniform(4.0, 9.0)
-        Hk = K @ (R + np.outer(t, nrm) / d) @ Kinv
-        H_true[k] = (Hk / Hk[2, 2]).reshape(9)
+    if legacy_r04:
+        H_true = np.zeros((n_planes, 9))
+        for k in range(n_planes):
+            nrm = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), 1.0])
+            nrm /= np.linalg.norm(nrm)
+            d = rng.uniform(4.0, 9.0)
+            H_true[k] = _plane_homography(K, Kinv, R, t, nrm, d)
+        src = rng.uniform(0.0, IMG, size=(n_points, 2))
+        seeds = rng.uniform(0.0, IMG, size=(n_planes, 2))
+    else:
+        seeds = rng.uniform(0.0, IMG, size=(n_planes, 2))
+        # the planes come from a generator of their own: the number of rejected candidates does not move the other draws,
+        # and the set is remembered per (seed, planes, separations) — the search takes seconds for ten planes
+        key = (seed, n_planes, float(plane_separation), float(feature_separation))
+        if key not in _PLANE_CACHE:
+            _PLANE_CACHE[key] = _separated_planes(np.random.default_rng([seed, 0x9E3779B9]), n_planes, seeds, K, Kinv, R, t,
+                                                  plane_separation, feature_separation)
+        H_true = _PLANE_CACHE[key].copy()
+        src = rng.uniform(0.0, IMG, size=(n_points, 2))
 
-    src = rng.uniform(0.0, IMG, size=(n_points, 2))
-    seeds = rng.uniform(0.0, IMG, size=(n_planes, 2))
     region = np.argmin(((src[:, None, :] - seeds[None, :, :]) ** 2).sum(-1), axis=1).astype(np.int32)
     dst = np.empty_like(src)
     aff = np.empty((n_points, 4))
@@ -137,3 +229,39 @@ def make_scene(n_points: int, n_planes: int, seed: int = 1234, outlier_frac: flo
         rowptr, col = np.zeros(n_points + 1, dtype=np.int32), np.zeros(0, dtype=np.int32)
     return Scene(src=src, dst=dst, aff=aff, gt_label=gt, H_true=H_true,
                  F=F.reshape(9).copy(), e2=e2.copy(), hit_rowptr=rowptr, hit_col=col)
+
+
+def adjusted_rand_index(a: np.ndarray, b: np.ndarray) -> float:
+    """Adjusted Rand index of two labelings (Hubert & Arabie), plain numpy."""
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    _, ai = np.unique(a, return_inverse=True)
+    _, bi = np.unique(b, return_inverse=True)
+    table = np.zeros((ai.max() + 1, bi.max() + 1), dtype=np.int64)
+    np.add.at(table, (ai, bi), 1)
+    c2 = lambda x: x.astype(np.float64) * (x.astype(np.float64) - 1.0) / 2.0
+    s_ij, s_a, s_b, total = c2(table).sum(), c2(table.sum(1)).sum(), c2(table.sum(0)).sum(), c2(np.array([a.size]))[0]
+    expected = s_a * s_b / total if total > 0 else 0.0
+    denom = 0.5 * (s_a + s_b) - expected
+    return float((s_ij - expected) / denom) if denom != 0 else 1.0
+
+
+def agreement(gt_label: np.ndarray, labels: np.ndarray, share: float = 0.8) -> dict:
+    """Result quality against the generator's ground truth: planes recovered (one label holds >= `share` of the plane's
+    inlier correspondences, and no label is counted for two planes), ARI over all correspondences with the outliers as a
+    class of their own, outliers labelled vs generated."""
+    gt_label, labels = np.asarray(gt_label), np.asarray(labels)
+    planes = int(gt_label.max()) + 1 if gt_label.size else 0
+    taken, recovered = set(), 0
+    for p in range(planes):
+        ip = np.flatnonzero(gt_label == p)
+        lp = labels[ip]
+        lp = lp[lp >= 0]
+        if lp.size == 0:
+            continue
+        cnt = np.bincount(lp)
+        best = int(np.argmax(cnt))
+        if cnt[best] >= share * ip.size and best not in taken:
+            taken.add(best)
+            recovered += 1
+    return {"planes_recovered": recovered, "planes": planes, "ari": adjusted_rand_index(gt_label, labels),
+            "outliers_labelled": int((labels < 0).sum()), "outliers_generated": int((gt_label < 0).sum())}

@@ -39,3 +39,30 @@ def test_a_rank_local_failure_ends_the_selection_on_every_rank():
     assert "shard" in r1["wrong_shard"]["msg"] and r1["wrong_shard"]["code"] == -2
     assert "forward" in r0["symmetric"]["msg"] and r0["symmetric"]["code"] == -2
     assert r0["clean_again"] == r0["clean"] and r1["clean_again"] == r1["clean"]
+
+
+def test_select_best_with_an_empty_shard_and_rank_local_failures():
+    """r04 advisor finding (medium): whether an mh_select_best call is a new exchange must come out the same on every
+    rank.  With total_m < world the last rank's shard is empty; enqueue-only followed by a fetch (twice) must run ONE
+    all-gather on every rank (a second one on the empty rank alone would wait for ever: the timeout below), also when
+    that rank skips the scoring call; the same models scored again are a second exchange everywhere.  A shard-size
+    mismatch and an unscored batch travel through the collective as error markers: every rank fails, none hangs."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "sharded_select_best_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in recs] == [0, 1]
+    r0, r1 = recs
+    for name in ("empty_shard", "empty_shard_unscored", "rescored", "full", "full_again"):
+        assert r0[name]["ok"] and r1[name]["ok"], (name, r0[name], r1[name])
+        assert r0[name]["result"] == r1[name]["result"], name
+    assert r0["empty_shard"]["result"][0] == 0                       # the only hypothesis of the batch
+    assert r0["exchanges_empty_shard"] == r1["exchanges_empty_shard"] == 1
+    assert r0["exchanges_rescored"] == r1["exchanges_rescored"] == 2
+    assert r0["full"]["result"] == r0["full_again"]["result"]
+    assert not r0["wrong_shard"]["ok"] and not r1["wrong_shard"]["ok"]
+    assert "shard" in r1["wrong_shard"]["msg"] and r1["wrong_shard"]["code"] == -2
+    assert "a rank reported an error" in r0["wrong_shard"]["msg"]
+    assert not r0["unscored"]["ok"] and not r1["unscored"]["ok"]
+    assert "not been scored" in r0["unscored"]["msg"] and "a rank reported an error" in r1["unscored"]["msg"]

@@ -43,14 +43,19 @@ def test_configs3_strong_split_over_ranks_equals_the_single_rank_batch():
     assert one["n_gpus"] == 1 and one["scaling"] == "strong"
     assert one["config"]["points"] == 50000 and one["config"]["models_per_step"] == 100000
     assert one["roofline"]["traffic_source"] is None or "profiles/" in one["roofline"]["traffic_source"]
-    for world in (2, 3):                                   # 3: a ragged split (33 334 / 33 333 / 33 333)
-        got = _bench(world)
+    # 3: a ragged split (33 334 / 33 333 / 33 333); 8: configs[3]'s own split, 12 500 hypotheses (5 GB of R) per rank, eight
+    # processes on the one GPU — the partition, counters, gather and selection of the 8-GPU run, minus RCCL and the wire
+    for world in (2, 3, 8):
+        got = _bench(world, *(["--no-other-mode"] if world == 8 else []))      # (eight weak-scaling batches of 40 GB do not fit one GPU)
         assert got["n_gpus"] == world and got["scaling"] == "strong"
         assert "configs[3]" in got["config"]["workload"]
         assert got["config"]["models_per_step"] == 100000
         # same counters -> same hypotheses -> the gathered score vector is the single-rank one, bit for bit
         assert got["scores_sha256"] == one["scores_sha256"]
         assert (got["best_model"], got["best_score"]) == (one["best_model"], one["best_score"])
+        if world == 8:
+            assert got["config"]["models_rank0"] == 12500 and "weak_scaling" not in got
+            continue
         weak = got["weak_scaling"]
         assert weak["models_per_step"] == 100000 * world and weak["value"] > 0
 

@@ -80,18 +80,17 @@ if world > 1:
     walls = [None] * world; digs = [None] * world
     dist.all_gather_object(walls, wall); dist.all_gather_object(digs, digest)
     wall = max(walls); same = len(set(digs)) == 1
-agree = 0
-for p in range(K):
-    lp = labels[sc.gt_label == p]; lp = lp[lp >= 0]
-    if lp.size: agree += np.bincount(lp).max()
+# Agreement with the generator's ground truth: a plane counts as RECOVERED when one label holds at least
+# 80 % of its inlier correspondences; ARI over all correspondences (outliers = one class of their own, label -1)
+quality = mh.synth.agreement(sc.gt_label, labels)
 if rank == 0:
     print(f"N={N} planes={K} hypotheses={HYP} gpus={world}: clusters={k} iterations={it.value} energy={en.value:.0f} "
-          f"loop={secs.value:.2f}s total={wall:.2f}s  inlier-agreement={agree/(sc.gt_label>=0).sum():.3f} "
-          f"outliers labelled -1: {(labels[sc.gt_label<0]==-1).mean():.3f}")
+          f"loop={secs.value:.2f}s total={wall:.2f}s  planes recovered {quality['planes_recovered']}/{K}  ARI {quality['ari']:.3f}  "
+          f"outliers labelled {quality['outliers_labelled']} (generated {quality['outliers_generated']})")
     print(json.dumps({"workload": "full_loop", "points": N, "planes": K, "hypotheses": HYP, "iterations": it.value,
                       "iter_hypotheses": ITER_HYP, "n_gpus": world, "clusters": k, "energy": en.value,
                       "loop_s": secs.value, "total_s": wall, "total_s_second_call": wall_warm, "digest": digest, "ranks_identical": same,
-                      "exchanges": hook.stats["calls"] if hook else 0}))
+                      "exchanges": hook.stats["calls"] if hook else 0, **quality}))
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if (k >= 0 and same) else 1)
