@@ -327,7 +327,9 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * DPP for mh_propose_dlt4, the LDS-staged form, whose 72 registers fit beside a resident sweep, for mh_prefetch_dlt4; 1: the
  * LDS-staged form everywhere; 2: the register form everywhere; same bits), 26 experiment: the resident residual sweep takes its items slice-major with this
  * many point slices (0, default: model block fastest, ~37 500 items), 27 the same order for the resident cost-matrix kernel,
- * 28 experiment: the cost-matrix kernel evaluates the near pairs of several models together (same matrix; slower) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * 28 experiment: the cost-matrix kernel evaluates the near pairs of several models together (same matrix; slower) — schedule only,
+ * 29 mean shift: once at most this many climbs of a batch are still running they run to their end in one persistent launch
+ * (default 16; 0 = a launch per iteration throughout) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

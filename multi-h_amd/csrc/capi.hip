@@ -153,7 +153,11 @@ struct mh_engine {
     // reference-style initialisation
     DevBuf<double> loc_H, loc_feat, ms_data, ms_mean;
     DevBuf<int> ms_votes, ms_out, ms_list, ms_pcnt, ms_heads, ms_tickets;
-    DevBuf<double> ms_partial;
+    DevBuf<double> ms_partial, ms_partial2;
+    DevBuf<int> ms_ctl, ms_pcnt2;            // the persistent tail of a mean-shift batch (meanshift.hip, k_ms_persist)
+    int ms_persist_per_cu = -1;              // workgroups of k_ms_persist a compute unit holds (-1: not queried; a failed query is not kept)
+    int tune_ms_persist = 16;                // key 29: the tail runs persistently once at most this many climbs are left (0 = never)
+    long long ms_persist_launches = 0, ms_persist_fallbacks = 0, ms_rounds = 0;
 
     // labeling
     int cost_L = 0;
@@ -1307,6 +1311,9 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     if (!e->h_ms_list) HIPCHK(hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * MS_LIST_PREFIX * B, hipHostMallocDefault));
     HIPCHK(e->ms_heads.reserve((size_t)B * 2 * MS_LIST_PREFIX));
     HIPCHK(e->ms_tickets.reserve((size_t)B));
+    HIPCHK(e->ms_ctl.reserve((size_t)3 * B));
+    HIPCHK(e->ms_partial2.reserve((size_t)B * 2 * 64 * 16));
+    HIPCHK(e->ms_pcnt2.reserve((size_t)B * 2 * 64));
     HIPCHK(hipMemsetAsync(e->ms_tickets.p, 0, sizeof(int) * (size_t)B, e->stream));
     int* const starts = reinterpret_cast<int*>(e->h_ms + B);
     const int* const starts_dev = reinterpret_cast<const int*>(e->h_ms_dev + B);
@@ -1350,14 +1357,39 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         MeanShiftActive active{};
         int n_active = climbs;
         for (int b = 0; b < climbs; ++b) active.climb[b] = (unsigned char)b;
+        // r05: once few climbs are left they run to their end in ONE launch (k_ms_persist) instead of a launch per iteration
+        // and a host round trip every few; a climb whose workgroups do not all become resident (a shared GPU) comes back
+        // untouched, and the call goes on with launched rounds.
+        bool persist_ok = e->tune_ms_persist > 0;
+        int iters_seen[B];
+        for (int b = 0; b < climbs; ++b) iters_seen[b] = 0;
         for (int round = 0; round < 20000 && n_active > 0; ++round) {     // rounds of device-side iterations
-            HIPCHK(launch_ms_climb(w, active, n_active, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
-                                   e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->ms_tickets.p, e->stream));
+            int G = 0;
+            if (persist_ok && round > 0 && n_active <= e->tune_ms_persist) {
+                if (e->ms_persist_per_cu < 0) { const int q = ms_persist_occupancy(); if (q > 0) e->ms_persist_per_cu = q; }
+                const int room = std::max(0, e->ms_persist_per_cu) * e->cu_count * 3 / 4;      // workgroups that are resident for sure
+                G = 64;
+                while (G > 1 && G * n_active > room) G /= 2;
+                if (G < 16 || G * n_active > room) G = 0;
+            }
+            ++e->ms_rounds;
+            if (G > 0) {
+                HIPCHK(launch_ms_persist(w, active, n_active, G, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
+                                         e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream));
+                ++e->ms_persist_launches;
+            } else {
+                HIPCHK(launch_ms_climb(w, active, n_active, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
+                                       e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->ms_tickets.p, e->stream));
+            }
             HIPCHK(hipStreamSynchronize(e->stream));
             int still = 0;
             for (int a = 0; a < n_active; ++a) {
                 const int b = active.climb[a];
-                if (!e->h_ms[b].out[1] && !e->h_ms[b].out[3]) active.climb[still++] = (unsigned char)b;
+                if (!e->h_ms[b].out[1] && !e->h_ms[b].out[3]) {
+                    if (G > 0 && e->h_ms[b].out[0] == iters_seen[b]) { persist_ok = false; ++e->ms_persist_fallbacks; }   // its gate closed
+                    active.climb[still++] = (unsigned char)b;
+                }
+                iters_seen[b] = e->h_ms[b].out[0];
             }
             n_active = still;
         }
@@ -1730,10 +1762,10 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     int local_rc = MH_OK;
     std::string local_msg;
     auto local_failure = [&](int code, const std::string& msg) { if (local_rc == MH_OK) { local_rc = code; local_msg = msg; } };
-    if (e->residual_mode == MH_RESIDUAL_SYMMETRIC)
-        local_failure(MH_ERR_INVALID, "the greedy selection scores and claims with the forward transfer error (the reference's); "
-                                      "switch back to MH_RESIDUAL_FORWARD for it");
-    else if (!sharded && M <= 0) local_failure(MH_ERR_NOT_SET, "model set is empty");
+    // r05: the selection follows the engine's residual mode — scores (score_models) and claims (k_sel_claim) both on the
+    // symmetric transfer error when that is set; the ranks of a sharded batch must agree (their records carry the mode)
+    const int symmetric = e->residual_mode == MH_RESIDUAL_SYMMETRIC ? 1 : 0;
+    if (!sharded && M <= 0) local_failure(MH_ERR_NOT_SET, "model set is empty");
     else if (M != mine) local_failure(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
     if (local_rc != MH_OK && !sharded) return fail(local_rc, local_msg);
     if (local_rc != MH_OK) M = 0;
@@ -1811,7 +1843,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         const int local_err = local_rc != MH_OK ? 1 : 0;
         const bool gather_scores = sharded && first && longest > 0;      // north_star's exchange, once per batch
         HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, my_off, key_local, gather_scores ? e->sel_scores.p : nullptr, s));
-        HIPCHK(launch_sel_record(e->sel_counts.p, orig, Hs, Mc, my_off, key_local, local_err, my_record, s));
+        HIPCHK(launch_sel_record(e->sel_counts.p, orig, Hs, Mc, my_off, key_local, local_err, symmetric, my_record, s));
         if (sharded) {
             if (gather_scores) {
                 rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, s);
@@ -1824,13 +1856,15 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, records, world, my_off, e->sel_orig[cur ^ 1].p,
                                   e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, s));
         HIPCHK(launch_sel_claim(e->pts(), records, world, gather_scores && !local_err ? key_check : nullptr, thr2, need, e->mask.p, e->sel_rec.p,
-                                e->sel_out_H.p, e->sel_counter.p, max_models, s));
+                                e->sel_out_H.p, e->sel_counter.p, max_models, s, symmetric));
         HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, my_record, need, e->h_sel_dev, s));
         HIPCHK(hipStreamSynchronize(s));                 // five control words through mapped memory: no copy
         if (local_rc != MH_OK) return fail(local_rc, local_msg);     // (the others have read this rank's error word by now)
         if (e->h_sel[4] != 0)                            // every rank sees the same word, so every rank leaves here
-            return fail(MH_ERR_HIP, e->h_sel[4] == 2 ? "greedy selection: the gathered score vector and the ranks' records disagree about the winner"
-                                                      : "greedy selection: a rank reported an error");
+            return fail(e->h_sel[4] == 3 ? MH_ERR_INVALID : MH_ERR_HIP,
+                        e->h_sel[4] == 2 ? "greedy selection: the gathered score vector and the ranks' records disagree about the winner"
+                        : e->h_sel[4] == 3 ? "greedy selection: the ranks are not in the same residual mode (mh_set_residual_mode)"
+                                           : "greedy selection: a rank reported an error");
         const int best = e->h_sel[0];
         if (best < need) break;
         if (counts_out) counts_out[selected] = best;
@@ -2436,6 +2470,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
+    if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }       // mean shift: persistent tail below this many climbs (0 = off)
     if (key == 8 && value >= 0 && value <= (1 << 20)) { e->trace_moves = value; return MH_OK; }
     if (key == 9 && value >= -1) { e->detail_move = value; return MH_OK; }
     if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }

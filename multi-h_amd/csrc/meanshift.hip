@@ -163,6 +163,187 @@ k_ms_iterate(MeanShiftWork all, MeanShiftActive active, int groups, double band_
     }
 }
 
+// ---- the tail of a batch without a launch per iteration (r05) ------------------------------------------------------
+// After a round or two of k_ms_iterate most of a batch's 256 climbs have ended; the one to sixteen that have not take
+// dozens to hundreds of iterations, and at one launch (about 15 us) per iteration plus a host round trip every few of
+// them they were most of mh_mean_shift's time.  k_ms_persist runs those climbs to their end in ONE
+// launch: G workgroups per climb (G a power of two, at most the 64 groups of the definition; workgroup g plays the
+// groups g, g + G, ...), a barrier per climb and iteration on a counter of the climb's own, and EVERY workgroup adds the
+// partials in group order and forms the new mean for itself — the same operations in the same order as the ticket
+// holder of k_ms_iterate, so nothing has to be handed back before the next sweep.  Partials are double-buffered by
+// iteration parity (a workgroup can be one barrier ahead of another, never two).  Same bits: a group's member sums are
+// the same strided sums and the same tree.
+// Residency: the barrier needs all G workgroups of a climb on the chip.  The first thing a workgroup does — before it
+// touches any state — is to arrive on the climb's gate word and wait there; a workgroup that waits longer than
+// `gate_timeout` closes the gate (one atomic on the same word decides between "everybody was there" and "closed"),
+// every workgroup of the climb leaves, and the host goes on with launched iterations (a GPU shared with other work).
+struct MeanShiftPersist {
+    int* gate;               // [climb] arrivals | closed bit; zero on entry
+    int* arrive;             // [climb] monotonic arrival counter of the iteration barriers; zero on entry
+    double* partial2;        // [climb][2][MS_GROUPS][16]
+    int* partial_cnt2;       // [climb][2][MS_GROUPS]
+    int* fell_back;          // [climb] set when the gate closed (the climb's state is untouched)
+};
+constexpr int MS_GATE_CLOSED = 1 << 30;
+
+__global__ void __launch_bounds__(256)
+k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int groups, int G, double band_sq, double stop_thresh,
+             int max_iters, unsigned long long gate_timeout)
+{
+    const int climb = active.climb[blockIdx.y];
+    const MeanShiftWork w = ms_climb(all, climb);
+    if (w.out[1] || w.out[3]) return;                       // (every workgroup of the climb reads the same words)
+    const int t = threadIdx.x;
+    const int D = w.d;
+    const int T = MS_GROUPS * 256;
+    __shared__ double sv[MS_MAXD][256];
+    __shared__ int sc[256];
+    __shared__ int s_flag, s_in, s_conv;
+    __shared__ double s_mean[MS_MAXD], s_move[MS_MAXD];
+
+    // ---- the gate ----
+    // One word: arrivals in the low bits, MS_GATE_CLOSED on top.  A workgroup arrives with a compare-and-swap that refuses a
+    // closed gate, so arrivals never grow once the bit is set: (G arrivals, bit or no bit) = everybody was there before
+    // anybody gave up -> open for all; (fewer than G, bit) -> closed for all.
+    if (t == 0) {
+        int* gate = ps.gate + climb;
+        int v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            if (v & MS_GATE_CLOSED) break;
+            const int seen = atomicCAS(gate, v, v + 1);
+            if (seen == v) { v = v + 1; break; }
+            v = seen;
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+        while ((v & (MS_GATE_CLOSED - 1)) < G && !(v & MS_GATE_CLOSED)) {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > gate_timeout) { v = atomicOr(gate, MS_GATE_CLOSED) | MS_GATE_CLOSED; break; }
+        }
+        s_flag = ((v & (MS_GATE_CLOSED - 1)) >= G) ? 1 : 0;
+        if (!s_flag) __hip_atomic_store(ps.fell_back + climb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_flag) return;
+
+    if (t < MS_MAXD) s_mean[t] = t < D ? w.mean[t] : 0.0;
+    __syncthreads();
+    double old[MS_MAXD], acc[MS_MAXD];
+#pragma unroll
+    for (int j = 0; j < MS_MAXD; ++j) old[j] = s_mean[j];
+    int* arrive = ps.arrive + climb;
+    int iters = 0, converged = 0, dead = 0;
+    for (int it = 0; it < max_iters; ++it) {
+        double* part = ps.partial2 + ((size_t)climb * 2 + (it & 1)) * MS_GROUPS * MS_MAXD;
+        int* pcnt = ps.partial_cnt2 + ((size_t)climb * 2 + (it & 1)) * MS_GROUPS;
+        for (int b = blockIdx.x; b < groups; b += G) {      // the groups this workgroup plays
+#pragma unroll
+            for (int j = 0; j < MS_MAXD; ++j) acc[j] = 0.0;
+            int cnt = 0;
+            for (int i = b * 256 + t; i < w.n; i += T) {
+                const double* row = w.data + (size_t)i * D;
+                double dist = 0.0;
+                bool plain = true;
+                double a[MS_MAXD];
+#pragma unroll
+                for (int j = 0; j < MS_MAXD; ++j) {
+                    a[j] = j < D ? fabs(old[j] - row[j]) : 0.0;
+                    plain = plain && (a[j] <= 0x1p500) && (a[j] >= 0x1p-500 || a[j] == 0.0);
+                }
+                if (__builtin_expect(plain, 1)) {
+#pragma unroll
+                    for (int j = 0; j < MS_MAXD; ++j) if (j < D) dist += a[j];
+                } else {
+                    asm volatile("; mean shift: sqrt path");
+                    for (int j = 0; j < D; ++j) { const double r = old[j] - row[j]; dist += sqrt(r * r); }
+                }
+                if (dist < band_sq) {
+                    for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
+                    ++cnt;
+                    w.votes[i] += 1;
+                }
+            }
+            auto put_sum = [&](int j, double v) {
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(part) + (size_t)b * MS_MAXD + j,
+                                   (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            if (__syncthreads_or(cnt) == 0) {
+                if (t < D) put_sum(t, 0.0);
+                if (t == 0) __hip_atomic_store(pcnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (int j = 0; j < MS_MAXD; ++j) sv[j][t] = acc[j];
+                sc[t] = cnt;
+                __syncthreads();
+                for (int s = 128; s >= 1; s >>= 1) {
+                    if (t < s) {
+                        for (int j = 0; j < D; ++j) sv[j][t] = sv[j][t] + sv[j][t + s];
+                        sc[t] += sc[t + s];
+                    }
+                    __syncthreads();
+                }
+                if (t < D) put_sum(t, sv[t][0]);
+                if (t == 0) __hip_atomic_store(pcnt + b, sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                // (sv / sc are reused by the next group)
+        }
+        // ---- the climb's barrier: my partials have landed, then everybody's ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            atomicAdd(arrive, 1);
+            const int target = G * (it + 1);
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        // ---- every workgroup forms the new mean for itself (the ticket holder's arithmetic) ----
+        if (t < 64) {
+            int in = 0;
+#pragma unroll
+            for (int b = 0; b < MS_GROUPS; ++b) {
+                const int c = b < groups ? __hip_atomic_load(pcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                in += c;
+            }
+            if (t == 0) s_in = in;
+            if (t < D && in != 0) {
+                double s = 0.0;
+#pragma unroll
+                for (int b = 0; b < MS_GROUPS; ++b) {
+                    const double v = b < groups ? __longlong_as_double((long long)__hip_atomic_load(
+                                         reinterpret_cast<const unsigned long long*>(part) + (size_t)b * MS_MAXD + t, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+                    s = s + v;
+                }
+                const double m = s * (1.0 / (double)in);
+                const double dd = m - s_mean[t];            // (the mean this iteration started from: thread t is its only writer)
+                s_move[t] = dd * dd;
+                s_mean[t] = m;
+            }
+        }
+        __syncthreads();
+        if (s_in == 0) { dead = 1; break; }
+        if (t == 0) {
+            double move = 0.0;
+            for (int q = 0; q < D; ++q) move = move + s_move[q];
+            s_conv = sqrt(move) < stop_thresh ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MS_MAXD; ++j) old[j] = s_mean[j];
+        ++iters;
+        converged = s_conv;
+        __syncthreads();                                    // (s_in / s_mean / s_conv are rewritten by the next iteration)
+        if (converged) break;
+    }
+    if (blockIdx.x == 0) {                                  // one workgroup writes the climb's state back
+        if (t < D) w.mean[t] = s_mean[t];
+        if (t == 0) {
+            w.out[0] += iters;
+            if (converged) w.out[1] = 1;
+            if (dead) w.out[3] = 1;
+        }
+    }
+}
+
 // (index, votes) of every row touched by the climb (the host sorts the short list); clears the votes.
 __global__ void __launch_bounds__(256)
 k_ms_collect(MeanShiftWork all)
@@ -240,6 +421,33 @@ hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active
     hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
     hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
     return hipGetLastError();
+}
+
+// The climbs active[0..n_active) to their end (or `max_iters` iterations) in one launch, G workgroups each; then compact /
+// publish as launch_ms_climb does.  ctl: 3 x MS_BATCH ints (gate, arrive, fell_back), cleared here.
+hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, int G, double band_sq, double stop_thresh,
+                             int max_iters, int* ctl, double* partial2, int* partial_cnt2, MeanShiftResultBlock* result_dev,
+                             int* heads_dev, int list_prefix, hipStream_t s)
+{
+    if (w.d > MS_MAXD || n_active < 1 || n_active > MS_BATCH || G < 1 || G > MS_GROUPS || (G & (G - 1))) return hipErrorInvalidValue;
+    const int groups = std::min(MS_GROUPS, (w.n + 255) / 256);
+    if (G > groups) { G = 1; while (G * 2 <= groups) G *= 2; }
+    hipError_t he = hipMemsetAsync(ctl, 0, sizeof(int) * 3 * MS_BATCH, s);
+    if (he != hipSuccess) return he;
+    MeanShiftPersist ps{ ctl, ctl + MS_BATCH, partial2, partial_cnt2, ctl + 2 * MS_BATCH };
+    hipLaunchKernelGGL(k_ms_persist, dim3(G, n_active), dim3(256), 0, s, w, active, ps, groups, G, band_sq, stop_thresh, max_iters,
+                       25000000ull /* 250 ms at 100 MHz */);
+    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
+    hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
+    return hipGetLastError();
+}
+
+// workgroups of k_ms_persist a compute unit holds (0: the query failed — not cached by the caller)
+int ms_persist_occupancy()
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist, 256, 0) != hipSuccess) return 0;
+    return per_cu;
 }
 
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s)

@@ -122,6 +122,14 @@ struct MeanShiftActive { unsigned char climb[MS_BATCH]; };       // the climbs a
 hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev, double band_sq,
                            double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix,
                            int* tickets /* MS_BATCH ints, zero */, hipStream_t s);
+// r05: the same for the FEW climbs that are still running after the first rounds — to their end (or max_iters) in one
+// launch, G workgroups per climb with a barrier of the climb's own per iteration (meanshift.hip, k_ms_persist); a climb
+// whose workgroups were not all resident within 250 ms leaves untouched with fell_back (ctl[2 * MS_BATCH + climb]) set.
+// ctl: 3 x MS_BATCH ints; partial2: MS_BATCH x 2 x 64 x 16 doubles; partial_cnt2: MS_BATCH x 2 x 64 ints.
+hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, int G, double band_sq, double stop_thresh,
+                             int max_iters, int* ctl, double* partial2, int* partial_cnt2, MeanShiftResultBlock* result_dev,
+                             int* heads_dev, int list_prefix, hipStream_t s);
+int ms_persist_occupancy();
 // compacts and clears the votes of all `climbs` climbs, ended or not
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s);
 
@@ -215,19 +223,19 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 hipError_t launch_sel_pack_points(const Points& p, const unsigned char* mask, double* cx1, double* cy1, double* cx2, double* cy2,
                                   int* count, hipStream_t s);
 // one rank's offer in a round of the greedy selection: 88 bytes, the unit of the sharded exchange
-struct SelRecord { unsigned long long key; double H[9]; int err; int pad; };
+struct SelRecord { unsigned long long key; double H[9]; int err; int mode; };      // mode: the rank's residual mode (must agree)
 static_assert(sizeof(SelRecord) == 88, "the exchanged record is 88 bytes");
 hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned int my_off, unsigned long long* key,
                              int* scores_full, hipStream_t s);
 hipError_t launch_sel_argmax_gathered(const int* gathered, int world, int longest, int base, int rem, unsigned long long* key,
                                       hipStream_t s);
 hipError_t launch_sel_record(const int* counts, const int* orig, const double* Hs, int Mc, unsigned int my_off,
-                             const unsigned long long* key_local, int err, SelRecord* record, hipStream_t s);
+                             const unsigned long long* key_local, int err, int mode, SelRecord* record, hipStream_t s);
 hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need, const SelRecord* records,
                               int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, hipStream_t s);
 hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
-                            hipStream_t s);
+                            hipStream_t s, int symmetric = 0);
 hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_record, int need, int* h_rec_dev, hipStream_t s);
 hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s);
 hipError_t launch_best_fused(int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,

@@ -80,11 +80,11 @@ k_sel_argmax_gathered(const int* __restrict__ gathered, int world, int longest, 
 // This rank's offer: the candidate whose key is the rank's best.  `record` must have been cleared (key 0 = no offer).
 __global__ void __launch_bounds__(256)
 k_sel_record(const int* __restrict__ counts, const int* __restrict__ orig, const double* __restrict__ Hs, int Mc,
-             unsigned int my_off, const unsigned long long* __restrict__ key_local, int err, SelRecord* __restrict__ record)
+             unsigned int my_off, const unsigned long long* __restrict__ key_local, int err, int mode, SelRecord* __restrict__ record)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const unsigned long long kl = *key_local;
-    if (c == 0) record->err = err;
+    if (c == 0) { record->err = err; record->mode = mode; }
     if (c >= Mc || !kl) return;
     const int o = orig ? orig[c] : c;
     if (sel_key(counts[c], my_off + (unsigned int)o) != kl) return;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256)
 k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
             const double* __restrict__ y2, int N, const SelRecord* __restrict__ records, int world,
             const unsigned long long* __restrict__ key_check, double thr2, int need, unsigned char* __restrict__ mask,
-            int* __restrict__ rec, double* __restrict__ sel_H, long long* __restrict__ sel_counter, int max_models)
+            int* __restrict__ rec, double* __restrict__ sel_H, long long* __restrict__ sel_counter, int max_models, int symmetric)
 {
     int wr = 0;
     const unsigned long long kg = sel_winner(records, world, &wr);
@@ -155,6 +155,7 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
         int err = 0;
         for (int r = 0; r < world; ++r) if (records[r].err) err = records[r].err;
         if (key_check && *key_check != kg) err = 2;
+        for (int r = 1; r < world; ++r) if (records[r].mode != records[0].mode) err = 3;      // forward on one rank, symmetric on another
         if (err) rec[4] = err;
     }
     if (!kg || best < need) return;
@@ -166,7 +167,15 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
         sel_counter[sel] = (long long)pos;
     }
     if (n >= N || !mask[n]) return;
-    const double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
+    double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
+    if (symmetric) {
+        // + the backward transfer through adj(H), every entry (mul, mul, sub) — the arithmetic of the scoring kernel's
+        // symmetric mode (residual.hip), so the points that leave are the points that were counted
+        const double a0 = h[4] * h[8] - h[5] * h[7], a1 = h[2] * h[7] - h[1] * h[8], a2 = h[1] * h[5] - h[2] * h[4];
+        const double a3 = h[5] * h[6] - h[3] * h[8], a4 = h[0] * h[8] - h[2] * h[6], a5 = h[2] * h[3] - h[0] * h[5];
+        const double a6 = h[3] * h[7] - h[4] * h[6], a7 = h[1] * h[6] - h[0] * h[7], a8 = h[0] * h[4] - h[1] * h[3];
+        d2 = d2 + fwd_d2(a0, a1, a2, a3, a4, a5, a6, a7, a8, x2[n], y2[n], x1[n], y1[n]);
+    }
     if (d2 < thr2) mask[n] = 0;
 }
 
@@ -291,10 +300,10 @@ hipError_t launch_sel_argmax_gathered(const int* gathered, int world, int longes
 }
 
 hipError_t launch_sel_record(const int* counts, const int* orig, const double* Hs, int Mc, unsigned int my_off,
-                             const unsigned long long* key_local, int err, SelRecord* record, hipStream_t s)
+                             const unsigned long long* key_local, int err, int mode, SelRecord* record, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sel_record, dim3(Mc > 0 ? (Mc + 255) / 256 : 1), dim3(256), 0, s, counts, orig, Hs, Mc, my_off, key_local,
-                       err, record);
+                       err, mode, record);
     return hipGetLastError();
 }
 
@@ -309,10 +318,10 @@ hipError_t launch_sel_compact(const int* counts, const int* orig, const double* 
 
 hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
-                            hipStream_t s)
+                            hipStream_t s, int symmetric)
 {
     hipLaunchKernelGGL(k_sel_claim, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, records, world,
-                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models);
+                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models, symmetric);
     return hipGetLastError();
 }
 

@@ -119,6 +119,25 @@ MHO_API void mho_score(const double* x1, const double* y1, const double* x2,
     }
 }
 
+// The same count on the SYMMETRIC transfer error (north_star's wording; no reference counterpart, so this restatement of
+// the definition  d2 = ||H p1 - p2||^2 + ||adj(H) p2 - p1||^2  is the checker; tests/test_gpu_symmetric.py also checks the
+// definition itself in exact rationals).
+MHO_API void mho_score_sym(const double* x1, const double* y1, const double* x2, const double* y2, int N, const double* H,
+                           int M, double thr2, const unsigned char* mask, int* counts)
+{
+    for (int m = 0; m < M; ++m) {
+        const double* h = H + 9 * (size_t)m;
+        double a[9];
+        adjugate(h, a);
+        int c = 0;
+        for (int n = 0; n < N; ++n) {
+            if (mask && !mask[n]) continue;
+            if (fwd_d2(h, x1[n], y1[n], x2[n], y2[n]) + fwd_d2(a, x2[n], y2[n], x1[n], y1[n]) < thr2) ++c;
+        }
+        counts[m] = c;
+    }
+}
+
 // Same loop, OpenMP over models: the "best-effort CPU" baseline B2 of BASELINE.md
 // (the reference's own loop is serial, M/MultiH.cpp:415-466).  Returns threads used.
 MHO_API int mho_score_mt(const double* x1, const double* y1, const double* x2,
@@ -1835,10 +1854,30 @@ MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1,
 // Sequential best-first selection over a fixed hypothesis list.  Per round: inlier counts over the points still in the
 // support set (strict d2 < thr2, the score of :430-443); the best count wins, the LOWEST hypothesis index on ties; stop
 // when the best count is below `need`; the winner's inliers leave the support set.  mask: in/out (1 = in the set).
+static int select_greedy_impl(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                              const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
+                              double* H_out, long long* index_out, int* counts_out, bool symmetric);
+
 MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* x2, const double* y2, int N,
                               const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
                               double* H_out /* max_models*9 */, long long* index_out, int* counts_out)
 {
+    return select_greedy_impl(x1, y1, x2, y2, N, H, M, thr2, need, max_models, mask, H_out, index_out, counts_out, false);
+}
+
+// ... on the symmetric transfer error (scores and claims both)
+MHO_API int mho_select_greedy_sym(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                                  const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
+                                  double* H_out /* max_models*9 */, long long* index_out, int* counts_out)
+{
+    return select_greedy_impl(x1, y1, x2, y2, N, H, M, thr2, need, max_models, mask, H_out, index_out, counts_out, true);
+}
+
+static int select_greedy_impl(const double* x1, const double* y1, const double* x2, const double* y2, int N,
+                              const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
+                              double* H_out, long long* index_out, int* counts_out, bool symmetric)
+{
+    auto score = symmetric ? mho_score_sym : mho_score;
     int selected = 0;
     std::vector<int> counts(M);
     for (int round = 0; round < max_models; ++round) {
@@ -1847,9 +1886,9 @@ MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* 
         // configs[4] size, 100 000 x 50 000 pairs per round, one core would need 8.5 s per round
         if ((long long)M * N >= 100000000ll) {
 #pragma omp parallel for schedule(static)
-            for (int m = 0; m < M; ++m) mho_score(x1, y1, x2, y2, N, H + 9 * (size_t)m, 1, thr2, mask, &counts[m]);
+            for (int m = 0; m < M; ++m) score(x1, y1, x2, y2, N, H + 9 * (size_t)m, 1, thr2, mask, &counts[m]);
         } else
-            mho_score(x1, y1, x2, y2, N, H, M, thr2, mask, counts.data());
+            score(x1, y1, x2, y2, N, H, M, thr2, mask, counts.data());
         int best = -1, bm = -1;
         for (int m = 0; m < M; ++m) if (counts[m] > best) { best = counts[m]; bm = m; }
         if (bm < 0 || best < need) break;
@@ -1858,8 +1897,14 @@ MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* 
         if (index_out) index_out[selected] = bm;
         if (counts_out) counts_out[selected] = best;
         ++selected;
-        for (int i = 0; i < N; ++i)
-            if (mask[i] && fwd_d2(h, x1[i], y1[i], x2[i], y2[i]) < thr2) mask[i] = 0;
+        double a[9];
+        adjugate(h, a);
+        for (int i = 0; i < N; ++i) {
+            if (!mask[i]) continue;
+            const double d2 = symmetric ? fwd_d2(h, x1[i], y1[i], x2[i], y2[i]) + fwd_d2(a, x2[i], y2[i], x1[i], y1[i])
+                                        : fwd_d2(h, x1[i], y1[i], x2[i], y2[i]);
+            if (d2 < thr2) mask[i] = 0;
+        }
     }
     return selected;
 }

@@ -96,6 +96,19 @@ def score(src, dst, H, thr2, mask=None):
     return cnt
 
 
+def score_sym(src, dst, H, thr2, mask=None):
+    """Inlier counts on the symmetric transfer error (mho_score_sym)."""
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    cnt = np.empty(H.shape[0], dtype=np.int32)
+    mp = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        mp = mask.ctypes.data_as(C.POINTER(C.c_ubyte))
+    lib().mho_score_sym(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], C.c_double(thr2), mp, _i(cnt))
+    return cnt
+
+
 def score_mt(src, dst, H, thr2):
     x1, y1, x2, y2 = soa(src, dst)
     H = f64(H).reshape(-1, 9)
@@ -336,18 +349,19 @@ def cluster_merging_and_labeling(src, dst, aff, H0, F, e2, lam, thr_h, rowptr, c
     return lab, H[:k].copy(), int(it.value), float(en.value), hook is not None
 
 
-def select_greedy(src, dst, H, thr2, need, max_models, mask=None):
+def select_greedy(src, dst, H, thr2, need, max_models, mask=None, symmetric=False):
     """The oracle's sequential best-first selection (oracle/mh_oracle.cpp section 12).  Returns
-    (H_selected, hypothesis indices, counts, mask_out)."""
+    (H_selected, hypothesis indices, counts, mask_out).  symmetric: scores and claims on the symmetric transfer error."""
     x1, y1, x2, y2 = soa(src, dst)
     H = f64(H).reshape(-1, 9)
     m = np.ones(x1.size, np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).copy()
     Hs = np.zeros((max_models, 9))
     idx = np.zeros(max_models, np.int64)
     cnt = np.zeros(max_models, np.int32)
-    k = lib().mho_select_greedy(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], C.c_double(thr2), int(need),
-                                int(max_models), m.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(Hs),
-                                idx.ctypes.data_as(C.POINTER(C.c_longlong)), _i(cnt))
+    fn = lib().mho_select_greedy_sym if symmetric else lib().mho_select_greedy
+    k = fn(_d(x1), _d(y1), _d(x2), _d(y2), x1.size, _d(H), H.shape[0], C.c_double(thr2), int(need),
+           int(max_models), m.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(Hs),
+           idx.ctypes.data_as(C.POINTER(C.c_longlong)), _i(cnt))
     return Hs[:k].copy(), idx[:k].copy(), cnt[:k].copy(), m
 
 

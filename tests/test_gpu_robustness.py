@@ -111,15 +111,26 @@ def test_expansion_restarts_with_fewer_workgroups_after_a_barrier_timeout(engine
     assert 0 < st["longest_barrier_wait_us"] < 5000, st["longest_barrier_wait_us"]
 
 
-def test_greedy_selection_refuses_the_symmetric_residual_mode(mh, engine, synth):
-    sc = synth.make_scene(500, 2, seed=1, with_neighbours=False)
+def test_greedy_selection_in_the_symmetric_residual_mode(mh, engine, synth, oracle):
+    """r05: mh_select_greedy follows the engine's residual mode — it scores AND claims on the symmetric transfer error
+    (until r04 it refused the mode).  Selected hypotheses, counts and the support mask equal the oracle's sequential
+    selection on the same error; the forward selection on the same batch is a different one."""
+    sc = synth.make_scene(1500, 3, seed=11, with_neighbours=False)
     engine.set_correspondences(sc.src, sc.dst, sc.aff)
-    engine.propose_dlt4(1, 0, 64)
+    engine.propose_dlt4(5, 0, 2000)
+    H = engine.get_models()
+    thr2 = 2.2 ** 2
     engine.set_residual_mode(True)
     try:
-        with pytest.raises(mh.MultiHError) as ei:
-            engine.select_greedy(2.2 ** 2, 8, 4)
-        assert ei.value.code == -2 and "forward" in str(ei.value)
+        Hs, counters, counts, mask = engine.select_greedy(thr2, 20, 6, np.ones(sc.n, np.uint8))
+        with np.errstate(all="ignore"):
+            H_ref, idx_ref, cnt_ref, mask_ref = oracle.select_greedy(sc.src, sc.dst, H, thr2, 20, 6, symmetric=True)
+            assert np.array_equal(engine.score(thr2), oracle.score_sym(sc.src, sc.dst, H, thr2))
     finally:
         engine.set_residual_mode(False)
-    assert len(engine.select_greedy(2.2 ** 2, 8, 4)[1]) >= 1
+    assert len(counters) >= 2
+    assert np.array_equal(counters, idx_ref) and np.array_equal(counts, cnt_ref) and np.array_equal(mask, mask_ref)
+    assert np.array_equal(Hs.view(np.uint64), H_ref.view(np.uint64))
+    engine.propose_dlt4(5, 0, 2000)
+    _, _, counts_fwd, _ = engine.select_greedy(thr2, 20, 6, np.ones(sc.n, np.uint8))
+    assert counts_fwd[0] >= counts[0]            # d2_sym >= d2_fwd pair by pair: a model never gains inliers

@@ -70,7 +70,7 @@ def test_sharded_scores_equal_single_process(oracle, synth, mh, world, total, mo
         assert p.exitcode == 0
     results.sort(key=lambda r: r[0])
     # single-process reference over the same global RNG counters
-    sc = synth.make_scene(600, 3, seed=5, with_neighbours=False)
+    sc = mh.synth.make_scene(600, 3, seed=5, with_neighbours=False)       # (the workers' generator)
     n_global = total if mode == "strong" else total * world
     idx = oracle.sample4(99, 0, n_global, sc.n)
     H, _, _ = oracle.dlt4(sc.src, sc.dst, idx)

@@ -83,6 +83,13 @@ if world > 1:
 # Agreement with the generator's ground truth: a plane counts as RECOVERED when one label holds at least
 # 80 % of its inlier correspondences; ARI over all correspondences (outliers = one class of their own, label -1)
 quality = mh.synth.agreement(sc.gt_label, labels)
+if rank == 0 and os.environ.get("CONFUSION"):
+    # planes x labels: where every ground-truth plane's correspondences ended up (column 0 = outlier label)
+    tab = np.zeros((K + 1, max(k, 0) + 1), dtype=np.int64)
+    np.add.at(tab, (sc.gt_label + 1, labels + 1), 1)
+    print("confusion (rows: outliers, plane 0..; columns: label -1, 0..):")
+    for r in range(K + 1):
+        print(("outl " if r == 0 else f"p{r - 1:<3d} ") + " ".join(f"{v:6d}" for v in tab[r]))
 if rank == 0:
     print(f"N={N} planes={K} hypotheses={HYP} gpus={world}: clusters={k} iterations={it.value} energy={en.value:.0f} "
           f"loop={secs.value:.2f}s total={wall:.2f}s  planes recovered {quality['planes_recovered']}/{K}  ARI {quality['ari']:.3f}  "

@@ -17,6 +17,8 @@ for n, planes in ((int(v), SIZES[int(v)]) for v in os.environ.get("SIZES", "500,
     feat = np.where(np.isfinite(feat), feat, 1e300)
     if os.environ.get("MS_ITERS"):
         e.set_tuning(7, int(os.environ["MS_ITERS"]))
+    if os.environ.get("MS_PERSIST"):                       # key 29: 0 = a launch per iteration throughout (the r04 schedule)
+        e.set_tuning(29, int(os.environ["MS_PERSIST"]))
     best = 1e9
     for _ in range(3):
         t = time.perf_counter()
