@@ -7,6 +7,8 @@
 #include "mh_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1336,6 +1338,10 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         for (int i = row + 1; i <= n; i += i & -i) fen[i] -= 1;
     };
     int unvisited = n;
+    // MULTIH_MS_STATS=1: where the call's time goes (a line on stderr at the end) — diagnostic
+    const bool ms_stats = std::getenv("MULTIH_MS_STATS") != nullptr;
+    double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0;
+    long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0;
     std::vector<double> cent;                                       // modes, d values each
     int n_cent = 0;
     std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: sorted (row, votes)
@@ -1343,6 +1349,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     while (unvisited > 0) {
         // the batch: MS_BATCH seeds drawn from the rows unvisited now (:55-56 for each draw); a small tail draws fewer
         const int climbs = std::min(B, unvisited);
+        ++st_batches;
         for (int b = 0; b < climbs; ++b) {
             unsigned long long z = seed + counter++;                // splitmix64
             z += 0x9E3779B97F4A7C15ull;
@@ -1373,6 +1380,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                 if (G < 16 || G * n_active > room) G = 0;
             }
             ++e->ms_rounds;
+            const auto t_round = std::chrono::steady_clock::now();
+            const int active_in = n_active;
             if (G > 0) {
                 HIPCHK(launch_ms_persist(w, active, n_active, G, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
                                          e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream));
@@ -1382,6 +1391,13 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                                        e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->ms_tickets.p, e->stream));
             }
             HIPCHK(hipStreamSynchronize(e->stream));
+            if (ms_stats) {
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_round).count();
+                long long its = 0;
+                for (int a = 0; a < n_active; ++a) its = std::max<long long>(its, e->h_ms[active.climb[a]].out[0] - iters_seen[active.climb[a]]);
+                if (G > 0) { st_persist_us += us; st_persist_iters += its; ++st_persist_rounds; st_persist_climbs += active_in; }
+                else { st_launch_us += us; ++st_launch_rounds; if (round > 0) { st_tail_us += us; st_tail_climbs += active_in; } }
+            }
             int still = 0;
             for (int a = 0; a < n_active; ++a) {
                 const int b = active.climb[a];
@@ -1476,6 +1492,11 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             if (best_votes[pr.first] < pr.second) { best_votes[pr.first] = pr.second; assign[pr.first] = (int)r; }
     *n_modes = n_cent;
     if (modes) std::copy(cent.begin(), cent.begin() + (size_t)std::min(n_cent, max_modes) * d, modes);
+    if (ms_stats)
+        fprintf(stderr, "[mh_mean_shift] n %d: %lld batches; launched rounds %lld (%.1f ms, of which rounds after the first %.1f ms on %lld climb-rounds); "
+                        "persistent rounds %lld (%.1f ms, %lld climbs, longest climbs %lld iterations in sum = %.1f us per iteration)\n",
+                n, st_batches, st_launch_rounds, st_launch_us * 1e-3, st_tail_us * 1e-3, st_tail_climbs, st_persist_rounds, st_persist_us * 1e-3,
+                st_persist_climbs, st_persist_iters, st_persist_iters ? st_persist_us / (double)st_persist_iters : 0.0);
     return MH_OK;
     });
 }

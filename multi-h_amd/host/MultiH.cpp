@@ -761,6 +761,17 @@ void mhh_set_neighbourhood(int knn_k, double radius) { g_knn = knn_k; g_radius =
 static long long g_max_hits = 0;
 extern "C" __attribute__((visibility("default")))
 void mhh_set_neighbour_max_hits(long long max_hits) { g_max_hits = max_hits; }
+// caller-supplied directed hit lists (MultiH::SetNeighbours) for the next mhh_run_process calls, CSR; n <= 0 clears them.
+// For tools/neighbourhood_sweep.py: which neighbourhood rule reproduces the reference's recorded barrsmith result.
+static std::vector<std::vector<int>> g_hits;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_neighbour_hits(const int* rowptr, const int* col, int n)
+{
+    g_hits.clear();
+    if (n <= 0 || !rowptr || !col) return;
+    g_hits.resize(n);
+    for (int i = 0; i < n; ++i) g_hits[i].assign(col + rowptr[i], col + rowptr[i + 1]);
+}
 // schedule knobs (mh_set_tuning) for the engines of the next mhh_run_process calls; key < 0 clears the list
 static std::vector<std::pair<int, int>> g_tuning;
 extern "C" __attribute__((visibility("default")))
@@ -811,6 +822,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     if (g_radius > 0.0 && g_max_hits > 0) { mh.SetNeighbourRadius(g_radius, g_max_hits); if (g_knn > 0) mh.SetFallbackK(g_knn); }
     else if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
     else if (g_knn > 0) mh.SetNeighbourK(g_knn);
+    if (!g_hits.empty() && (int)g_hits.size() == n) mh.SetNeighbours(g_hits);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init
     if (init_H && n_init > 0) {
         std::vector<cv::Mat> hs;

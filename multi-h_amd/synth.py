@@ -108,7 +108,11 @@ def _feature6(H9: np.ndarray) -> np.ndarray:
 def _separated_planes(rng, n_planes: int, seeds: np.ndarray, K, Kinv, R, t, sep: float, feat_sep: float) -> np.ndarray:
     """K plane homographies of ONE relative pose that are distinguishable where they are observed: every point of the
     Voronoi cell of plane k is transferred at least `sep` pixels away by every other plane's homography (and the other
-    way round), and the 6-D merge features of any two planes differ by at least `feat_sep` in L1.  Without this the
+    way round), and the 6-D merge features of any two planes differ by at least `feat_sep` in L1.  `sep` has to exceed TWO
+    truncation radii (2 x 4.95 px at the harness defaults): the reference's data cost falls towards the truncation
+    threshold (M/MultiH.cpp:501-502: 200 at a perfect fit, 0 at the threshold), so a homography half-way between two planes
+    less than that apart explains both at a LOWER cost than their own models — with 8 px the loop merged four planes
+    into one model that way (profiles/r05_loop_confusion_sep8.txt).  Without any separation the
     scene is K planes in name only: with normals and depths drawn independently, 40-90 % of a plane's correspondences
     lie within the reference's truncation threshold (4.95 px) of ANOTHER plane's homography, and PEARL's labeling
     cannot (and, with the reference's data cost growing towards the threshold, M/MultiH.cpp:501-502, will not) keep the
@@ -172,14 +176,16 @@ def _separated_planes(rng, n_planes: int, seeds: np.ndarray, K, Kinv, R, t, sep:
 def make_scene(n_points: int, n_planes: int, seed: int = 1234, outlier_frac: float = 0.25,
                noise: float = 0.5, knn: int = 16, symmetric: bool = True,
                with_neighbours: bool = True, legacy_r04: bool = False,
-               plane_separation: float = 8.0, feature_separation: float = 15.0) -> Scene:
+               plane_separation: float = 13.0, feature_separation: float = 15.0) -> Scene:
     """legacy_r04: the generator as it stood until round 4 (normals and depths of the planes drawn independently of
     each other — planes that cannot be told apart inside the truncation threshold, see _separated_planes)."""
     rng = np.random.default_rng(seed)
     K = np.array([[1000.0, 0, 500.0], [0, 1000.0, 500.0], [0, 0, 1.0]])
     Kinv = np.linalg.inv(K)
     R = _rot(0.03, -0.08, 0.02)
-    t = np.array([0.40, 0.05, 0.08])
+    # The baseline: twice the r04 one in the current generator.  Same epipole and F (both are scale-free in t), twice the
+    # parallax — room for ten planes that stay more than two truncation radii (2 x 4.95 px) apart where they are observed.
+    t = np.array([0.40, 0.05, 0.08]) * (1.0 if legacy_r04 else 2.0)
     tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
     F = Kinv.T @ tx @ R @ Kinv
     F = F / np.linalg.norm(F)

@@ -97,7 +97,8 @@ def test_expansion_restarts_with_fewer_workgroups_after_a_barrier_timeout(engine
     engine.set_tuning(14, 2)
     labels, energy, cycles = engine.expand()
     st = engine.expand_stats()
-    assert st["barrier_timeout_retries"] == 2 and st["solver_workgroups"] == 256 // 4
+    # r05: the first retry keeps the grid (a delayed dispatch on a shared GPU is not a missing workgroup), the second halves it
+    assert st["barrier_timeout_retries"] == 2 and st["solver_workgroups"] == 256 // 2
     assert energy == e_ref and cycles == cyc_ref and np.array_equal(labels, lab_ref)
     engine.set_tuning(14, 1)
     labels, energy, _ = engine.expand(init)                      # the restart begins from the caller's labeling again
