@@ -106,6 +106,7 @@ struct mh_engine {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side_pre = nullptr;
     int tune_score32_resident = 12;          // key 24: the FP32 pre-test score as a resident grid with n point slices (12: 1.98 ms against 2.14 hardware-dispatched at 50k x 100k, tools/score32_probe.py); 0 = hardware dispatch, -1 = ~37 500 items
+    int occ_score32 = -1, occ_cost32 = -1;   // workgroups per compute unit of the resident score / cost kernels on THIS engine's device (-1: not asked yet)
     int tune_cost32_batched = 0;             // key 28: 1 = experiment: k_cost32 evaluates the near pairs of several models together (score32.hip, cost32_wg_batched; slower: 4.45 vs 4.10 ms)
     int tune_cost32_slice_major = 0;         // key 27: the resident cost-matrix kernel takes its items slice-major (experiment)
     int tune_sweep_slices = 0;               // key 26: > 0 = the resident sweep takes its items slice-major with this many point slices (experiment)
@@ -767,7 +768,7 @@ int score_models(mh_engine* e, const Points& p, const double* Hs, int m, double 
             ctl = e->sweep_ctl.p;
         }
         HIPCHK(launch_score32(p, Hs, e->H32.p, m, thr2, e->absmax_dst, dmask, counts_dev, e->fb_pairs.p, e->tune_score32_tiling, e->stream,
-                              ctl, e->cu_count, e->tune_score32_resident));
+                              ctl, e->cu_count, e->tune_score32_resident, &e->occ_score32));
         e->score_pairs += (long long)m * p.n;
         return MH_OK;
     }
@@ -1693,7 +1694,7 @@ int mh_cost_matrix(mh_engine* e, int* C_host, int* counts)
                 ctl = e->sweep_ctl.p;
             }
             HIPCHK(launch_cost32(e->pts(), e->H.p, e->H32.p, e->m, e->lambda, thr2, e->absmax_dst, e->C.p, e->ldc, e->counts.p, e->stream,
-                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0, e->tune_cost32_slice_major, e->tune_cost32_batched));
+                                 ctl, e->cu_count, e->tune_cost32_resident > 0 ? e->tune_cost32_resident : 0, e->tune_cost32_slice_major, e->tune_cost32_batched, &e->occ_cost32));
         } else
             HIPCHK(launch_cost_matrix(e->pts(), e->H.p, e->m, e->lambda, thr2, e->C.p, e->ldc, e->counts.p, e->stream));
     }
@@ -2499,7 +2500,11 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 12 && (value == 1 || value == 2)) { e->tune_reduce_launches = value; return MH_OK; }
     if (key == 14 && value >= 0 && value <= 8) { e->inject_barrier_timeouts = value; return MH_OK; }
     if (key == 15 && (value == 0 || value == 1)) { e->tune_score32 = value; return MH_OK; }
+#ifdef MH_TUNING
     if (key == 16 && value >= 0 && value <= 16) { e->tune_score32_tiling = value; return MH_OK; }
+#else
+    if (key == 16 && value == 0) return MH_OK;
+#endif
     if (key == 17 && value >= 0 && value <= 1000) { e->tune_cascade_iters = value; return MH_OK; }
     if (key == 18 && value >= 0 && value <= 1000) { e->inject_select_failure = value; return MH_OK; }
     if (key == 19 && value >= -1 && value <= 1024) { e->tune_sweep_headroom = value; return MH_OK; }
@@ -2509,9 +2514,16 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 23 && value >= -1 && value <= 64) { e->tune_cost32_resident = value; return MH_OK; }
     if (key == 24 && value >= -1 && value <= 64) { e->tune_score32_resident = value; return MH_OK; }
     if (key == 25 && value >= 0 && value <= 2) { e->tune_dlt_variant = value; return MH_OK; }
+#ifdef MH_TUNING
+    // measured-and-rejected schedules: measurement libraries only
     if (key == 26 && value >= 0 && value <= 4096) { e->tune_sweep_slices = value; return MH_OK; }
     if (key == 27 && (value == 0 || value == 1)) { e->tune_cost32_slice_major = value; return MH_OK; }
     if (key == 28 && (value == 0 || value == 1)) { e->tune_cost32_batched = value; return MH_OK; }
+#else
+    if ((key == 26 || key == 27 || key == 28) && value == 0) return MH_OK;
+    if (key == 16 || key == 26 || key == 27 || key == 28)
+        return fail(MH_ERR_INVALID, "this schedule variant exists only in a library built with -DMH_TUNING");
+#endif
     return fail(MH_ERR_INVALID, "unknown tuning key");
     });
 }

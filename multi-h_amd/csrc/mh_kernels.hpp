@@ -48,11 +48,12 @@ hipError_t launch_model32(const double* H, int M, double X, double Y, double Cma
 // Cmax: the bound on |x2|, |y2| the table was made with; thr2 in [2^-40, 2^40]
 hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                           int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s, int* resident_ctl = nullptr,
-                          int cu_count = 256, int resident_slices = 0);
+                          int cu_count = 256, int resident_slices = 0, int* occ_cache = nullptr);
 // the materialised int32 cost matrix (launch_cost_matrix, datacost.hip) through the same pre-test; H32 made with the same Cmax
 hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
                          int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl = nullptr, int cu_count = 256,
-                         int psplit_override = 0, int slice_major = 0, int batched = 0);
+                         int psplit_override = 0, int slice_major = 0, int batched = 0, int* occ_cache = nullptr);
+// occ_cache (both launchers): the caller's per-engine cache of the resident kernel's workgroups per compute unit (-1 = not asked yet)
 hipError_t launch_inliers_of_model(const Points& p, const double* H, int idx, double thr2,
                                    int label_value, int* labels, hipStream_t s);
 hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, double* moments,

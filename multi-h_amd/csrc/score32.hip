@@ -587,7 +587,8 @@ k_cost32_resident(const double* __restrict__ x1, const double* __restrict__ y1, 
 // H32: the table launch_model32 made for these models with the same Cmax.  thr2 in [2^-40, 2^40], coordinates below 2^20.
 template <bool BATCH>
 static hipError_t launch_cost32_t(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
-                                  int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major)
+                                  int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major,
+                                  int* occ_cache)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     constexpr int MC = 32;
@@ -606,8 +607,14 @@ static hipError_t launch_cost32_t(const Points& p, const double* H, const float*
     const float k1 = (float)(std::fmax(1.12 * 2.25 * std::sqrt(std::fabs(thr2)), 25.4 * 5.9604644775390625e-08 * Cmax) * (1.0 + 1e-6)) + 1e-30f;
     if (resident_ctl) {
         // resident grid: as many workgroups as the chip holds, ~37 500 items (r04 experiment: mh_set_tuning key 23)
-        static int per_cu = -1;
-        if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cost32_resident<MC, WAVES, BATCH>, 64 * WAVES, 0) != hipSuccess) per_cu = 0;
+        // workgroups a compute unit holds: asked once per ENGINE (the caller's cache; a function-local static would be shared
+        // by every engine, device and host thread, and would keep a failed query for ever — r04 advisor finding)
+        int per_cu = occ_cache ? *occ_cache : -1;
+        if (per_cu < 0) {
+            int q = 0;
+            per_cu = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, (const void*)k_cost32_resident<MC, WAVES, BATCH>, 64 * WAVES, 0) == hipSuccess ? q : 0;
+            if (per_cu > 0 && occ_cache) *occ_cache = per_cu;
+        }
         const int grid = per_cu * cu_count;
         int ps = psplit_override > 0 ? psplit_override : (37500 + gx - 1) / gx;
         if (ps > ntiles) ps = ntiles;
@@ -627,12 +634,19 @@ static hipError_t launch_cost32_t(const Points& p, const double* H, const float*
 
 hipError_t launch_cost32(const Points& p, const double* H, const float* H32, int M, double lambda, double thr2, double Cmax,
                          int* C, long long ldc, int* counts, hipStream_t s, int* resident_ctl, int cu_count, int psplit_override, int slice_major,
-                         int batched)
+                         int batched, int* occ_cache)
 {
     // batched: the experiment above (mh_set_tuning key 28) instead of the default form, in which every wave x model iteration
     // with a near pair runs the IEEE formula at once and hands the costs to the owning lanes through LDS
-    return batched ? launch_cost32_t<true>(p, H, H32, M, lambda, thr2, Cmax, C, ldc, counts, s, resident_ctl, cu_count, psplit_override, slice_major)
-                   : launch_cost32_t<false>(p, H, H32, M, lambda, thr2, Cmax, C, ldc, counts, s, resident_ctl, cu_count, psplit_override, slice_major);
+#ifdef MH_TUNING
+    // (a measured-and-rejected variant: compiled into measurement libraries only, mh_set_tuning key 28; so are the
+    // slice-major item order, key 27, and the other tilings of the score kernel below, key 16)
+    if (batched) return launch_cost32_t<true>(p, H, H32, M, lambda, thr2, Cmax, C, ldc, counts, s, resident_ctl, cu_count, psplit_override, slice_major, nullptr);
+#else
+    (void)batched;
+    slice_major = 0;
+#endif
+    return launch_cost32_t<false>(p, H, H32, M, lambda, thr2, Cmax, C, ldc, counts, s, resident_ctl, cu_count, psplit_override, slice_major, occ_cache);
 }
 
 hipError_t launch_model32(const double* H, int M, double X, double Y, double Cmax, float* H32, hipStream_t s)
@@ -645,14 +659,18 @@ hipError_t launch_model32(const double* H, int M, double X, double Y, double Cma
 template <int PPL, int MC, int MINW = 1>
 static hipError_t launch_score32_t(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                                    int* counts, unsigned long long* fallback_pairs, hipStream_t s, int* resident_ctl = nullptr,
-                                   int cu_count = 256, int resident_slices = 0)
+                                   int cu_count = 256, int resident_slices = 0, int* occ_cache = nullptr)
 {
     const int gx = (M + MC - 1) / MC, ntiles = (p.n + 256 * PPL - 1) / (256 * PPL);
     int psplit = gx < 1024 ? (2048 + gx - 1) / gx : (ntiles >= 16 ? 4 : 1);
     int resident = 0;
     if (resident_ctl && resident_slices != 0 && !mask) {
-        static int per_cu = -1;
-        if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_score32_resident<PPL, MC, false, MINW>, 256, 0) != hipSuccess) per_cu = 0;
+        int per_cu = occ_cache ? *occ_cache : -1;              // per engine, and a failed query is not kept (see launch_cost32_t)
+        if (per_cu < 0) {
+            int q = 0;
+            per_cu = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, (const void*)k_score32_resident<PPL, MC, false, MINW>, 256, 0) == hipSuccess ? q : 0;
+            if (per_cu > 0 && occ_cache) *occ_cache = per_cu;
+        }
         int ps = resident_slices > 0 ? resident_slices : (37500 + gx - 1) / gx;
         if (ps > ntiles) ps = ntiles;
         if (ps < 1) ps = 1;
@@ -684,11 +702,12 @@ static hipError_t launch_score32_t(const Points& p, const double* H, const float
 // FP64.  tiling: points per lane / models per workgroup (a schedule choice; the counts do not depend on it).
 hipError_t launch_score32(const Points& p, const double* H, const float* H32, int M, double thr2, double Cmax, const unsigned char* mask,
                           int* counts, unsigned long long* fallback_pairs, int tiling, hipStream_t s, int* resident_ctl, int cu_count,
-                          int resident_slices)
+                          int resident_slices, int* occ_cache)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
     if (tiling == 0 && resident_ctl && resident_slices != 0)
-        return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s, resident_ctl, cu_count, resident_slices);
+        return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s, resident_ctl, cu_count, resident_slices, occ_cache);
+#ifdef MH_TUNING
     switch (tiling) {
     case 1: return launch_score32_t<4, 16>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     case 2: return launch_score32_t<8, 32>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
@@ -706,9 +725,11 @@ hipError_t launch_score32(const Points& p, const double* H, const float* H32, in
     case 14: return launch_score32_t<4, 64, 5>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     case 15: return launch_score32_t<4, 64, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
     case 16: return launch_score32_t<2, 64, 8>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
-    // 4 points per lane, 64 models per workgroup, registers capped at 80 for six waves per SIMD (2.20 ms; <4, 32, 5> 2.26, uncapped 2.51)
-    default: return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
+    default: break;
     }
+#endif
+    // 4 points per lane, 64 models per workgroup, registers capped at 80 for six waves per SIMD (2.20 ms; <4, 32, 5> 2.26, uncapped 2.51)
+    return launch_score32_t<4, 64, 6>(p, H, H32, M, thr2, Cmax, mask, counts, fallback_pairs, s);
 }
 
 } // namespace mh

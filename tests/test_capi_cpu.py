@@ -91,3 +91,32 @@ def test_product_tree_never_touches_the_oracle():
     assert not bad, f"product files reference the oracle: {bad}"
     out = subprocess.run(["ldd", os.path.join(ROOT, "multi-h_amd", "libmultih_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_product_library_kernels_are_the_product_instantiations_only(mh, engine_lib):
+    """the kernel templates carry measurement switches (residual_wg: CALIB = store-only calibration,
+    CONTRACT = fused multiply-adds — not bit-exact —, TILED = tile-major R, SF = asm store flavours; k_cost32: BATCH;
+    k_score32: tilings) — none of them may be instantiated in the product library.  The kernel names the host side
+    registers are strings of the .so: demangle them and look at the template arguments."""
+    raw = subprocess.run(["strings", mh.LIB_PATH], capture_output=True, text=True).stdout
+    names = sorted({l for l in raw.splitlines() if re.match(r"^_ZN2mh\d+k_", l)})
+    assert len(names) > 40
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    kernels = sorted({re.sub(r"\(.*", "", d).replace("void ", "") for d in dem})
+    res = [k for k in kernels if k.startswith("mh::k_residual")]
+    assert 5 <= len(res) <= 8, res
+    for k in res:
+        a = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        # <PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI, MINW>
+        assert len(a) == 15 and a[0] == "4" and a[1] == "16", k
+        assert a[6] == "false" and a[9] == "false" and a[11] == "false" and a[12] == "0" and a[14] == "1", f"measurement variant in the product library: {k}"
+        assert a[5] == "true", f"compiler division in the product library: {k}"
+    cost = [k for k in kernels if k.startswith("mh::k_cost32")]
+    assert sorted(cost) == ["mh::k_cost32<32, 8, false>", "mh::k_cost32_resident<32, 8, false>"], cost
+    score = [k for k in kernels if k.startswith("mh::k_score32")]
+    assert score and all(k.endswith("<4, 64, false, 6>") or k.endswith("<4, 64, true, 6>") for k in score), score
+    # ... while the measurement library (when it has been built) does carry them
+    tuning = os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_hip_tuning.so")
+    if os.path.exists(tuning) and os.path.getmtime(tuning) >= os.path.getmtime(mh.LIB_PATH):
+        traw = subprocess.run(["strings", tuning], capture_output=True, text=True).stdout
+        assert len({l for l in traw.splitlines() if re.match(r"^_ZN2mh\d+k_residual", l)}) > 20

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Experiment (r04): the int32 cost matrix (k_cost32) as a resident grid — mh_set_tuning key 23: 0 hardware dispatch, -1 resident
 with ~37 500 items, n resident with n point slices.  Same matrix (checked on sample rows and counts)."""
+import os as _os
+# r05: these schedule variants live in the measurement library only (python multi-h_amd/build.py --tuning)
+_os.environ.setdefault("MH_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "multi-h_amd", "libmultih_hip_tuning.so"))
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Fused score pass, 50k points x 100k DLT hypotheses: FP32 pre-test (csrc/score32.hip) vs the FP64 sweep; then the propose +
 greedy selection stage that uses it."""
+import os as _os
+# r05: these schedule variants live in the measurement library only (python multi-h_amd/build.py --tuning)
+_os.environ.setdefault("MH_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "multi-h_amd", "libmultih_hip_tuning.so"))
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

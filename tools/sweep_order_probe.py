@@ -2,6 +2,9 @@
 """Experiment (r04): the resident residual sweep taking its items SLICE-major (mh_set_tuning key 26 = number of point
 slices; consecutive items are the slices of one model block, so the workgroups at work write a compact window of R)
 against the launcher's rule (key 26 = 0: model block fastest, ~37 500 items).  Same counts, same sample rows."""
+import os as _os
+# r05: these schedule variants live in the measurement library only (python multi-h_amd/build.py --tuning)
+_os.environ.setdefault("MH_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "multi-h_amd", "libmultih_hip_tuning.so"))
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
