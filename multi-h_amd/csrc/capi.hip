@@ -157,9 +157,10 @@ struct mh_engine {
     DevBuf<double> loc_H, loc_feat, ms_data, ms_mean;
     DevBuf<int> ms_votes, ms_out, ms_list, ms_pcnt, ms_heads, ms_tickets;
     DevBuf<double> ms_partial, ms_partial2;
+    DevBuf<unsigned long long> ms_ticks;     // MULTIH_MS_STATS: phase ticks of the persistent kernel
     DevBuf<int> ms_ctl, ms_pcnt2;            // the persistent tail of a mean-shift batch (meanshift.hip, k_ms_persist)
-    int ms_persist_per_cu = -1;              // workgroups of k_ms_persist a compute unit holds (-1: not queried; a failed query is not kept)
-    int tune_ms_persist = 16;                // key 29: the tail runs persistently once at most this many climbs are left (0 = never)
+    int ms_persist_per_cu = -1, ms_persist_per_cu6 = -1;   // workgroups of k_ms_persist<10> / <6> a compute unit holds (-1: not queried; a failed query is not kept)
+    int tune_ms_persist = 12;                // key 29: the tail runs persistently once at most this many climbs are left (0 = never)
     long long ms_persist_launches = 0, ms_persist_fallbacks = 0, ms_rounds = 0;
 
     // labeling
@@ -1342,7 +1343,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     // MULTIH_MS_STATS=1: where the call's time goes (a line on stderr at the end) — diagnostic
     const bool ms_stats = std::getenv("MULTIH_MS_STATS") != nullptr;
     double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0;
-    long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0;
+    long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0, st_G = 0;
+    if (ms_stats) { HIPCHK(e->ms_ticks.reserve(4)); HIPCHK(hipMemsetAsync(e->ms_ticks.p, 0, sizeof(unsigned long long) * 4, e->stream)); }
     std::vector<double> cent;                                       // modes, d values each
     int n_cent = 0;
     std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: sorted (row, votes)
@@ -1372,21 +1374,22 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         int iters_seen[B];
         for (int b = 0; b < climbs; ++b) iters_seen[b] = 0;
         for (int round = 0; round < 20000 && n_active > 0; ++round) {     // rounds of device-side iterations
-            int G = 0;
-            if (persist_ok && round > 0 && n_active <= e->tune_ms_persist) {
-                if (e->ms_persist_per_cu < 0) { const int q = ms_persist_occupancy(); if (q > 0) e->ms_persist_per_cu = q; }
-                const int room = std::max(0, e->ms_persist_per_cu) * e->cu_count * 3 / 4;      // workgroups that are resident for sure
-                G = 64;
-                while (G > 1 && G * n_active > room) G /= 2;
-                if (G < 16 || G * n_active > room) G = 0;
+            int G = 0;                                         // > 0: this round runs persistently, G workgroups per climb
+            if (persist_ok && round > 0 && n_active <= e->tune_ms_persist && ms_persist_supported(n, d)) {
+                int& per_cu = d == 10 ? e->ms_persist_per_cu : e->ms_persist_per_cu6;
+                if (per_cu < 0) { const int q = ms_persist_occupancy(d); if (q > 0) per_cu = q; }
+                const int room = std::max(0, per_cu) * e->cu_count * 7 / 8;      // workgroups that are resident for sure
+                const int groups = std::min(64, (n + 255) / 256);
+                if (groups * n_active <= room) G = groups;
             }
             ++e->ms_rounds;
             const auto t_round = std::chrono::steady_clock::now();
             const int active_in = n_active;
             if (G > 0) {
-                HIPCHK(launch_ms_persist(w, active, n_active, G, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
-                                         e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream));
+                HIPCHK(launch_ms_persist(w, active, n_active, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
+                                         e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream, ms_stats ? e->ms_ticks.p : nullptr));
                 ++e->ms_persist_launches;
+                st_G += G;
             } else {
                 HIPCHK(launch_ms_climb(w, active, n_active, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
                                        e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->ms_tickets.p, e->stream));
@@ -1493,6 +1496,12 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             if (best_votes[pr.first] < pr.second) { best_votes[pr.first] = pr.second; assign[pr.first] = (int)r; }
     *n_modes = n_cent;
     if (modes) std::copy(cent.begin(), cent.begin() + (size_t)std::min(n_cent, max_modes) * d, modes);
+    if (ms_stats) {
+        unsigned long long tk[4] = { 0, 0, 0, 0 };
+        (void)hipMemcpy(tk, e->ms_ticks.p, sizeof(tk), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mh_mean_shift] persistent kernel, first climb's first workgroup: gate %.1f ms, sweep + tree + partial stores %.1f ms, barrier %.1f ms, "
+                        "new mean %.1f ms; mean G %.1f\n", tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, st_persist_rounds ? (double)st_G / st_persist_rounds : 0.0);
+    }
     if (ms_stats)
         fprintf(stderr, "[mh_mean_shift] n %d: %lld batches; launched rounds %lld (%.1f ms, of which rounds after the first %.1f ms on %lld climb-rounds); "
                         "persistent rounds %lld (%.1f ms, %lld climbs, longest climbs %lld iterations in sum = %.1f us per iteration)\n",

@@ -164,16 +164,19 @@ k_ms_iterate(MeanShiftWork all, MeanShiftActive active, int groups, double band_
 }
 
 // ---- the tail of a batch without a launch per iteration (r05) ------------------------------------------------------
-// After a round or two of k_ms_iterate most of a batch's 256 climbs have ended; the one to sixteen that have not take
-// dozens to hundreds of iterations, and at one launch (about 15 us) per iteration plus a host round trip every few of
-// them they were most of mh_mean_shift's time.  k_ms_persist runs those climbs to their end in ONE
-// launch: G workgroups per climb (G a power of two, at most the 64 groups of the definition; workgroup g plays the
-// groups g, g + G, ...), a barrier per climb and iteration on a counter of the climb's own, and EVERY workgroup adds the
-// partials in group order and forms the new mean for itself — the same operations in the same order as the ticket
-// holder of k_ms_iterate, so nothing has to be handed back before the next sweep.  Partials are double-buffered by
-// iteration parity (a workgroup can be one barrier ahead of another, never two).  Same bits: a group's member sums are
-// the same strided sums and the same tree.
-// Residency: the barrier needs all G workgroups of a climb on the chip.  The first thing a workgroup does — before it
+// After a round or two of k_ms_iterate most of a batch's 256 climbs have ended; the handful that have not take dozens to
+// hundreds of iterations, and at one launch per iteration (about 29 us each with the host round trip every few: four
+// dependent trips to memory for a thread's rows, the tree, the ticket, the launch) they were most of mh_mean_shift's time
+// (DESIGN.md 3.5).  k_ms_persist runs those climbs to their end in ONE launch:
+//  * one workgroup per GROUP of the definition (64 per climb), so the strided sums and the tree are the same operations;
+//  * a thread's rows never change from iteration to iteration (rows g, g + T, ... of the 64 x 256 global threads), so it
+//    LOADS THEM ONCE into registers (at most MS_CACHED_ROWS = 4 rows: n <= 65 536; larger inputs keep the launched form)
+//    and an iteration reads nothing but the 64 partials; votes are counted in registers and added at the end;
+//  * a barrier per climb and iteration on a counter of the climb's own; EVERY workgroup then adds the partials in group
+//    order and forms the new mean for itself — the ticket holder's arithmetic of k_ms_iterate, operation for operation —
+//    so nothing has to be handed back before the next sweep.  Partials are double-buffered by iteration parity (a
+//    workgroup can be one barrier ahead of another, never two).
+// Residency: the barrier needs all workgroups of a climb on the chip.  The first thing a workgroup does — before it
 // touches any state — is to arrive on the climb's gate word and wait there; a workgroup that waits longer than
 // `gate_timeout` closes the gate (one atomic on the same word decides between "everybody was there" and "closed"),
 // every workgroup of the climb leaves, and the host goes on with launched iterations (a GPU shared with other work).
@@ -183,24 +186,32 @@ struct MeanShiftPersist {
     double* partial2;        // [climb][2][MS_GROUPS][16]
     int* partial_cnt2;       // [climb][2][MS_GROUPS]
     int* fell_back;          // [climb] set when the gate closed (the climb's state is untouched)
+    unsigned long long* ticks;   // nullable diagnostic: 100 MHz ticks of the first climb's first workgroup in {gate + row load, sweep + tree, barrier, new mean}
 };
 constexpr int MS_GATE_CLOSED = 1 << 30;
+constexpr int MS_CACHED_ROWS = 4;
 
-__global__ void __launch_bounds__(256)
-k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int groups, int G, double band_sq, double stop_thresh,
+// (three waves per SIMD: 168 registers — the 10-D form would take 203 and leave room for two; it spills 15 of them into 60 bytes)
+template <int D>
+__global__ void __launch_bounds__(256, 3)
+k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int groups, double band_sq, double stop_thresh,
              int max_iters, unsigned long long gate_timeout)
 {
     const int climb = active.climb[blockIdx.y];
     const MeanShiftWork w = ms_climb(all, climb);
     if (w.out[1] || w.out[3]) return;                       // (every workgroup of the climb reads the same words)
     const int t = threadIdx.x;
-    const int D = w.d;
+    const int b = blockIdx.x;                               // my group
+    const int G = groups;
     const int T = MS_GROUPS * 256;
-    __shared__ double sv[MS_MAXD][256];
+    __shared__ double sv[D][256];
     __shared__ int sc[256];
     __shared__ int s_flag, s_in, s_conv;
     __shared__ double s_mean[MS_MAXD], s_move[MS_MAXD];
 
+    const bool timed = ps.ticks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    unsigned long long tk[4] = { 0, 0, 0, 0 }, tk0 = __builtin_amdgcn_s_memrealtime();
+    auto lap = [&](int which) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tk[which] += now - tk0; tk0 = now; };
     // ---- the gate ----
     // One word: arrivals in the low bits, MS_GATE_CLOSED on top.  A workgroup arrives with a compare-and-swap that refuses a
     // closed gate, so arrivals never grow once the bit is set: (G arrivals, bit or no bit) = everybody was there before
@@ -226,98 +237,121 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
     __syncthreads();
     if (!s_flag) return;
 
+    // ---- my rows, once ----
+    double r[MS_CACHED_ROWS][D];
+    int vote[MS_CACHED_ROWS];
+    int nr = 0;
+#pragma unroll
+    for (int k = 0; k < MS_CACHED_ROWS; ++k) {
+        const int i = b * 256 + t + k * T;
+        vote[k] = 0;
+        if (i < w.n) {
+            nr = k + 1;
+            const double* row = w.data + (size_t)i * D;
+#pragma unroll
+            for (int j = 0; j < D; ++j) r[k][j] = row[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) r[k][j] = 0.0;
+        }
+    }
     if (t < MS_MAXD) s_mean[t] = t < D ? w.mean[t] : 0.0;
     __syncthreads();
-    double old[MS_MAXD], acc[MS_MAXD];
-#pragma unroll
-    for (int j = 0; j < MS_MAXD; ++j) old[j] = s_mean[j];
+    lap(0);
+
     int* arrive = ps.arrive + climb;
     int iters = 0, converged = 0, dead = 0;
     for (int it = 0; it < max_iters; ++it) {
         double* part = ps.partial2 + ((size_t)climb * 2 + (it & 1)) * MS_GROUPS * MS_MAXD;
         int* pcnt = ps.partial_cnt2 + ((size_t)climb * 2 + (it & 1)) * MS_GROUPS;
-        for (int b = blockIdx.x; b < groups; b += G) {      // the groups this workgroup plays
+        double old[D], acc[D];
 #pragma unroll
-            for (int j = 0; j < MS_MAXD; ++j) acc[j] = 0.0;
-            int cnt = 0;
-            for (int i = b * 256 + t; i < w.n; i += T) {
-                const double* row = w.data + (size_t)i * D;
+        for (int j = 0; j < D; ++j) { old[j] = s_mean[j]; acc[j] = 0.0; }
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < MS_CACHED_ROWS; ++k) {
+            if (k < nr) {
+                // (the membership test of k_ms_iterate, operation for operation: |r| for sqrt(r * r) where that is exact)
                 double dist = 0.0;
                 bool plain = true;
-                double a[MS_MAXD];
+                double a[D];
 #pragma unroll
-                for (int j = 0; j < MS_MAXD; ++j) {
-                    a[j] = j < D ? fabs(old[j] - row[j]) : 0.0;
+                for (int j = 0; j < D; ++j) {
+                    a[j] = fabs(old[j] - r[k][j]);
                     plain = plain && (a[j] <= 0x1p500) && (a[j] >= 0x1p-500 || a[j] == 0.0);
                 }
                 if (__builtin_expect(plain, 1)) {
 #pragma unroll
-                    for (int j = 0; j < MS_MAXD; ++j) if (j < D) dist += a[j];
+                    for (int j = 0; j < D; ++j) dist += a[j];
                 } else {
                     asm volatile("; mean shift: sqrt path");
-                    for (int j = 0; j < D; ++j) { const double r = old[j] - row[j]; dist += sqrt(r * r); }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) { const double q = old[j] - r[k][j]; dist += sqrt(q * q); }
                 }
                 if (dist < band_sq) {
-                    for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) acc[j] = acc[j] + r[k][j];
                     ++cnt;
-                    w.votes[i] += 1;
+                    ++vote[k];
                 }
             }
-            auto put_sum = [&](int j, double v) {
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(part) + (size_t)b * MS_MAXD + j,
-                                   (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            };
-            if (__syncthreads_or(cnt) == 0) {
-                if (t < D) put_sum(t, 0.0);
-                if (t == 0) __hip_atomic_store(pcnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                for (int j = 0; j < MS_MAXD; ++j) sv[j][t] = acc[j];
-                sc[t] = cnt;
+        }
+        auto put_sum = [&](int j, double v) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(part) + (size_t)b * MS_MAXD + j,
+                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (__syncthreads_or(cnt) == 0) {
+            if (t < D) put_sum(t, 0.0);
+            if (t == 0) __hip_atomic_store(pcnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) sv[j][t] = acc[j];
+            sc[t] = cnt;
+            __syncthreads();
+            for (int s = 128; s >= 1; s >>= 1) {
+                if (t < s) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) sv[j][t] = sv[j][t] + sv[j][t + s];
+                    sc[t] += sc[t + s];
+                }
                 __syncthreads();
-                for (int s = 128; s >= 1; s >>= 1) {
-                    if (t < s) {
-                        for (int j = 0; j < D; ++j) sv[j][t] = sv[j][t] + sv[j][t + s];
-                        sc[t] += sc[t + s];
-                    }
-                    __syncthreads();
-                }
-                if (t < D) put_sum(t, sv[t][0]);
-                if (t == 0) __hip_atomic_store(pcnt + b, sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();                                // (sv / sc are reused by the next group)
+            if (t < D) put_sum(t, sv[t][0]);
+            if (t == 0) __hip_atomic_store(pcnt + b, sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- the climb's barrier: my partials have landed, then everybody's ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        lap(1);
         if (t == 0) {
             atomicAdd(arrive, 1);
             const int target = G * (it + 1);
             while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
+        lap(2);
         // ---- every workgroup forms the new mean for itself (the ticket holder's arithmetic) ----
+        // the climb's G x 16 partial sums come through LDS (all 256 threads fetch, device-scope loads all in flight at once);
+        // 64 of them held in registers by each of D lanes cost the kernel a wave per SIMD
+        double* flat = &sv[0][0];                           // (D x 256 doubles >= 64 x 16; the tree is done with it)
+        for (int idx = t; idx < G * MS_MAXD; idx += 256)
+            flat[idx] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part) + idx,
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        int in = 0;
         if (t < 64) {
-            int in = 0;
+            in = t < G ? __hip_atomic_load(pcnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
-            for (int b = 0; b < MS_GROUPS; ++b) {
-                const int c = b < groups ? __hip_atomic_load(pcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                in += c;
-            }
+            for (int m = 32; m >= 1; m >>= 1) in += __shfl_xor(in, m, 64);          // (integers: any order)
             if (t == 0) s_in = in;
-            if (t < D && in != 0) {
-                double s = 0.0;
-#pragma unroll
-                for (int b = 0; b < MS_GROUPS; ++b) {
-                    const double v = b < groups ? __longlong_as_double((long long)__hip_atomic_load(
-                                         reinterpret_cast<const unsigned long long*>(part) + (size_t)b * MS_MAXD + t, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-                    s = s + v;
-                }
-                const double m = s * (1.0 / (double)in);
-                const double dd = m - s_mean[t];            // (the mean this iteration started from: thread t is its only writer)
-                s_move[t] = dd * dd;
-                s_mean[t] = m;
-            }
+        }
+        __syncthreads();
+        if (t < D && in != 0) {
+            double s = 0.0;
+            for (int q = 0; q < G; ++q) s = s + flat[q * MS_MAXD + t];               // groups in sequence (s is never -0)
+            const double m = s * (1.0 / (double)in);
+            const double dd = m - s_mean[t];                // (the mean this iteration started from: thread t is its only writer)
+            s_move[t] = dd * dd;
+            s_mean[t] = m;
         }
         __syncthreads();
         if (s_in == 0) { dead = 1; break; }
@@ -327,13 +361,18 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
             s_conv = sqrt(move) < stop_thresh ? 1 : 0;
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MS_MAXD; ++j) old[j] = s_mean[j];
         ++iters;
         converged = s_conv;
-        __syncthreads();                                    // (s_in / s_mean / s_conv are rewritten by the next iteration)
+        lap(3);
         if (converged) break;
+        // (s_in / s_conv are rewritten only after the next iteration's barriers; s_mean is read at its top by everybody
+        // before thread t < D of wave 0 can write it again — the tree's or the barrier's __syncthreads lie between)
     }
+    // votes of my rows (this thread is their only writer)
+#pragma unroll
+    for (int k = 0; k < MS_CACHED_ROWS; ++k)
+        if (k < nr && vote[k]) w.votes[b * 256 + t + k * T] += vote[k];
+    if (timed) for (int q = 0; q < 4; ++q) atomicAdd(ps.ticks + q, tk[q]);
     if (blockIdx.x == 0) {                                  // one workgroup writes the climb's state back
         if (t < D) w.mean[t] = s_mean[t];
         if (t == 0) {
@@ -423,31 +462,39 @@ hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active
     return hipGetLastError();
 }
 
-// The climbs active[0..n_active) to their end (or `max_iters` iterations) in one launch, G workgroups each; then compact /
-// publish as launch_ms_climb does.  ctl: 3 x MS_BATCH ints (gate, arrive, fell_back), cleared here.
-hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, int G, double band_sq, double stop_thresh,
+// The climbs active[0..n_active) to their end (or `max_iters` iterations) in one launch, one workgroup per group of the
+// definition; then compact / publish as launch_ms_climb does.  ctl: 3 x MS_BATCH ints (gate, arrive, fell_back), cleared
+// here.  hipErrorNotSupported: no persistent form for this input (d other than 6 / 10, more than 4 rows per thread).
+hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, double band_sq, double stop_thresh,
                              int max_iters, int* ctl, double* partial2, int* partial_cnt2, MeanShiftResultBlock* result_dev,
-                             int* heads_dev, int list_prefix, hipStream_t s)
+                             int* heads_dev, int list_prefix, hipStream_t s, unsigned long long* ticks)
 {
-    if (w.d > MS_MAXD || n_active < 1 || n_active > MS_BATCH || G < 1 || G > MS_GROUPS || (G & (G - 1))) return hipErrorInvalidValue;
+    if (w.d > MS_MAXD || n_active < 1 || n_active > MS_BATCH) return hipErrorInvalidValue;
+    if (!ms_persist_supported(w.n, w.d)) return hipErrorNotSupported;
     const int groups = std::min(MS_GROUPS, (w.n + 255) / 256);
-    if (G > groups) { G = 1; while (G * 2 <= groups) G *= 2; }
     hipError_t he = hipMemsetAsync(ctl, 0, sizeof(int) * 3 * MS_BATCH, s);
     if (he != hipSuccess) return he;
-    MeanShiftPersist ps{ ctl, ctl + MS_BATCH, partial2, partial_cnt2, ctl + 2 * MS_BATCH };
-    hipLaunchKernelGGL(k_ms_persist, dim3(G, n_active), dim3(256), 0, s, w, active, ps, groups, G, band_sq, stop_thresh, max_iters,
-                       25000000ull /* 250 ms at 100 MHz */);
+    MeanShiftPersist ps{ ctl, ctl + MS_BATCH, partial2, partial_cnt2, ctl + 2 * MS_BATCH, ticks };
+    const unsigned long long gate_timeout = 25000000ull;    // 250 ms at 100 MHz
+    if (w.d == 10)
+        hipLaunchKernelGGL(k_ms_persist<10>, dim3(groups, n_active), dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
+    else
+        hipLaunchKernelGGL(k_ms_persist<6>, dim3(groups, n_active), dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
     hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
     hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
     return hipGetLastError();
 }
 
+// the two feature spaces of the path: 10-D (EstablishStablePointSets) and 6-D (MergingStep); rows cached in registers
+bool ms_persist_supported(int n, int d) { return (d == 10 || d == 6) && n <= MS_CACHED_ROWS * MS_GROUPS * 256; }
+
 // workgroups of k_ms_persist a compute unit holds (0: the query failed — not cached by the caller)
-int ms_persist_occupancy()
+int ms_persist_occupancy(int d)
 {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist, 256, 0) != hipSuccess) return 0;
-    return per_cu;
+    const hipError_t he = d == 10 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist<10>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist<6>, 256, 0);
+    return he == hipSuccess ? per_cu : 0;
 }
 
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s)

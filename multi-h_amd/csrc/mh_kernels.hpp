@@ -124,13 +124,15 @@ hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active
                            double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix,
                            int* tickets /* MS_BATCH ints, zero */, hipStream_t s);
 // r05: the same for the FEW climbs that are still running after the first rounds — to their end (or max_iters) in one
-// launch, G workgroups per climb with a barrier of the climb's own per iteration (meanshift.hip, k_ms_persist); a climb
-// whose workgroups were not all resident within 250 ms leaves untouched with fell_back (ctl[2 * MS_BATCH + climb]) set.
-// ctl: 3 x MS_BATCH ints; partial2: MS_BATCH x 2 x 64 x 16 doubles; partial_cnt2: MS_BATCH x 2 x 64 ints.
-hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, int G, double band_sq, double stop_thresh,
+// launch, one workgroup per group of the definition with the thread's rows in registers and a barrier of the climb's own
+// per iteration (meanshift.hip, k_ms_persist); a climb whose workgroups were not all resident within 250 ms leaves
+// untouched with fell_back (ctl[2 * MS_BATCH + climb]) set.  ctl: 3 x MS_BATCH ints; partial2: MS_BATCH x 2 x 64 x 16
+// doubles; partial_cnt2: MS_BATCH x 2 x 64 ints.  Needs n_active x min(64, ceil(n / 256)) workgroups resident at once.
+hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, double band_sq, double stop_thresh,
                              int max_iters, int* ctl, double* partial2, int* partial_cnt2, MeanShiftResultBlock* result_dev,
-                             int* heads_dev, int list_prefix, hipStream_t s);
-int ms_persist_occupancy();
+                             int* heads_dev, int list_prefix, hipStream_t s, unsigned long long* ticks = nullptr);
+bool ms_persist_supported(int n, int d);
+int ms_persist_occupancy(int d);
 // compacts and clears the votes of all `climbs` climbs, ended or not
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s);
 

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 mh = importlib.import_module("multi-h_amd")
 
 
-def kept_correspondences():
+def kept_correspondences(with_rows=False):
     """(x1 y1 x2 y2 a11 a12 a21 a22) of the reference's 1 094 kept correspondences, in result-file order, and their labels."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "barrsmith.npz"))
     pts, res = g["points"], g["result"]
@@ -43,6 +43,8 @@ def kept_correspondences():
         rows.append(best)
     rows = np.asarray(rows)
     ok = rows >= 0
+    if with_rows:
+        return pts, rows[ok], res[ok, 8].astype(int)
     return pts[rows[ok]], res[ok, 8].astype(int), int(ok.sum()), int(len(res))
 
 
@@ -96,6 +98,45 @@ def run(route, corr, F, e2, seed=1234, hypotheses=20000, knn=0):
     return k, labels, it.value, en.value
 
 
+def front_half(pts, seed=1234):
+    """The reference's GetFundamentalMatrixAndRefineData (M/MultiH.cpp:770-848) on ALL input correspondences through the
+    engine's pieces — F by 8-point RANSAC, epipoles, Hartley-Sturm correction + affine consistency filter + optimal affinity
+    — exactly what Process() does without a given F (tests/test_gpu_alternation.py holds that decomposition equal to it).
+    Returns (indices of the kept rows, their REFINED correspondences, F, e2)."""
+    e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+    e.set_correspondences(pts[:, 0:2], pts[:, 2:4], pts[:, 4:8])
+    F, e2, mask, inl = e.estimate_fundamental(seed ^ 0xf00d, 4000, 2.6)
+    e1, e2 = e.epipoles(F)
+    keep, refined = e.refine_correspondences(F, e1, e2, mask)
+    e.close()
+    idx = np.flatnonzero(keep)
+    return idx, np.ascontiguousarray(refined[idx]), F, e2
+
+
+def raw_route(seeds=(1234, 7, 99), knn=0):
+    """From the RAW input file (2 903 rows) as the reference's harness runs it: front half, then Process() on the kept,
+    refined correspondences; compared with the reference's labels on the rows BOTH kept."""
+    pts, ref_rows, ref_labels = kept_correspondences(with_rows=True)
+    out = {}
+    for route in ("stable_sets", "dlt"):
+        runs = []
+        for seed in seeds:
+            idx, refined, F, e2 = front_half(pts, seed)
+            k, labels, it, en = run(route, refined, F, e2, seed=seed, knn=knn)
+            full = np.full(len(pts), -2, dtype=int)              # -2: dropped by OUR front half
+            full[idx] = labels
+            ours = full[ref_rows]
+            both = ours > -2
+            a = agreement(ours[both], ref_labels[both]) if k > 0 else {"planes": int(k)}
+            a.update(seed=seed, kept_by_us=int(len(idx)), kept_by_both=int(both.sum()), kept_by_reference=int(len(ref_rows)))
+            runs.append(a)
+            print(f"raw input, {route:12s} seed {seed:5d}: we keep {len(idx)} of {len(pts)} (the reference kept {len(ref_rows)}, {int(both.sum())} in common): "
+                  f"{k} planes, ARI on the reference's inliers {a.get('ari_reference_inliers', float('nan')):.3f}, all {a.get('ari_all', float('nan')):.3f}, "
+                  f"histogram {a.get('ours_histogram')}", flush=True)
+        out[route] = runs
+    return out
+
+
 def main():
     corr, ref, matched, total = kept_correspondences()
     e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
@@ -123,6 +164,8 @@ def main():
                     print(f"  sweep {route:12s} k-NN {knn:3d} seed {seed:5d}: {k} planes, ARI inliers {a['ari_reference_inliers']:.3f}, all {a['ari_all']:.3f}, "
                           f"histogram {a['ours_histogram']}", flush=True)
         run("dlt", corr, F, e2, knn=0)
+    if os.environ.get("RAW", "1") != "0":
+        rec["from_the_raw_input_file"] = raw_route()
     print(json.dumps(rec))
     return rec
 
