@@ -190,7 +190,8 @@ def full_loop_extra(a):
         return {"error": err}
     out = {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 100000 proposals, then 20 merge/label/re-estimate iterations",
            "fixed_iterations": 20, "iterations_reported_by_the_class": rec["iterations"],
-           "iterations_note": "GetIterationNumber() is the reference's iteration_number - 1 (M/MultiH.cpp:311): 19 after 20 LabelingSteps",
+           "iterations_note": "GetIterationNumber() is the reference's iteration_number - 1 (M/MultiH.cpp:311): 19 after 20 LabelingSteps; fewer when the loop "
+                              "converges before the twentieth (the reference's own stop rule, :295, stays in force)",
            "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
            "ground_truth": {"what": "agreement of the labels with the generator's ground truth: a plane is recovered when one label holds >= 80 % of "
                                     "its inlier correspondences; ARI over all correspondences (outliers a class of their own)",
@@ -538,6 +539,22 @@ def main():
         eng.set_tuning(15, 1)
     assert eng.model_count == M_res
     cost64_ms = ms_c64 / max(n_c64, 1)
+    # ... and north_star's SYMMETRIC transfer error (MH_RESIDUAL_SYMMETRIC: d2 = ||H p1 - p2||^2 + ||adj(H) p2 - p1||^2, the same
+    # 8-byte matrix; the reference has the forward form only, so this is an extension — tests/test_symmetric_exact.py checks its
+    # definition in exact rationals): FP64-issue bound, 57 rounded operations per pair
+    eng.set_residual_mode(True)
+    try:
+        eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        for _ in range(3):
+            eng.residual_matrix(thr2, fetch_R=False, fetch_counts=False)
+        eng.synchronize()
+        n_sy, ms_sy = eng.profile_get(1)
+        eng.profile_enable(False)
+    finally:
+        eng.set_residual_mode(False)
+    sym_ms = ms_sy / max(n_sy, 1)
     cost_bytes = 4.0 * N * M_res + 32.0 * N + 72.0 * M_res + 4.0 * M_res
     avg_res_ms = head["res_ms"]
     alg_bytes = 8.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
@@ -625,6 +642,12 @@ def main():
                                "models_resident": M_res, "ms": cost_ms, "ms_fp64_everywhere": cost64_ms, "algorithmic_bytes_per_launch": cost_bytes, "GBps": cost_bytes / (cost_ms * 1e-3) / 1e9,
                                "frac_of_hbm_peak": frac("cost_matrix_s4.frac_of_hbm_peak", cost_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS),
                                "frac_of_hbm_peak_fp64_everywhere": frac("cost_matrix_s4.frac_of_hbm_peak_fp64_everywhere", cost_bytes / (cost64_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)},
+            "symmetric_transfer": {"what": "mh_residual_matrix in MH_RESIDUAL_SYMMETRIC mode on the same batch: forward + backward transfer error, R written "
+                                           "(8 B per pair); 57 rounded FP64 operations per pair (2 x 28 + the sum), FP64-issue bound",
+                                   "models_resident": M_res, "ms": sym_ms, "ops_per_pair": 57, "ops_per_s": 57.0 * N * M_res / (sym_ms * 1e-3),
+                                   "utilisation_vs_2.4GHz_fp64_vector_peak": frac("symmetric_transfer.utilisation", 57.0 * N * M_res / (sym_ms * 1e-3) / (256 * 4 * 16 * 2.4e9)),
+                                   "frac_of_hbm_peak": frac("symmetric_transfer.frac_of_hbm_peak", (8.0 * N * M_res) / (sym_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS),
+                                   "hypotheses_per_s": M_res / (sym_ms * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": frac("roofline.frac", achieved / HBM_PEAK_GBPS), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes,

@@ -1344,6 +1344,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     const bool ms_stats = std::getenv("MULTIH_MS_STATS") != nullptr;
     double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0;
     long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0, st_G = 0;
+    std::vector<std::pair<int, int>> st_climbs;              // (iterations, rows touched) of every climb
     if (ms_stats) { HIPCHK(e->ms_ticks.reserve(4)); HIPCHK(hipMemsetAsync(e->ms_ticks.p, 0, sizeof(unsigned long long) * 4, e->stream)); }
     std::vector<double> cent;                                       // modes, d values each
     int n_cent = 0;
@@ -1430,6 +1431,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         }
         // apply the climbs in draw order; one whose seed an earlier climb of the batch has visited never started in
         // the reference's terms and is dropped
+        if (ms_stats)
+            for (int b = 0; b < climbs; ++b) st_climbs.emplace_back(e->h_ms[b].out[0], e->h_ms[b].out[2]);
         for (int b = 0; b < climbs; ++b) {
             const int st = starts[b];
             if (visited[st]) continue;
@@ -1501,6 +1504,20 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         (void)hipMemcpy(tk, e->ms_ticks.p, sizeof(tk), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mh_mean_shift] persistent kernel, first climb's first workgroup: gate %.1f ms, sweep + tree + partial stores %.1f ms, barrier %.1f ms, "
                         "new mean %.1f ms; mean G %.1f\n", tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, st_persist_rounds ? (double)st_G / st_persist_rounds : 0.0);
+    }
+    if (ms_stats && !st_climbs.empty()) {
+        // how long the climbs are and how many rows they touch: is the tail made of dense or of sparse climbs?
+        const int edges[6] = { 2, 6, 12, 30, 100, 1 << 30 };
+        int lo = 0;
+        for (int q = 0; q < 6; ++q) {
+            long long cnt = 0, its = 0;
+            std::vector<int> touched;
+            for (const auto& c : st_climbs) if (c.first > lo && c.first <= edges[q]) { ++cnt; its += c.first; touched.push_back(c.second); }
+            std::sort(touched.begin(), touched.end());
+            if (cnt) fprintf(stderr, "[mh_mean_shift]   climbs of %d..%d iterations: %lld (%lld iterations in sum); rows touched: median %d, 90 %% %d, max %d\n",
+                             lo + 1, edges[q] > 100000 ? 99999 : edges[q], cnt, its, touched[touched.size() / 2], touched[touched.size() * 9 / 10], touched.back());
+            lo = edges[q];
+        }
     }
     if (ms_stats)
         fprintf(stderr, "[mh_mean_shift] n %d: %lld batches; launched rounds %lld (%.1f ms, of which rounds after the first %.1f ms on %lld climb-rounds); "

@@ -68,8 +68,10 @@ def test_bench_launcher_reports_a_failing_rank():
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
-def _loop(world, iter_hyp=0):
+def _loop(world, iter_hyp=0, init=None):
     env = _clean_env(N="50000", K="10", HYP="100000", ITERS="20", ITER_HYP=str(iter_hyp), LOOP_BACKEND="gloo", LOOP_DEVICE="0")
+    if init:
+        env["INIT"] = init
     script = os.path.join(ROOT, "tools", "loop_bench.py")
     if world == 1:
         cmd = [sys.executable, script]
@@ -82,7 +84,7 @@ def _loop(world, iter_hyp=0):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, f"loop_bench_world{world}{'_reproposal' if iter_hyp else ''}.json"), "w") as f:
+    with open(os.path.join(OUT, f"loop_bench_world{world}{'_reproposal' if iter_hyp else ''}{'_' + init if init else ''}.json"), "w") as f:
         json.dump(rec, f)
     return rec
 
@@ -90,8 +92,14 @@ def _loop(world, iter_hyp=0):
 def test_configs4_full_loop_at_size_is_independent_of_world_size():
     one = _loop(1)
     # GetIterationNumber() is the reference's `iteration_number - 1` (M/MultiH.cpp:311): 19 after 20 iterations
-    assert one["points"] == 50000 and one["hypotheses"] == 100000 and one["iterations"] == 19
-    assert one["clusters"] >= 5, "10 planes were generated; merging and the compatibility check keep the supported ones"
+    assert one["points"] == 50000 and one["hypotheses"] == 100000 and 1 <= one["iterations"] <= 19      # (20 at most: the loop also ends when it has converged, M/MultiH.cpp:295)
+    # r05: agreement with the generator's ground truth (tools/loop_bench.py, synth.agreement).  The scene's ten planes are
+    # separated where they are observed (synth._separated_planes); from 100 000 random 4-tuples the loop keeps a model for
+    # every plane and one or two in-between models that the reference's falling data cost rewards:
+    # r05 measured 8 of 10 planes at the 80 % level, ARI 0.937, 12 445 of 12 450 outliers rejected
+    assert one["planes"] == 10 and one["planes_recovered"] >= 8 and one["ari"] >= 0.9, one
+    assert 10 <= one["clusters"] <= 13
+    assert abs(one["outliers_labelled"] - one["outliers_generated"]) <= 0.02 * one["outliers_generated"]
     two = _loop(2)
     assert two["ranks_identical"] and two["exchanges"] > 0
     assert two["digest"] == one["digest"] and two["clusters"] == one["clusters"] and two["energy"] == one["energy"]
@@ -101,7 +109,16 @@ def test_configs4_with_a_proposal_batch_in_every_iteration_is_independent_of_wor
     """configs[4] read literally — "20 propose-expand iterations": every iteration draws a fresh batch of 100 000 DLT
     hypotheses on the points the labeling leaves unexplained (sharded over the ranks like the first batch)."""
     one = _loop(1, iter_hyp=100000)
-    assert one["iter_hypotheses"] == 100000 and one["iterations"] == 19 and one["clusters"] >= 5
+    assert one["iter_hypotheses"] == 100000 and one["iterations"] <= 19
+    assert one["planes_recovered"] >= 8 and one["ari"] >= 0.9 and 10 <= one["clusters"] <= 13, one      # r05 measured 9 / 0.975 / 10
     two = _loop(2, iter_hyp=100000)
     assert two["ranks_identical"] and two["exchanges"] > one["exchanges"]
     assert two["digest"] == one["digest"] and two["clusters"] == one["clusters"] and two["energy"] == one["energy"]
+
+
+def test_configs4_by_the_references_own_initialisation_recovers_every_plane():
+    """The reference's route — per-point HAF homographies, mean shift, 3-point fits (INIT_STABLE_SETS), then the loop and the
+    post-filter — on the configs[4] scene: r05 measured 10 of 10 planes, ARI 1.000, 12 447 of 12 450 outliers rejected
+    (with the r04 generator, whose planes lay inside each other's truncation threshold: 6 of 10; tools/plane_trace.py)."""
+    one = _loop(1, init="stable")
+    assert one["planes_recovered"] >= 9 and one["ari"] >= 0.95 and 10 <= one["clusters"] <= 11, one

@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 mh = importlib.import_module("multi-h_amd")
 import oracle_lib as O
 N, K = int(os.environ.get("N", 50000)), int(os.environ.get("K", 10))
-t0 = time.time(); sc = mh.synth.make_scene(N, K, seed=1234); print(f"scene {time.time()-t0:.1f}s, hits {sc.hit_col.size}")
+# LEGACY=1: the r04 generator (planes inside each other's truncation threshold: the HARD instances of the max-flows)
+t0 = time.time(); sc = mh.synth.make_scene(N, K, seed=1234, legacy_r04=bool(os.environ.get("LEGACY"))); print(f"scene {time.time()-t0:.1f}s ({'r04 generator' if os.environ.get('LEGACY') else 'current generator'}), hits {sc.hit_col.size}")
 e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2)
 t0 = time.time(); e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col); print(f"graph upload {time.time()-t0:.2f}s")
