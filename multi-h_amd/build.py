@@ -28,7 +28,8 @@ ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 KERNEL_SOURCES = ["residual.hip", "dlt4.hip", "datacost.hip", "reestimate.hip", "expand.hip",
-                  "knn.hip", "graph.hip", "fund.hip", "meanshift.hip", "refine.hip", "select.hip", "score32.hip", "compat.hip", "capi.hip"]
+                  "knn.hip", "graph.hip", "fund.hip", "meanshift.hip", "refine.hip", "select.hip", "score32.hip", "compat.hip",
+                  "capi.hip", "capi_front.hip", "capi_score.hip", "capi_select.hip", "capi_label.hip"]
 
 
 def _newer(target: str, deps: list[str]) -> bool:
