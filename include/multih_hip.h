@@ -155,7 +155,9 @@ MH_API int mh_get_samples(mh_engine* e, int* idx /* m x 4, valid after mh_propos
  *   MH_RESIDUAL_FORWARD   d2 = |H p1 - p2|^2 — the reference's formula (M/MultiH.cpp:434-441), default;
  *   MH_RESIDUAL_SYMMETRIC d2 = |H p1 - p2|^2 + |H^-1 p2 - p1|^2 — north_star's "symmetric transfer",
  *                         an extension with no reference counterpart (H^-1 = adjugate, same rounding
- *                         discipline).  Data cost / labeling always use the forward formula. */
+ *                         discipline; the definition is checked in exact rationals, tests/test_symmetric_exact.py).
+ *                         Used by mh_score, mh_residual_matrix, mh_get_residual_rows and (r05) mh_select_greedy;
+ *                         data cost / labeling always use the forward formula. */
 enum { MH_RESIDUAL_FORWARD = 0, MH_RESIDUAL_SYMMETRIC = 1 };
 MH_API int mh_set_residual_mode(mh_engine* e, int mode);
 /* Inlier count of every current model over all points, forward transfer error, strict
@@ -214,13 +216,13 @@ MH_API int mh_set_transport(mh_engine* e, int rank, int world, mh_allgather_stre
  * point_mask (n bytes, nullable = all ones): in = points that may support a model, out = points no selected model
  * explains.  H_out: max_models x 9; counters_out / counts_out (nullable): position of each selected hypothesis in the
  * whole batch and its inlier count when selected.  Per round the host reads five control words from mapped memory; no
- * host<->device copy is issued inside the loop (mh_get_copy_stats).  Forward transfer error only (MH_ERR_INVALID in
- * symmetric mode).
+ * host<->device copy is issued inside the loop (mh_get_copy_stats).  Scores AND claims on the engine's residual mode
+ * (r05: the symmetric transfer error too; until r04 the mode was refused).
  * Sharded batch (a transport is set; total_m = size of the whole batch, 0 = the resident set is the whole batch): in the
  * first round the ranks all-gather their int32 score vectors (north_star's exchange); in every round they all-gather
  * one 88-byte record each — {best score and its position, that hypothesis' H, an error word} — and pick the same
  * winner.  Outputs do not depend on the number of ranks.  A rank-local failure (the state of that rank's engine: wrong
- * shard size, symmetric mode, a failing scoring launch) does not keep the rank out of the round's collectives: it offers
+ * shard size, a failing scoring launch) does not keep the rank out of the round's collectives: it offers
  * nothing, sets the record's error word, and after the exchange every rank leaves the loop — the failing one with its
  * own error, the others with MH_ERR_HIP "a rank reported an error".  Arguments (thr2, need, max_models, total_m) must be
  * the same on every rank. */
@@ -245,7 +247,12 @@ MH_API int mh_adopt_prefetched(mh_engine* e);
  * path: the next sweep starts at once and writes the engine's other counts buffer (after such a call MH_BUF_COUNTS is
  * undefined until the next scoring call).  A later call with outputs — before anything else has been scored — or
  * mh_synchronize completes it; the ranks' send buffer is the batch's own counts buffer (no padding kernel).  The
- * host-synchronised transport runs the same steps on the main stream. */
+ * host-synchronised transport runs the same steps on the main stream.
+ * Whether a call is a NEW exchange is decided from state that is the same on every rank (r05): the model-set generation
+ * the last exchange belongs to and whether a scoring call has been made since — on an empty shard the scoring entry points
+ * are no-ops that succeed and count.  The ranks make the same calls; a rank-local failure (a model set that is not the
+ * rank's shard, an unscored batch) travels through the collective as an error marker: that rank returns its own error,
+ * every other rank's next fetch fails with MH_ERR_HIP "a rank reported an error", none is left waiting. */
 MH_API int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* best_count);
 /* mh_score and mh_select_greedy decide most (point, model) pairs in FP32 with a rigorous error bound and only the pairs
  * within that bound of the threshold in FP64 (csrc/score32.hip; the counts are the FP64 formula's, bit for bit).  pairs:
@@ -275,8 +282,11 @@ MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int*
  * relabel/push rounds that began with fewer than 64 solver rows still holding excess (the tail of a move), 20 restarts of
  * the expansion after a grid-barrier timeout (a GPU shared with other persistent launches: each restart halves the
  * solver's workgroups; results never depend on their number), 21 workgroups of the solver launch in the attempt that
- * completed, 22 moves solved inside one XCD (small cores), 23 the longest single wait at a grid barrier in microseconds (the give-up time of
- * the next expansion's first attempts is max(20 ms, 50 x the longest such wait the engine has seen); only the last attempt waits 3 s)}. */
+ * completed, 22 restarts of all expansions of this engine so far, 23 the longest single wait at a grid barrier in microseconds (the give-up time of
+ * the next expansion's first attempts is max(20 ms, 50 x the longest such wait the engine has seen); r05: the FIRST barrier of a
+ * launch — the one that waits for every workgroup to be dispatched — gets max(250 ms, ten times that), a timed-out attempt is
+ * repeated once with the same grid before the grid is halved, word 22 = restarts of all expansions of this engine so far; only
+ * the last attempt waits 3 s)}. */
 MH_API int mh_get_expand_stats(mh_engine* e, long long stats[24]);
 /* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid

@@ -1,6 +1,8 @@
 // capi_front.hip: epipolar front half, per-point homographies, mean shift — part of the C ABI of include/multih_hip.h (see capi_engine.hpp for the split).
 #include "capi_engine.hpp"
 
+#include <unordered_map>
+
 namespace {
 
 // cyclic Jacobi, 3x3 symmetric (host copy of the device solver's recurrence)
@@ -254,13 +256,24 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     int unvisited = n;
     // MULTIH_MS_STATS=1: where the call's time goes (a line on stderr at the end) — diagnostic
     const bool ms_stats = std::getenv("MULTIH_MS_STATS") != nullptr;
-    double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0;
+    double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0, st_apply_us = 0;
+    const auto t_call = std::chrono::steady_clock::now();
     long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0, st_G = 0;
     std::vector<std::pair<int, int>> st_climbs;              // (iterations, rows touched) of every climb
-    if (ms_stats) { HIPCHK(e->ms_ticks.reserve(4)); HIPCHK(hipMemsetAsync(e->ms_ticks.p, 0, sizeof(unsigned long long) * 4, e->stream)); }
+    if (ms_stats) { HIPCHK(e->ms_ticks.reserve(5)); HIPCHK(hipMemsetAsync(e->ms_ticks.p, 0, sizeof(unsigned long long) * 5, e->stream)); }
     std::vector<double> cent;                                       // modes, d values each
     int n_cent = 0;
-    std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: sorted (row, votes)
+    std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: (row, votes), unordered
+    std::vector<int> pos(n, -1);                                    // scratch: row -> position in the list being merged into
+    // modes binned by their first coordinate (cells of bandWidth / 2; anything beyond +-2^50 cells — rows parked at 1e300 —
+    // shares one catch-all cell, where every centroid is a candidate for every other)
+    std::unordered_map<long long, std::vector<int>> bins;
+    const long long cell_of_special = (1ll << 62);
+    const double inv_half = 2.0 / band_width;
+    auto cell_of = [&](double x) -> long long {
+        const double c = std::floor(x * inv_half);
+        return (c > -0x1p50 && c < 0x1p50) ? (long long)c : cell_of_special;      // (false for NaN too)
+    };
     unsigned long long counter = 0;
     while (unvisited > 0) {
         // the batch: MS_BATCH seeds drawn from the rows unvisited now (:55-56 for each draw); a small tail draws fewer
@@ -345,6 +358,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         // the reference's terms and is dropped
         if (ms_stats)
             for (int b = 0; b < climbs; ++b) st_climbs.emplace_back(e->h_ms[b].out[0], e->h_ms[b].out[2]);
+        const auto t_apply = std::chrono::steady_clock::now();
         for (int b = 0; b < climbs; ++b) {
             const int st = starts[b];
             if (visited[st]) continue;
@@ -368,42 +382,60 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                 mine[k] = { list[2 * k], list[2 * k + 1] };
                 if (!visited[list[2 * k]]) { mark_visited(list[2 * k]); --unvisited; }
             }
-            std::sort(mine.begin(), mine.end());
+            // (r05: the lists stay in the order the device compacted them — nothing below depends on it; sorting them was a
+            // third of the host's share of a call at 50 000 rows)
             if (!out[1]) {
                 if (!visited[st]) { mark_visited(st); --unvisited; }    // climb that captured no row
                 continue;
             }
             int merge_with = -1;
-            // :101-109, first centroid with sqrt(sum) < bandWidth/2.  The running sum of squares only grows, so a
-            // centroid is rejected as soon as it exceeds the squared limit by a safe margin; the deciding comparison
-            // is the reference's own.
+            // :101-109, first centroid with sqrt(sum) < bandWidth/2.  r05: the centroids are binned by their first coordinate
+            // in cells of bandWidth/2 — a centroid that passes differs by less than that in EVERY coordinate, so it lies in
+            // the mean's cell or a neighbouring one — and the candidates are tested with the reference's own comparison, the
+            // lowest index winning; the scan over all centroids was quadratic in the number of modes (5 500 at 50 000 rows).
             const double half = band_width / 2, reject = half * half * (1.0 + 1e-9);
-            for (int cn = 0; cn < n_cent && merge_with < 0; ++cn) {
-                const double* c = cent.data() + (size_t)cn * d;
-                double sq = 0.0;
-                int j = 0;
-                for (; j < d && sq <= reject; ++j) { const double x = mean[j] - c[j]; sq = sq + x * x; }
-                if (j == d && std::sqrt(sq) < half) merge_with = cn;
+            const long long cell0 = cell_of(mean[0]);
+            for (long long cell = cell0 - 1; cell <= cell0 + 1; ++cell) {
+                const auto it = bins.find(cell);
+                if (it == bins.end()) continue;
+                for (const int cn : it->second) {
+                    if (merge_with >= 0 && cn > merge_with) continue;
+                    const double* c = cent.data() + (size_t)cn * d;
+                    double sq = 0.0;
+                    int j = 0;
+                    for (; j < d && sq <= reject; ++j) { const double x = mean[j] - c[j]; sq = sq + x * x; }
+                    if (j == d && std::sqrt(sq) < half) merge_with = cn;
+                }
+                if (cell == cell_of_special) break;                       // (the catch-all cell has no neighbours)
             }
             if (merge_with > -1) {
                 double* c = cent.data() + (size_t)merge_with * d;
+                const long long before = cell_of(c[0]);
                 for (int j = 0; j < d; ++j) c[j] = 0.5 * (c[j] + mean[j]);
-                std::vector<std::pair<int, int>> merged;
-                const auto& a = votes[merge_with];
-                size_t i = 0, k = 0;
-                while (i < a.size() || k < mine.size()) {
-                    if (k >= mine.size() || (i < a.size() && a[i].first < mine[k].first)) merged.push_back(a[i++]);
-                    else if (i >= a.size() || mine[k].first < a[i].first) merged.push_back(mine[k++]);
-                    else { merged.push_back({ a[i].first, a[i].second + mine[k].second }); ++i; ++k; }
+                const long long after = cell_of(c[0]);
+                if (after != before) {
+                    auto& vb = bins[before];
+                    vb.erase(std::find(vb.begin(), vb.end(), merge_with));
+                    bins[after].push_back(merge_with);
                 }
-                votes[merge_with].swap(merged);
+                // votes of the two lists added row by row through a row -> position index (no order needed)
+                auto& a = votes[merge_with];
+                for (size_t i = 0; i < a.size(); ++i) pos[a[i].first] = (int)i;
+                for (const auto& pr : mine) {
+                    if (pos[pr.first] >= 0) a[pos[pr.first]].second += pr.second;
+                    else { pos[pr.first] = (int)a.size(); a.push_back(pr); }
+                }
+                for (const auto& pr : a) pos[pr.first] = -1;
             } else {
                 cent.insert(cent.end(), mean, mean + d);
+                bins[cell0].push_back(n_cent);
                 ++n_cent;
-                votes.push_back(mine);
+                votes.push_back(std::move(mine));
             }
         }
+        if (ms_stats) st_apply_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_apply).count();
     }
+    const auto t_final = std::chrono::steady_clock::now();
     std::vector<int> best_votes(n, 0);
     for (int i = 0; i < n; ++i) assign[i] = -1;
     for (size_t r = 0; r < votes.size(); ++r)                       // :133-146, first maximum wins
@@ -412,10 +444,10 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     *n_modes = n_cent;
     if (modes) std::copy(cent.begin(), cent.begin() + (size_t)std::min(n_cent, max_modes) * d, modes);
     if (ms_stats) {
-        unsigned long long tk[4] = { 0, 0, 0, 0 };
+        unsigned long long tk[5] = { 0, 0, 0, 0, 0 };
         (void)hipMemcpy(tk, e->ms_ticks.p, sizeof(tk), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[mh_mean_shift] persistent kernel, first climb's first workgroup: gate %.1f ms, sweep + tree + partial stores %.1f ms, barrier %.1f ms, "
-                        "new mean %.1f ms; mean G %.1f\n", tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, st_persist_rounds ? (double)st_G / st_persist_rounds : 0.0);
+        fprintf(stderr, "[mh_mean_shift] persistent kernel, first climb's first workgroup: gate %.1f ms, row load %.1f ms, sweep + tree + partial stores %.1f ms, barrier %.1f ms, "
+                        "new mean %.1f ms; mean G %.1f\n", tk[4] * 1e-5, tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, st_persist_rounds ? (double)st_G / st_persist_rounds : 0.0);
     }
     if (ms_stats && !st_climbs.empty()) {
         // how long the climbs are and how many rows they touch: is the tail made of dense or of sparse climbs?
@@ -431,6 +463,10 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             lo = edges[q];
         }
     }
+    if (ms_stats)
+        fprintf(stderr, "[mh_mean_shift] host: applying the batches' climbs (lists, visited set, vote merging) %.1f ms; final assignment %.1f ms; whole call %.1f ms\n",
+                st_apply_us * 1e-3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_final).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
     if (ms_stats)
         fprintf(stderr, "[mh_mean_shift] n %d: %lld batches; launched rounds %lld (%.1f ms, of which rounds after the first %.1f ms on %lld climb-rounds); "
                         "persistent rounds %lld (%.1f ms, %lld climbs, longest climbs %lld iterations in sum = %.1f us per iteration)\n",

@@ -185,14 +185,14 @@ struct MeanShiftPersist {
     int* arrive;             // [climb] monotonic arrival counter of the iteration barriers; zero on entry
     double* partial2;        // [climb][2][MS_GROUPS][16]
     int* partial_cnt2;       // [climb][2][MS_GROUPS]
-    int* fell_back;          // [climb] set when the gate closed (the climb's state is untouched)
+    int* fell_back;          // [climb] the gate's verdict: 1 = closed before everybody was there (the climb's state is untouched), 2 = open
     unsigned long long* ticks;   // nullable diagnostic: 100 MHz ticks of the first climb's first workgroup in {gate + row load, sweep + tree, barrier, new mean}
 };
 constexpr int MS_GATE_CLOSED = 1 << 30;
 constexpr int MS_CACHED_ROWS = 4;
 
 // (three waves per SIMD: 168 registers — the 10-D form would take 203 and leave room for two; it spills 15 of them into 60 bytes)
-template <int D>
+template <int D, bool TIMED>
 __global__ void __launch_bounds__(256, 3)
 k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int groups, double band_sq, double stop_thresh,
              int max_iters, unsigned long long gate_timeout)
@@ -209,33 +209,44 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
     __shared__ int s_flag, s_in, s_conv;
     __shared__ double s_mean[MS_MAXD], s_move[MS_MAXD];
 
-    const bool timed = ps.ticks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
-    unsigned long long tk[4] = { 0, 0, 0, 0 }, tk0 = __builtin_amdgcn_s_memrealtime();
-    auto lap = [&](int which) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tk[which] += now - tk0; tk0 = now; };
+    // TIMED (MULTIH_MS_STATS): phase ticks of the first climb's first workgroup; compiled out of the product instantiation
+    const bool timed = TIMED && ps.ticks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    unsigned long long tk[TIMED ? 5 : 1] = {}, tk0 = TIMED ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto lap = [&](int which) { if (TIMED) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tk[TIMED ? which : 0] += now - tk0; tk0 = now; } };
     // ---- the gate ----
-    // One word: arrivals in the low bits, MS_GATE_CLOSED on top.  A workgroup arrives with a compare-and-swap that refuses a
-    // closed gate, so arrivals never grow once the bit is set: (G arrivals, bit or no bit) = everybody was there before
-    // anybody gave up -> open for all; (fewer than G, bit) -> closed for all.
+    // gate word: arrivals in the low bits (one atomicAdd per workgroup — a compare-and-swap loop of 64 workgroups on one
+    // word cost 100 us per launch), MS_GATE_CLOSED on top; verdict word: written once by whoever closes the gate.  Open for
+    // all: G arrivals seen with the bit clear, or the closer found G arrivals in the word it closed (nobody can be missing
+    // then).  Closed for all: the closer found fewer — workgroups that arrive later find the bit in what their atomicAdd
+    // returns, waiters find it in what they poll, and all of them follow the verdict.
     if (t == 0) {
         int* gate = ps.gate + climb;
-        int v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {
-            if (v & MS_GATE_CLOSED) break;
-            const int seen = atomicCAS(gate, v, v + 1);
-            if (seen == v) { v = v + 1; break; }
-            v = seen;
-        }
+        int* verdict = ps.fell_back + climb;                // 0 = none yet, 1 = closed (fall back), 2 = open after all
+        int v = atomicAdd(gate, 1) + 1;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
-        while ((v & (MS_GATE_CLOSED - 1)) < G && !(v & MS_GATE_CLOSED)) {
-            __builtin_amdgcn_s_sleep(2);
-            v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > gate_timeout) { v = atomicOr(gate, MS_GATE_CLOSED) | MS_GATE_CLOSED; break; }
+        int open = -1;
+        while (open < 0) {
+            if (v & MS_GATE_CLOSED) {
+                int d = 0;
+                while ((d = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(2);
+                open = d == 2 ? 1 : 0;
+            } else if ((v & (MS_GATE_CLOSED - 1)) >= G) {
+                open = 1;
+            } else if (__builtin_amdgcn_s_memrealtime() - t0 > gate_timeout) {
+                const int old = atomicOr(gate, MS_GATE_CLOSED);
+                if (old & MS_GATE_CLOSED) { v = old; continue; }            // somebody else closed it: follow their verdict
+                open = (old & (MS_GATE_CLOSED - 1)) >= G ? 1 : 0;
+                __hip_atomic_store(verdict, open ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        s_flag = ((v & (MS_GATE_CLOSED - 1)) >= G) ? 1 : 0;
-        if (!s_flag) __hip_atomic_store(ps.fell_back + climb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag = open;
     }
     __syncthreads();
     if (!s_flag) return;
+    lap(4);
 
     // ---- my rows, once ----
     double r[MS_CACHED_ROWS][D];
@@ -264,29 +275,28 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
     for (int it = 0; it < max_iters; ++it) {
         double* part = ps.partial2 + ((size_t)climb * 2 + (it & 1)) * MS_GROUPS * MS_MAXD;
         int* pcnt = ps.partial_cnt2 + ((size_t)climb * 2 + (it & 1)) * MS_GROUPS;
-        double old[D], acc[D];
+        double acc[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) { old[j] = s_mean[j]; acc[j] = 0.0; }
+        for (int j = 0; j < D; ++j) acc[j] = 0.0;
         int cnt = 0;
 #pragma unroll
         for (int k = 0; k < MS_CACHED_ROWS; ++k) {
             if (k < nr) {
-                // (the membership test of k_ms_iterate, operation for operation: |r| for sqrt(r * r) where that is exact)
+                // (the membership test of k_ms_iterate, operation for operation: |r| for sqrt(r * r) where that is exact; the
+                // mean comes from LDS — broadcast reads — so that it does not occupy twenty registers beside the rows)
                 double dist = 0.0;
                 bool plain = true;
-                double a[D];
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    a[j] = fabs(old[j] - r[k][j]);
-                    plain = plain && (a[j] <= 0x1p500) && (a[j] >= 0x1p-500 || a[j] == 0.0);
+                    const double a = fabs(s_mean[j] - r[k][j]);
+                    plain = plain && (a <= 0x1p500) && (a >= 0x1p-500 || a == 0.0);
+                    dist += a;
                 }
-                if (__builtin_expect(plain, 1)) {
-#pragma unroll
-                    for (int j = 0; j < D; ++j) dist += a[j];
-                } else {
+                if (__builtin_expect(!plain, 0)) {
                     asm volatile("; mean shift: sqrt path");
+                    dist = 0.0;
 #pragma unroll
-                    for (int j = 0; j < D; ++j) { const double q = old[j] - r[k][j]; dist += sqrt(q * q); }
+                    for (int j = 0; j < D; ++j) { const double q = s_mean[j] - r[k][j]; dist += sqrt(q * q); }
                 }
                 if (dist < band_sq) {
 #pragma unroll
@@ -308,16 +318,32 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
             for (int j = 0; j < D; ++j) sv[j][t] = acc[j];
             sc[t] = cnt;
             __syncthreads();
-            for (int s = 128; s >= 1; s >>= 1) {
-                if (t < s) {
+            // the tree of k_ms_iterate: levels 128 and 64 pair lanes of different waves (through LDS), levels 32 .. 1 pair
+            // lane l with lane l + s of ONE wave — the same two operands, added once (a + b = b + a), fetched with a lane
+            // shuffle instead of an LDS round trip and a workgroup barrier per level
+            if (t < 128) {
 #pragma unroll
-                    for (int j = 0; j < D; ++j) sv[j][t] = sv[j][t] + sv[j][t + s];
-                    sc[t] += sc[t + s];
-                }
-                __syncthreads();
+                for (int j = 0; j < D; ++j) sv[j][t] = sv[j][t] + sv[j][t + 128];
+                sc[t] += sc[t + 128];
             }
-            if (t < D) put_sum(t, sv[t][0]);
-            if (t == 0) __hip_atomic_store(pcnt + b, sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (t < 64) {
+                double v[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) v[j] = sv[j][t] + sv[j][t + 64];
+                int c = sc[t] + sc[t + 64];
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) v[j] = v[j] + __shfl_down(v[j], s, 64);     // (lanes >= s compute values nobody reads)
+                    c += __shfl_down(c, s, 64);
+                }
+                if (t == 0) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) put_sum(j, v[j]);
+                    __hip_atomic_store(pcnt + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         // ---- the climb's barrier: my partials have landed, then everybody's ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -335,7 +361,7 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
         // 64 of them held in registers by each of D lanes cost the kernel a wave per SIMD
         double* flat = &sv[0][0];                           // (D x 256 doubles >= 64 x 16; the tree is done with it)
         for (int idx = t; idx < G * MS_MAXD; idx += 256)
-            flat[idx] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part) + idx,
+            if ((idx & (MS_MAXD - 1)) < D) flat[idx] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part) + idx,
                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         int in = 0;
         if (t < 64) {
@@ -372,7 +398,7 @@ k_ms_persist(MeanShiftWork all, MeanShiftActive active, MeanShiftPersist ps, int
 #pragma unroll
     for (int k = 0; k < MS_CACHED_ROWS; ++k)
         if (k < nr && vote[k]) w.votes[b * 256 + t + k * T] += vote[k];
-    if (timed) for (int q = 0; q < 4; ++q) atomicAdd(ps.ticks + q, tk[q]);
+    if (TIMED && timed) for (int q = 0; q < 5; ++q) atomicAdd(ps.ticks + q, tk[TIMED ? q : 0]);
     if (blockIdx.x == 0) {                                  // one workgroup writes the climb's state back
         if (t < D) w.mean[t] = s_mean[t];
         if (t == 0) {
@@ -476,10 +502,11 @@ hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& acti
     if (he != hipSuccess) return he;
     MeanShiftPersist ps{ ctl, ctl + MS_BATCH, partial2, partial_cnt2, ctl + 2 * MS_BATCH, ticks };
     const unsigned long long gate_timeout = 25000000ull;    // 250 ms at 100 MHz
-    if (w.d == 10)
-        hipLaunchKernelGGL(k_ms_persist<10>, dim3(groups, n_active), dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
-    else
-        hipLaunchKernelGGL(k_ms_persist<6>, dim3(groups, n_active), dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
+    const dim3 grid(groups, n_active);
+    if (w.d == 10 && ticks) hipLaunchKernelGGL((k_ms_persist<10, true>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
+    else if (w.d == 10) hipLaunchKernelGGL((k_ms_persist<10, false>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
+    else if (ticks) hipLaunchKernelGGL((k_ms_persist<6, true>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
+    else hipLaunchKernelGGL((k_ms_persist<6, false>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
     hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
     hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
     return hipGetLastError();
@@ -492,8 +519,8 @@ bool ms_persist_supported(int n, int d) { return (d == 10 || d == 6) && n <= MS_
 int ms_persist_occupancy(int d)
 {
     int per_cu = 0;
-    const hipError_t he = d == 10 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist<10>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist<6>, 256, 0);
+    const hipError_t he = d == 10 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist<10, false>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_persist<6, false>, 256, 0);
     return he == hipSuccess ? per_cu : 0;
 }
 
