@@ -339,7 +339,11 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * many point slices (0, default: model block fastest, ~37 500 items), 27 the same order for the resident cost-matrix kernel,
  * 28 experiment: the cost-matrix kernel evaluates the near pairs of several models together (same matrix; slower) — schedule only,
  * 29 mean shift: once at most this many climbs of a batch are still running they run to their end in one persistent launch
- * (default 12, and never more than are resident at once; 0 = a launch per iteration throughout) — schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * (default 12, and never more than are resident at once; 0 = a launch per iteration throughout) — schedule only,
+ * 30 NOT schedule-only: mh_select_greedy refits every round's winner to the correspondences of the support set it explains
+ * (the loop's per-label HAF least squares, M/MultiH.cpp:913-989, with one label; needs affinities and the epipolar geometry)
+ * before it claims them, and the refit takes the hypothesis' place in H_out when it is finite and explains at least as many
+ * (0 = off, the default of the engine; class MultiH switches it on: SetProposalRefit).  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

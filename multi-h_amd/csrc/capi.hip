@@ -414,7 +414,8 @@ void mh_destroy(mh_engine* e)
     if (e->h_sel) (void)hipHostFree(e->h_sel);
     for (int b = 0; b < 2; ++b) { e->sel_orig[b].release(); e->sel_cand_H[b].release(); }
     e->sel_counts.release(); e->sel_rec.release(); e->sel_scores.release(); e->sel_gathered.release(); e->sel_out_H.release();
-    e->sel_records.release(); e->sel_counter.release(); e->sel_keys.release();
+    e->sel_records.release(); e->sel_counter.release(); e->sel_keys.release(); e->sel_refit.release(); e->sel_refit_ctr.release();
+    e->ms_partial2.release(); e->ms_ctl.release(); e->ms_pcnt2.release(); e->ms_ticks.release();
     for (int q = 0; q < mh_engine::PF_DEPTH; ++q) { e->pf_H[q].release(); e->pf_samples[q].release(); if (e->pf_ev[q]) (void)hipEventDestroy(e->pf_ev[q]); }
     e->best_key.release(); e->H32.release(); e->fb_pairs.release();
     if (e->h_best) (void)hipHostFree(e->h_best);
@@ -736,7 +737,8 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
-    if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }       // mean shift: persistent tail below this many climbs (0 = off)
+    if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }
+    if (key == 30 && (value == 0 || value == 1)) { e->tune_select_refine = value; return MH_OK; }     // NOT schedule-only: changes what mh_select_greedy selects       // mean shift: persistent tail below this many climbs (0 = off)
     if (key == 8 && value >= 0 && value <= (1 << 20)) { e->trace_moves = value; return MH_OK; }
     if (key == 9 && value >= -1) { e->detail_move = value; return MH_OK; }
     if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }

@@ -164,6 +164,9 @@ struct mh_engine {
     DevBuf<unsigned long long> ms_ticks;     // MULTIH_MS_STATS: phase ticks of the persistent kernel
     DevBuf<int> ms_ctl, ms_pcnt2;            // the persistent tail of a mean-shift batch (meanshift.hip, k_ms_persist)
     int ms_persist_per_cu = -1, ms_persist_per_cu6 = -1;   // workgroups of k_ms_persist<10> / <6> a compute unit holds (-1: not queried; a failed query is not kept)
+    int tune_select_refine = 0;              // key 30: mh_select_greedy refits each round's winner to its inliers before the claim (0 = off)
+    DevBuf<double> sel_refit;                // the refit (9 doubles) and its inlier count
+    DevBuf<int> sel_refit_ctr;
     int tune_ms_persist = 12;                // key 29: the tail runs persistently once at most this many climbs are left (0 = never)
     long long ms_persist_launches = 0, ms_persist_fallbacks = 0, ms_rounds = 0;
 

@@ -89,6 +89,16 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     // r05: the selection follows the engine's residual mode — scores (score_models) and claims (k_sel_claim) both on the
     // symmetric transfer error when that is set; the ranks of a sharded batch must agree (their records carry the mode)
     const int symmetric = e->residual_mode == MH_RESIDUAL_SYMMETRIC ? 1 : 0;
+    // r05, key 30: each round's winner is refitted to its inliers before it claims them (select.hip, launch_sel_refit).  Needs the
+    // affinities and the epipolar geometry (the per-label HAF least squares of the loop); a setting, like thr2, that the ranks share.
+    const bool refine = e->tune_select_refine != 0;
+    if (refine && (!e->have_aff || !e->have_epi))
+        return fail(MH_ERR_NOT_SET, "mh_select_greedy with refitted winners (mh_set_tuning key 30) needs affinities and the epipolar geometry");
+    if (refine) {
+        HIPCHK(e->labels_pts.reserve((size_t)n));
+        HIPCHK(e->sel_refit.reserve(10));
+        HIPCHK(e->sel_refit_ctr.reserve(2));
+    }
     if (!sharded && M <= 0) local_failure(MH_ERR_NOT_SET, "model set is empty");
     else if (M != mine) local_failure(MH_ERR_INVALID, "the resident model set is not this rank's shard of total_m hypotheses");
     if (local_rc != MH_OK && !sharded) return fail(local_rc, local_msg);
@@ -179,8 +189,16 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         }
         HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, records, world, my_off, e->sel_orig[cur ^ 1].p,
                                   e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, s));
+        const double* refit = nullptr;
+        if (refine) {
+            // every rank holds all the points and the same records: the refit is computed redundantly, identically
+            Affines aff{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
+            HIPCHK(launch_sel_refit(e->pts(), aff, e->epi, records, world, thr2, need, e->mask.p, e->labels_pts.p, e->sel_refit.p,
+                                    e->sel_refit_ctr.p, e->sel_refit_ctr.p + 1, s, symmetric));
+            refit = e->sel_refit.p;
+        }
         HIPCHK(launch_sel_claim(e->pts(), records, world, gather_scores && !local_err ? key_check : nullptr, thr2, need, e->mask.p, e->sel_rec.p,
-                                e->sel_out_H.p, e->sel_counter.p, max_models, s, symmetric));
+                                e->sel_out_H.p, e->sel_counter.p, max_models, s, symmetric, refit));
         HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, my_record, need, e->h_sel_dev, s));
         HIPCHK(hipStreamSynchronize(s));                 // five control words through mapped memory: no copy
         if (local_rc != MH_OK) return fail(local_rc, local_msg);     // (the others have read this rank's error word by now)

@@ -238,7 +238,13 @@ hipError_t launch_sel_compact(const int* counts, const int* orig, const double* 
                               int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, hipStream_t s);
 hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
-                            hipStream_t s, int symmetric = 0);
+                            hipStream_t s, int symmetric = 0, const double* refit = nullptr);
+// r05 (mh_set_tuning key 30): the round's winner refitted to its inliers in the support set by the per-label HAF least squares
+// (one label); refit = 9 doubles + the refit's inlier count; launch_sel_claim takes it in the winner's place when it is finite and
+// explains at least as many points.  labels: n ints, counter / label_count: one int each (scratch).
+hipError_t launch_sel_refit(const Points& p, const Affines& a, const Epipolar& ep, const SelRecord* records, int world, double thr2,
+                            int need, const unsigned char* mask, int* labels, double* refit, int* counter, int* label_count,
+                            hipStream_t s, int symmetric);
 hipError_t launch_sel_publish(int* rec, unsigned long long* keys, SelRecord* my_record, int need, int* h_rec_dev, hipStream_t s);
 hipError_t launch_best_publish(unsigned long long* key, int* h_best_dev, hipStream_t s);
 hipError_t launch_best_fused(int* scores, int world, int longest, int base, int rem, int* h_best_dev, int* clear,

@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256)
 k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
             const double* __restrict__ y2, int N, const SelRecord* __restrict__ records, int world,
             const unsigned long long* __restrict__ key_check, double thr2, int need, unsigned char* __restrict__ mask,
-            int* __restrict__ rec, double* __restrict__ sel_H, long long* __restrict__ sel_counter, int max_models, int symmetric)
+            int* __restrict__ rec, double* __restrict__ sel_H, long long* __restrict__ sel_counter, int max_models, int symmetric,
+            const double* __restrict__ refit /* nullable: 9 doubles + the refit's inlier count as a double */)
 {
     int wr = 0;
     const unsigned long long kg = sel_winner(records, world, &wr);
@@ -162,6 +163,13 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
     const int sel = rec[3];
     if (sel >= max_models) return;
     const double* h = records[wr].H;
+    // r05: the winner refitted to its own inliers (k_sel_winner_labels -> k_haf_reestimate -> k_sel_count) takes its place
+    // when the refit is finite and explains at least as many points of the support set as the hypothesis did
+    if (refit && refit[9] >= (double)best) {
+        bool finite = true;
+        for (int q = 0; q < 9; ++q) finite = finite && fabs(refit[q]) < 0x1p1000;
+        if (finite) h = refit;
+    }
     if (n == 0) {
         for (int q = 0; q < 9; ++q) sel_H[9 * (size_t)sel + q] = h[q];
         sel_counter[sel] = (long long)pos;
@@ -177,6 +185,70 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
         d2 = d2 + fwd_d2(a0, a1, a2, a3, a4, a5, a6, a7, a8, x2[n], y2[n], x1[n], y1[n]);
     }
     if (d2 < thr2) mask[n] = 0;
+}
+
+// ---- the winner refitted to its inliers before it claims them (r05, mh_set_tuning key 30) --------------------------------
+// A hypothesis fitted to four matches explains 60-70 % of its plane at the inlier threshold; what it leaves behind is
+// raw material for a later winner that sits BETWEEN two planes.  With the refit the winner of a round is
+// re-estimated from the points of the support set it explains — the per-label HAF least squares of the loop
+// (k_haf_reestimate, reestimate.hip, M/MultiH.cpp:913-989) with one label — and the refit takes the hypothesis' place if
+// it explains at least as many points.
+// labels[n] = 0 for the winner's inliers in the support set, -1 elsewhere; refit[0..9) = the winner's H (what a label
+// without points keeps), refit[9] = 0.
+__global__ void __launch_bounds__(256)
+k_sel_winner_labels(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+                    const double* __restrict__ y2, int N, const SelRecord* __restrict__ records, int world, double thr2, int need,
+                    const unsigned char* __restrict__ mask, int* __restrict__ labels, double* __restrict__ refit, int symmetric)
+{
+    int wr = 0;
+    const unsigned long long kg = sel_winner(records, world, &wr);
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const double* h = records[wr].H;
+    if (n == 0) {
+        for (int q = 0; q < 9; ++q) refit[q] = h[q];
+        refit[9] = 0.0;
+    }
+    if (n >= N) return;
+    int lab = -1;
+    if (kg && (int)(kg >> 32) >= need && mask[n]) {
+        double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
+        if (symmetric) {
+            const double a0 = h[4] * h[8] - h[5] * h[7], a1 = h[2] * h[7] - h[1] * h[8], a2 = h[1] * h[5] - h[2] * h[4];
+            const double a3 = h[5] * h[6] - h[3] * h[8], a4 = h[0] * h[8] - h[2] * h[6], a5 = h[2] * h[3] - h[0] * h[5];
+            const double a6 = h[3] * h[7] - h[4] * h[6], a7 = h[1] * h[6] - h[0] * h[7], a8 = h[0] * h[4] - h[1] * h[3];
+            d2 = d2 + fwd_d2(a0, a1, a2, a3, a4, a5, a6, a7, a8, x2[n], y2[n], x1[n], y1[n]);
+        }
+        if (d2 < thr2) lab = 0;
+    }
+    labels[n] = lab;
+}
+
+// refit[9] = number of points of the support set inside thr of the refit (an integer count kept in a double: exact)
+__global__ void __launch_bounds__(256)
+k_sel_count(const double* __restrict__ x1, const double* __restrict__ y1, const double* __restrict__ x2,
+            const double* __restrict__ y2, int N, double thr2, const unsigned char* __restrict__ mask, double* __restrict__ refit,
+            int* __restrict__ counter, int symmetric)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const double* h = refit;
+    bool in = false;
+    if (n < N && mask[n]) {
+        double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
+        if (symmetric) {
+            const double a0 = h[4] * h[8] - h[5] * h[7], a1 = h[2] * h[7] - h[1] * h[8], a2 = h[1] * h[5] - h[2] * h[4];
+            const double a3 = h[5] * h[6] - h[3] * h[8], a4 = h[0] * h[8] - h[2] * h[6], a5 = h[2] * h[3] - h[0] * h[5];
+            const double a6 = h[3] * h[7] - h[4] * h[6], a7 = h[1] * h[6] - h[0] * h[7], a8 = h[0] * h[4] - h[1] * h[3];
+            d2 = d2 + fwd_d2(a0, a1, a2, a3, a4, a5, a6, a7, a8, x2[n], y2[n], x1[n], y1[n]);
+        }
+        in = d2 < thr2;
+    }
+    const unsigned long long m = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
+}
+
+__global__ void k_sel_count_finish(const int* __restrict__ counter, double* __restrict__ refit)
+{
+    if (threadIdx.x == 0) refit[9] = (double)*counter;
 }
 
 __global__ void k_sel_publish(int* __restrict__ rec, unsigned long long* __restrict__ keys, SelRecord* __restrict__ my_record,
@@ -318,10 +390,27 @@ hipError_t launch_sel_compact(const int* counts, const int* orig, const double* 
 
 hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
-                            hipStream_t s, int symmetric)
+                            hipStream_t s, int symmetric, const double* refit)
 {
     hipLaunchKernelGGL(k_sel_claim, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, records, world,
-                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models, symmetric);
+                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models, symmetric, refit);
+    return hipGetLastError();
+}
+
+// the round's winner refitted to its inliers: labels (n ints), refit (10 doubles), counter (1 int) are scratch of the caller
+hipError_t launch_sel_refit(const Points& p, const Affines& a, const Epipolar& ep, const SelRecord* records, int world, double thr2,
+                            int need, const unsigned char* mask, int* labels, double* refit, int* counter, int* label_count,
+                            hipStream_t s, int symmetric)
+{
+    const dim3 grid((p.n + 255) / 256);
+    hipLaunchKernelGGL(k_sel_winner_labels, grid, dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, records, world, thr2, need, mask,
+                       labels, refit, symmetric);
+    hipError_t he = launch_reestimate(p, a, labels, 1, ep, refit, label_count, s);
+    if (he != hipSuccess) return he;
+    he = hipMemsetAsync(counter, 0, sizeof(int), s);
+    if (he != hipSuccess) return he;
+    hipLaunchKernelGGL(k_sel_count, grid, dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, thr2, mask, refit, counter, symmetric);
+    hipLaunchKernelGGL(k_sel_count_finish, dim3(1), dim3(64), 0, s, counter, refit);
     return hipGetLastError();
 }
 

@@ -466,6 +466,7 @@ bool MultiH::ProposeModels(uint64_t seed, long long first, int M, int max_models
     }
     std::vector<double> H(9 * (size_t)max_models);
     int selected = 0;
+    if (!Check(mh_set_tuning(engine, 30, proposal_refit ? 1 : 0), "mh_set_tuning(30)")) return false;
     if (!Check(mh_select_greedy(engine, sqr_threshold_homography, need, max_models, mask.data(), H.data(), nullptr, nullptr,
                                 &selected, (long long)M),
                "mh_select_greedy"))
@@ -772,6 +773,10 @@ void mhh_set_neighbour_hits(const int* rowptr, const int* col, int n)
     g_hits.resize(n);
     for (int i = 0; i < n; ++i) g_hits[i].assign(col + rowptr[i], col + rowptr[i + 1]);
 }
+// MultiH::SetProposalRefit for the next mhh_run_process calls (default 1)
+static int g_proposal_refit = 1;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_proposal_refit(int on) { g_proposal_refit = on; }
 // schedule knobs (mh_set_tuning) for the engines of the next mhh_run_process calls; key < 0 clears the list
 static std::vector<std::pair<int, int>> g_tuning;
 extern "C" __attribute__((visibility("default")))
@@ -818,6 +823,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     else mh.SetSharding(g_shard_rank, g_shard_world, g_shard_fn, g_shard_ctx);
     mh.SetDevice(g_device);
     mh.SetCompatibilityCheck(g_post_filter != 0);
+    mh.SetProposalRefit(g_proposal_refit != 0);
     for (const auto& kv : g_tuning) mh.SetEngineTuning(kv.first, kv.second);
     if (g_radius > 0.0 && g_max_hits > 0) { mh.SetNeighbourRadius(g_radius, g_max_hits); if (g_knn > 0) mh.SetFallbackK(g_knn); }
     else if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);

@@ -105,6 +105,11 @@ public:
     // on the points currently labelled outlier and appends at most `max_new` models that gather
     // >= max(min inliers, 8) of them.  0 hypotheses (default) keeps the reference's behaviour.
     void SetIterativeProposal(int hypotheses, int max_new) { iter_hypotheses = hypotheses; iter_max_new = max_new; }
+    // r05: every winner of the greedy selection is refitted to the correspondences it explains — the loop's per-label HAF
+    // least squares with one label (M/MultiH.cpp:913-989) — before it claims them, and the refit takes its place when it
+    // explains at least as many (mh_set_tuning key 30).  A hypothesis fitted to four matches explains 60-70 % of its plane;
+    // what it leaves behind used to feed models that sit between two planes.  Default on.
+    void SetProposalRefit(bool on) { proposal_refit = on; }
     // Multi-GPU propose stage (BASELINE configs[3] and [4]): one process per GPU, every rank holds all
     // correspondences and owns a contiguous shard of each hypothesis batch (the hypotheses are a pure function of
     // (seed, counter), so the union over ranks is the single-GPU batch).  In the first greedy round the ranks all-gather
@@ -166,6 +171,7 @@ protected:
     uint64_t proposal_seed = 1234;
     int proposal_hypotheses = 10000;
     int proposal_max_models = 32;
+    bool proposal_refit = true;
     int fixed_iterations = 0;
     int iter_hypotheses = 0, iter_max_new = 4;
     int fundamental_hypotheses = 4000;

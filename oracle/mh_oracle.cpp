@@ -1776,6 +1776,9 @@ typedef int (*mho_expand_hook)(int N, int L, const int* cost, const int* hit_row
 // test): with n > 0 the loop below also stops after its n-th LabelingStep.  0 = the reference's stop rule alone.
 static int g_fixed_iterations = 0;
 MHO_API void mho_set_fixed_iterations(int n) { g_fixed_iterations = n; }
+// The product's MultiH::SetProposalRefit (default on since r05): mho_process's DLT route selects with refitted winners.
+static int g_select_refit = 1;
+MHO_API void mho_set_select_refit(int on) { g_select_refit = on; }
 
 MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1, const double* x2, const double* y2,
                                              const double* aff, int N, double* H, int Nh, int max_models,
@@ -1854,9 +1857,10 @@ MHO_API int mho_cluster_merging_and_labeling(const double* x1, const double* y1,
 // Sequential best-first selection over a fixed hypothesis list.  Per round: inlier counts over the points still in the
 // support set (strict d2 < thr2, the score of :430-443); the best count wins, the LOWEST hypothesis index on ties; stop
 // when the best count is below `need`; the winner's inliers leave the support set.  mask: in/out (1 = in the set).
+struct SelectRefit { const double* aff; const double* F; const double* e2; };      // non-null: refit every winner (see below)
 static int select_greedy_impl(const double* x1, const double* y1, const double* x2, const double* y2, int N,
                               const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
-                              double* H_out, long long* index_out, int* counts_out, bool symmetric);
+                              double* H_out, long long* index_out, int* counts_out, bool symmetric, const SelectRefit* refit = nullptr);
 
 MHO_API int mho_select_greedy(const double* x1, const double* y1, const double* x2, const double* y2, int N,
                               const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
@@ -1873,9 +1877,21 @@ MHO_API int mho_select_greedy_sym(const double* x1, const double* y1, const doub
     return select_greedy_impl(x1, y1, x2, y2, N, H, M, thr2, need, max_models, mask, H_out, index_out, counts_out, true);
 }
 
+// ... with every round's winner REFITTED to the points of the support set it explains before it claims them (the product's
+// mh_set_tuning key 30 / MultiH::SetProposalRefit, the default of Process()'s DLT route since r05): the per-label HAF least
+// squares of the loop (mho_haf_reestimate, M/MultiH.cpp:913-989) with one label; the refit takes the hypothesis' place when
+// it is finite and explains at least as many points of the support set.
+MHO_API int mho_select_greedy_refit(const double* x1, const double* y1, const double* x2, const double* y2, const double* aff, int N,
+                                    const double* F, const double* e2, const double* H, int M, double thr2, int need, int max_models,
+                                    unsigned char* mask, double* H_out /* max_models*9 */, long long* index_out, int* counts_out)
+{
+    const SelectRefit r{ aff, F, e2 };
+    return select_greedy_impl(x1, y1, x2, y2, N, H, M, thr2, need, max_models, mask, H_out, index_out, counts_out, false, &r);
+}
+
 static int select_greedy_impl(const double* x1, const double* y1, const double* x2, const double* y2, int N,
                               const double* H, int M, double thr2, int need, int max_models, unsigned char* mask,
-                              double* H_out, long long* index_out, int* counts_out, bool symmetric)
+                              double* H_out, long long* index_out, int* counts_out, bool symmetric, const SelectRefit* refit)
 {
     auto score = symmetric ? mho_score_sym : mho_score;
     int selected = 0;
@@ -1893,6 +1909,24 @@ static int select_greedy_impl(const double* x1, const double* y1, const double* 
         for (int m = 0; m < M; ++m) if (counts[m] > best) { best = counts[m]; bm = m; }
         if (bm < 0 || best < need) break;
         const double* h = H + 9 * (size_t)bm;
+        double hr[9];
+        if (refit) {
+            auto d2_of = [&](const double* g, int i) {
+                if (!symmetric) return fwd_d2(g, x1[i], y1[i], x2[i], y2[i]);
+                double ga[9];
+                adjugate(g, ga);
+                return fwd_d2(g, x1[i], y1[i], x2[i], y2[i]) + fwd_d2(ga, x2[i], y2[i], x1[i], y1[i]);
+            };
+            std::vector<int> lab(N, -1);
+            for (int i = 0; i < N; ++i) if (mask[i] && d2_of(h, i) < thr2) lab[i] = 0;
+            for (int q = 0; q < 9; ++q) hr[q] = h[q];
+            mho_haf_reestimate(x1, y1, x2, y2, refit->aff, N, lab.data(), 1, refit->F, refit->e2, hr, nullptr);
+            bool finite = true;
+            for (int q = 0; q < 9; ++q) finite = finite && std::fabs(hr[q]) < 0x1p1000;
+            int c = 0;
+            if (finite) for (int i = 0; i < N; ++i) if (mask[i] && d2_of(hr, i) < thr2) ++c;
+            if (finite && c >= best) h = hr;
+        }
         for (int q = 0; q < 9; ++q) H_out[9 * (size_t)selected + q] = h[q];
         if (index_out) index_out[selected] = bm;
         if (counts_out) counts_out[selected] = best;
@@ -2074,8 +2108,11 @@ MHO_API int mho_process(const double* x1, const double* y1, const double* x2, co
         mho_sample4(seed, 0, hypotheses, N, idx.data());
         mho_dlt4(x1, y1, x2, y2, idx.data(), hypotheses, Hh.data(), nullptr, nullptr);
         std::vector<unsigned char> mask(N, 1);
-        nh = mho_select_greedy(x1, y1, x2, y2, N, Hh.data(), hypotheses, thr2, std::max(min_inliers, 8),
-                               std::min(max_propose, max_models), mask.data(), models.data(), nullptr, nullptr);
+        nh = g_select_refit
+                 ? mho_select_greedy_refit(x1, y1, x2, y2, aff, N, F, e2, Hh.data(), hypotheses, thr2, std::max(min_inliers, 8),
+                                           std::min(max_propose, max_models), mask.data(), models.data(), nullptr, nullptr)
+                 : mho_select_greedy(x1, y1, x2, y2, N, Hh.data(), hypotheses, thr2, std::max(min_inliers, 8),
+                                     std::min(max_propose, max_models), mask.data(), models.data(), nullptr, nullptr);
     }
     if (iterations) *iterations = 0;
     if (energy_out) *energy_out = 0.0;

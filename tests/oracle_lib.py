@@ -349,6 +349,21 @@ def cluster_merging_and_labeling(src, dst, aff, H0, F, e2, lam, thr_h, rowptr, c
     return lab, H[:k].copy(), int(it.value), float(en.value), hook is not None
 
 
+def select_greedy_refit(src, dst, aff, F, e2, H, thr2, need, max_models, mask=None):
+    """mho_select_greedy_refit: every round's winner refitted to its inliers (HAF least squares, one label) before the claim."""
+    x1, y1, x2, y2 = soa(src, dst)
+    H = f64(H).reshape(-1, 9)
+    aff, F, e2 = f64(aff), f64(F).reshape(9), f64(e2).reshape(2)
+    m = np.ones(x1.size, np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).copy()
+    Hs = np.zeros((max_models, 9))
+    idx = np.zeros(max_models, np.int64)
+    cnt = np.zeros(max_models, np.int32)
+    k = lib().mho_select_greedy_refit(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(F), _d(e2), _d(H), H.shape[0],
+                                      C.c_double(thr2), int(need), int(max_models), m.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(Hs),
+                                      idx.ctypes.data_as(C.POINTER(C.c_longlong)), _i(cnt))
+    return Hs[:k].copy(), idx[:k].copy(), cnt[:k].copy(), m
+
+
 def select_greedy(src, dst, H, thr2, need, max_models, mask=None, symmetric=False):
     """The oracle's sequential best-first selection (oracle/mh_oracle.cpp section 12).  Returns
     (H_selected, hypothesis indices, counts, mask_out).  symmetric: scores and claims on the symmetric transfer error."""

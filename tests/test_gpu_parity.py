@@ -1227,6 +1227,34 @@ def test_gpu_mean_shift_outside_the_plain_range(engine, oracle):
     assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64))
 
 
+@pytest.mark.parametrize("d", [6, 10, 7])
+def test_gpu_mean_shift_schedules_agree(engine, oracle, d):
+    """r05: the tail of a batch of climbs runs in one persistent launch (k_ms_persist: the thread's rows in registers, a
+    barrier of the climb's own per iteration; mh_set_tuning key 29 = the number of climbs below which it takes over, 0 =
+    a launch per iteration throughout, the r04 schedule).  A schedule, not a result: modes and assignment are the same
+    for every setting and equal the oracle's — dense clusters (climbs of dozens of iterations over hundreds of members),
+    rows parked at 1e300, and a dimension (7) the persistent form does not exist for."""
+    rng = np.random.default_rng(100 + d)
+    n = 12000
+    centres = rng.uniform(-60, 60, size=(40, d))
+    data = np.concatenate([c + rng.normal(0, 0.45, size=(220, d)) for c in centres])
+    data = np.concatenate([data, rng.uniform(-60, 60, size=(n - len(data), d))])
+    data[7000:7040] = 1e300
+    with np.errstate(all="ignore"):
+        modes_o, assign_o, k_o = oracle.mean_shift(data, 2.2, 31)
+    try:
+        for persist, per_round in ((12, 6), (0, 6), (1, 6), (12, 1), (64, 3)):
+            engine.set_tuning(29, persist)
+            engine.set_tuning(7, per_round)
+            modes, assign, k = engine.mean_shift(data, 2.2, 31)
+            assert k == k_o, (persist, per_round)
+            assert np.array_equal(assign, assign_o), (persist, per_round)
+            assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64)), (persist, per_round)
+    finally:
+        engine.set_tuning(29, 12)
+        engine.set_tuning(7, 6)
+
+
 def test_process_with_reference_style_initialisation(mh, engine_lib, synth):
     """INIT_STABLE_SETS: per-point HAF -> mean shift -> 3-point LSQ per cluster (the reference's own
     ComputeLocalHomographies + EstablishStablePointSets), then the usual merge/label loop."""

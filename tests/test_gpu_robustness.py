@@ -135,3 +135,42 @@ def test_greedy_selection_in_the_symmetric_residual_mode(mh, engine, synth, orac
     engine.propose_dlt4(5, 0, 2000)
     _, _, counts_fwd, _ = engine.select_greedy(thr2, 20, 6, np.ones(sc.n, np.uint8))
     assert counts_fwd[0] >= counts[0]            # d2_sym >= d2_fwd pair by pair: a model never gains inliers
+
+def test_greedy_selection_with_refitted_winners(mh, engine, synth, oracle):
+    """r05 (mh_set_tuning key 30, MultiH::SetProposalRefit): every round's winner is refitted to the correspondences of the
+    support set it explains — k_haf_reestimate with one label — and the refit takes its place when it is finite and explains
+    at least as many.  Selected models (the refits, bit for bit), positions, counts and the support mask equal the oracle's
+    sequential restatement; a refit explains more of its plane than the four-point hypothesis did."""
+    sc = mh.synth.make_scene(6000, 4, seed=5, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.set_epipolar(sc.F, sc.e2)
+    thr2 = 2.2 ** 2
+    engine.propose_dlt4(9, 0, 4000)
+    H = engine.get_models()
+    plain_H, plain_idx, plain_cnt, plain_mask = engine.select_greedy(thr2, 20, 8, np.ones(sc.n, np.uint8))
+    engine.propose_dlt4(9, 0, 4000)
+    engine.set_tuning(30, 1)
+    try:
+        Hs, counters, counts, mask = engine.select_greedy(thr2, 20, 8, np.ones(sc.n, np.uint8))
+    finally:
+        engine.set_tuning(30, 0)
+    with np.errstate(all="ignore"):
+        H_ref, idx_ref, cnt_ref, mask_ref = oracle.select_greedy_refit(sc.src, sc.dst, sc.aff, sc.F, sc.e2, H, thr2, 20, 8)
+    assert len(counters) >= 4
+    assert np.array_equal(counters, idx_ref) and np.array_equal(counts, cnt_ref) and np.array_equal(mask, mask_ref)
+    assert np.array_equal(Hs.view(np.uint64), H_ref.view(np.uint64))
+    # the first winner is the same hypothesis either way; refitted it leaves fewer of its plane's points behind
+    assert counters[0] == plain_idx[0] and counts[0] == plain_cnt[0]
+    assert not np.array_equal(Hs[0], plain_H[0])
+    assert (mask == 0).sum() >= (plain_mask == 0).sum()
+    # without affinities / epipolar geometry the option is refused, not ignored
+    e2 = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+    try:
+        e2.set_correspondences(sc.src, sc.dst, sc.aff)
+        e2.propose_dlt4(9, 0, 500)
+        e2.set_tuning(30, 1)
+        with pytest.raises(mh.MultiHError) as ei:
+            e2.select_greedy(thr2, 20, 4)
+        assert ei.value.code == -4 or "epipolar" in str(ei.value)
+    finally:
+        e2.close()
