@@ -211,7 +211,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         if (best < need) break;
         if (counts_out) counts_out[selected] = best;
         ++selected;
-        active -= best;                                   // the selected model's inliers have left the support set
+        active -= e->h_sel[5];                            // what the claim took out of the support set (the winner's inliers, or its refit's)
         Mc = e->h_sel[2];
         cur ^= 1;
         first = false;

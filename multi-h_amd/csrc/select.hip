@@ -103,7 +103,8 @@ __device__ __forceinline__ unsigned long long sel_winner(const SelRecord* __rest
     return kg;
 }
 
-// rec: [0] best count of the round, [1] its global counter, [2] next candidate count, [3] models selected so far,
+// rec: [0] best count of the round, [1] its global counter, [2] next candidate count, [3] models selected so far, [5] points that
+// left the support set in this round's claim,
 // [4] sticky error (a rank reported one, or the two ways of finding the first round's winner disagree).
 __global__ void __launch_bounds__(256)
 k_sel_compact(const int* __restrict__ counts, const int* __restrict__ orig, const double* __restrict__ Hs, int Mc, int need,
@@ -174,17 +175,23 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
         for (int q = 0; q < 9; ++q) sel_H[9 * (size_t)sel + q] = h[q];
         sel_counter[sel] = (long long)pos;
     }
-    if (n >= N || !mask[n]) return;
-    double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
-    if (symmetric) {
-        // + the backward transfer through adj(H), every entry (mul, mul, sub) — the arithmetic of the scoring kernel's
-        // symmetric mode (residual.hip), so the points that leave are the points that were counted
-        const double a0 = h[4] * h[8] - h[5] * h[7], a1 = h[2] * h[7] - h[1] * h[8], a2 = h[1] * h[5] - h[2] * h[4];
-        const double a3 = h[5] * h[6] - h[3] * h[8], a4 = h[0] * h[8] - h[2] * h[6], a5 = h[2] * h[3] - h[0] * h[5];
-        const double a6 = h[3] * h[7] - h[4] * h[6], a7 = h[1] * h[6] - h[0] * h[7], a8 = h[0] * h[4] - h[1] * h[3];
-        d2 = d2 + fwd_d2(a0, a1, a2, a3, a4, a5, a6, a7, a8, x2[n], y2[n], x1[n], y1[n]);
+    bool leaves = false;
+    if (n < N && mask[n]) {
+        double d2 = fwd_d2(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], x1[n], y1[n], x2[n], y2[n]);
+        if (symmetric) {
+            // + the backward transfer through adj(H), every entry (mul, mul, sub) — the arithmetic of the scoring kernel's
+            // symmetric mode (residual.hip), so the points that leave are the points that were counted
+            const double a0 = h[4] * h[8] - h[5] * h[7], a1 = h[2] * h[7] - h[1] * h[8], a2 = h[1] * h[5] - h[2] * h[4];
+            const double a3 = h[5] * h[6] - h[3] * h[8], a4 = h[0] * h[8] - h[2] * h[6], a5 = h[2] * h[3] - h[0] * h[5];
+            const double a6 = h[3] * h[7] - h[4] * h[6], a7 = h[1] * h[6] - h[0] * h[7], a8 = h[0] * h[4] - h[1] * h[3];
+            d2 = d2 + fwd_d2(a0, a1, a2, a3, a4, a5, a6, a7, a8, x2[n], y2[n], x1[n], y1[n]);
+        }
+        leaves = d2 < thr2;
+        if (leaves) mask[n] = 0;
     }
-    if (d2 < thr2) mask[n] = 0;
+    // rec[5]: how many points left the support set (the winner's count — or its refit's: the host keeps the size of the set)
+    const unsigned long long lm = __ballot(leaves);
+    if ((threadIdx.x & 63) == 0 && lm) atomicAdd(&rec[5], (int)__popcll(lm));
 }
 
 // ---- the winner refitted to its inliers before it claims them (r05, mh_set_tuning key 30) --------------------------------
@@ -255,10 +262,11 @@ __global__ void k_sel_publish(int* __restrict__ rec, unsigned long long* __restr
                               int need, int* __restrict__ h_rec)
 {
     if (threadIdx.x != 0) return;
-    h_rec[0] = rec[0]; h_rec[1] = rec[1]; h_rec[2] = rec[2]; h_rec[4] = rec[4];
+    h_rec[0] = rec[0]; h_rec[1] = rec[1]; h_rec[2] = rec[2]; h_rec[4] = rec[4]; h_rec[5] = rec[5];
     if (rec[0] >= need) rec[3] += 1;
     h_rec[3] = rec[3];
     rec[2] = 0;
+    rec[5] = 0;
     keys[0] = 0; keys[1] = 0;
     my_record->key = 0;
 }
