@@ -49,10 +49,15 @@ def test_agreement_with_the_references_labels(mh, engine_lib, route):
         aris.append(a["ari_reference_inliers"])
         lines.append(f"seed {seed}: {k} planes, ARI on the reference's inliers {a['ari_reference_inliers']:.3f}, all points {a['ari_all']:.3f}, "
                      + "purity " + " ".join(f"{p}:{v['purity']:.2f}" for p, v in a["per_reference_plane"].items()))
-        assert 4 <= k <= 10, lines[-1]                                   # the reference: 5 planes
+        # the reference: 5 planes.  r05: the default route refits every selected hypothesis to its inliers before it claims
+        # them (MultiH::SetProposalRefit) and comes out at 5 / 6 / 6 planes over the three seeds (r04: 8 / 6 / 6); the
+        # reference's own route starts from hundreds of stable sets and keeps more small clusters (8 / 8 / 6)
+        assert (4 <= k <= 7) if route == "dlt" else (4 <= k <= 10), lines[-1]
         assert labels.min() >= -1 and labels.max() == k - 1
         clean.append(a["per_reference_plane"][2]["purity"])
     print(f"\n[barrsmith, {route}] " + "\n                ".join(lines))
-    assert np.median(aris) >= 0.6, lines
-    assert max(aris) >= 0.65, lines
+    # r05 measured: dlt 0.935 / 0.909 / 0.892 (r04: 0.44 / 0.67 / 0.68), stable_sets 0.887 / 0.716 / 0.579
+    assert np.median(aris) >= (0.85 if route == "dlt" else 0.6), lines
+    assert min(aris) >= (0.8 if route == "dlt" else 0.5), lines
+    assert max(aris) >= (0.9 if route == "dlt" else 0.65), lines
     assert max(clean) >= 0.9, lines                                      # the reference's cleanest plane (128 points) comes out as one label
