@@ -124,7 +124,7 @@ def cpu_baseline(sc, thr2: float, sample: int, seed: int, beside=None):
     return out, H, c1
 
 
-def labeling_extra(mh, eng, a, thr2, lam):
+def labeling_extra(mh, eng, a, thr2, lam, legacy=False):
     """Context for the label half of the path (not part of `value`): one LabelingStep on the GPU next
     to the REFERENCE's own alpha-expansion (oracle/_ref: GCoptimization + BK compiled unmodified, its
     lazy callback data cost restated) on one host core, same inputs, labels compared."""
@@ -132,7 +132,9 @@ def labeling_extra(mh, eng, a, thr2, lam):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    sc = mh.synth.make_scene(a.points, a.planes, seed=a.seed)
+    # legacy: the r04 generator — planes inside each other's truncation threshold, i.e. ambiguous data terms: the HARD
+    # instances of the alpha-expansion (cores of thousands of sites, several cycles), kept as the solver's stress figure
+    sc = mh.synth.make_scene(a.points, a.planes, seed=a.seed, legacy_r04=legacy)
     eng.set_correspondences(sc.src, sc.dst, sc.aff)
     eng.set_epipolar(sc.F, sc.e2)
     eng.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
@@ -673,6 +675,7 @@ def main():
             assert np.array_equal(eng.score(thr2), cs), "GPU/oracle score mismatch"
             try:
                 out["labeling"] = labeling_extra(mh, eng, a, thr2, lam)
+                out["labeling_on_the_r04_scene"] = labeling_extra(mh, eng, a, thr2, lam, legacy=True)
             except Exception as ex:                      # context only: never lose the headline line
                 out["labeling"] = {"error": repr(ex)}
             try:
