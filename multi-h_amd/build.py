@@ -70,7 +70,7 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """C++ host mirror of the reference class (no HIP in these files; g++)."""
-    srcs = [os.path.join(HOST, f) for f in ("MultiH.cpp", "merge_step.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("MultiH.cpp", "merge_step.cpp", "approx_neighbours.cpp")]
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "multih_hip.h"))
     hdrs.append(os.path.join(ROOT, "include", "multih_rccl.h"))

@@ -510,6 +510,25 @@ void MultiH::ClusterMergingAndLabeling()
             rowptr[i + 1] = static_cast<int>(col.size());
         }
         ok = Check(mh_set_neighbors_csr(engine, rowptr.data(), col.data(), N), "mh_set_neighbors_csr");
+    } else if (neighbour_mode == NEIGHBOURS_APPROX) {
+        // the reference's own rule as FLANN's default search answers it (MultiH.h, SetNeighbourApprox): built on the host —
+        // where the reference builds it — from the float32 (x1, y1, x2, y2) vectors of :233-250, handed over as directed hits
+        std::vector<double> pv(4 * (size_t)N);
+        for (int i = 0; i < N; ++i) {
+            pv[4 * (size_t)i] = (double)static_cast<float>(src_points[i].x);
+            pv[4 * (size_t)i + 1] = (double)static_cast<float>(src_points[i].y);
+            pv[4 * (size_t)i + 2] = (double)static_cast<float>(dst_points[i].x);
+            pv[4 * (size_t)i + 3] = (double)static_cast<float>(dst_points[i].y);
+        }
+        std::vector<std::vector<int>> hits;
+        multih::ApproxNeighbourHits(pv.data(), N, approx_trees, approx_checks, 1.0 / locality_lambda, approx_seed, hits);
+        std::vector<int> rowptr(N + 1, 0), col;
+        for (int i = 0; i < N; ++i) {
+            col.insert(col.end(), hits[i].begin(), hits[i].end());
+            rowptr[i + 1] = static_cast<int>(col.size());
+        }
+        if (log_to_console) printf("[Multi-H] %d approximate neighbourhood hits (%d trees, %d checks)\n", (int)col.size(), approx_trees, approx_checks);
+        ok = Check(mh_set_neighbors_csr(engine, rowptr.data(), col.data(), N), "mh_set_neighbors_csr");
     } else if (neighbour_mode == NEIGHBOURS_KNN) {
         // the k nearest hits within the reference's radius 1 / locality_lambda (M/MultiH.cpp:252-253); see MultiH.h
         ok = Check(mh_build_neighbors_knn_radius(engine, std::min(knn, N - 1), 1.0 / locality_lambda), "mh_build_neighbors_knn_radius");
@@ -758,6 +777,11 @@ extern "C" __attribute__((visibility("default")))
 void mhh_set_post_filter(int on) { g_post_filter = on; }
 extern "C" __attribute__((visibility("default")))
 void mhh_set_neighbourhood(int knn_k, double radius) { g_knn = knn_k; g_radius = radius; }
+// MultiH::SetNeighbourApprox for the next mhh_run_process calls (trees <= 0 switches it off again)
+static int g_approx_trees = 0, g_approx_checks = 32;
+static unsigned long long g_approx_seed = 0;
+extern "C" __attribute__((visibility("default")))
+void mhh_set_neighbourhood_approx(int trees, int checks, unsigned long long seed) { g_approx_trees = trees; g_approx_checks = checks; g_approx_seed = seed; }
 // bound on the hits of the complete radius list (MultiH::SetNeighbourRadius' max_hits); <= 0 restores the default
 static long long g_max_hits = 0;
 extern "C" __attribute__((visibility("default")))
@@ -828,6 +852,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     if (g_radius > 0.0 && g_max_hits > 0) { mh.SetNeighbourRadius(g_radius, g_max_hits); if (g_knn > 0) mh.SetFallbackK(g_knn); }
     else if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
     else if (g_knn > 0) mh.SetNeighbourK(g_knn);
+    if (g_approx_trees > 0) mh.SetNeighbourApprox(g_approx_trees, g_approx_checks, g_approx_seed);
     if (!g_hits.empty() && (int)g_hits.size() == n) mh.SetNeighbours(g_hits);
     if (iter_max_new < 0) mh.SetInitialisation(MultiH::INIT_STABLE_SETS);      // test hook: negative = reference-style init
     if (init_H && n_init > 0) {

@@ -82,6 +82,12 @@ public:
     // The complete radius list instead (every hit within `radius`, exact), bounded by `max_hits` because it grows like
     // N^2: beyond the bound the k nearest hits within the radius are used and a line says so.
     void SetNeighbourRadius(double radius, long long max_hits = 1ll << 28) { neighbour_mode = NEIGHBOURS_RADIUS; neighbour_radius = radius; neighbour_max_hits = max_hits; }
+    // r05: the reference's neighbourhood as FLANN's DEFAULT search answers it — `trees` randomised KD-trees (4), best-bin-first
+    // with `checks` examined points per query (32), the hits among them inside 1 / locality_lambda — re-enacted on the host
+    // with the engine's counter RNG (approx_neighbours.cpp; OpenCV / FLANN are outside /root/reference: restated from the
+    // published algorithm, parity unpinned).  About 29 one-way hits per correspondence, 70 % of the exact 31 nearest.
+    void SetNeighbourApprox(int trees = 4, int checks = 32, uint64_t seed = 0x464c414e4eull)
+    { neighbour_mode = NEIGHBOURS_APPROX; approx_trees = trees; approx_checks = checks; approx_seed = seed; }
     // k of that fallback (default 16) without leaving the radius mode
     void SetFallbackK(int k) { knn = k; }
     // Initial cluster_homographies (what EstablishStablePointSets hands to the loop).
@@ -163,7 +169,9 @@ protected:
     mh_engine* engine = nullptr;
     int device = 0;
     std::vector<std::pair<int, int>> engine_tuning;
-    enum { NEIGHBOURS_KNN = 0, NEIGHBOURS_RADIUS = 1 };
+    enum { NEIGHBOURS_KNN = 0, NEIGHBOURS_RADIUS = 1, NEIGHBOURS_APPROX = 2 };
+    int approx_trees = 4, approx_checks = 32;
+    uint64_t approx_seed = 0;
     int neighbour_mode = NEIGHBOURS_KNN;
     int knn = 16;
     double neighbour_radius = 0.0;

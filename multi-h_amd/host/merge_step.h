@@ -73,4 +73,10 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
                        double* medians = nullptr /* nh, optional: per-cluster median-of-medians */,
                        const CompatStatsFn* stats_fn = nullptr, bool* failed = nullptr);
 
+// The reference's neighbourhood as FLANN's default search answers it (approx_neighbours.cpp): `trees` randomised KD-trees,
+// best-bin-first with `checks` examined points per query, the hits among them within `radius`; pv = n x 4 float32-rounded
+// (x1, y1, x2, y2) as doubles.
+void ApproxNeighbourHits(const double* pv, int n, int trees, int checks, double radius, uint64_t seed,
+                         std::vector<std::vector<int>>& hits);
+
 } // namespace multih

@@ -439,3 +439,42 @@ def test_two_batches_prefetched_ahead(mh, engine, synth):
         assert np.array_equal(cnt, want[i][2]), i
     with pytest.raises(mh.MultiHError):
         engine.adopt_prefetched()
+
+
+def test_process_with_the_approximate_neighbourhood(mh, engine_lib):
+    """MultiH::SetNeighbourApprox (r05): Process() with the FLANN-like neighbourhood built inside the class equals Process() with
+    the same hit lists handed in through SetNeighbours (mhh_approx_neighbour_hits -> mhh_set_neighbour_hits) — labels, models,
+    energy — and differs from the default neighbourhood's run only through the graph."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    dp = C.POINTER(C.c_double)
+    sc = mh.synth.make_scene(4000, 3, seed=12, with_neighbours=False)
+    src, dst, aff, F, e2 = (np.ascontiguousarray(a) for a in (sc.src, sc.dst, sc.aff, sc.F, sc.e2))
+
+    def process():
+        labels = np.full(sc.n, -7, dtype=np.int32); H = np.zeros((64, 9)); it, en = C.c_int(0), C.c_double(0)
+        k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), sc.n, F.ctypes.data_as(dp),
+                                 e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(2.2), C.c_double(0.005), C.c_double(0.5), 20,
+                                 C.c_ulonglong(5), 5000, 16, 0, None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), H.ctypes.data_as(dp), 64,
+                                 C.byref(it), C.byref(en), None, 0, 4)
+        return k, labels, H[:max(k, 0)].copy(), en.value
+
+    seed = 0x464c414e4e
+    host.mhh_set_neighbourhood_approx(4, 32, C.c_ulonglong(seed))
+    try:
+        inside = process()
+    finally:
+        host.mhh_set_neighbourhood_approx(0, 32, C.c_ulonglong(0))
+    rowptr = np.zeros(sc.n + 1, dtype=np.int32); col = np.zeros(sc.n * 32, dtype=np.int32)
+    total = host.mhh_approx_neighbour_hits(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), sc.n, 4, 32, C.c_double(1.0 / 0.005), C.c_ulonglong(seed),
+                                           rowptr.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)), col.size)
+    assert total > 8 * sc.n
+    host.mhh_set_neighbour_hits(rowptr.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)), sc.n)
+    try:
+        handed_in = process()
+    finally:
+        host.mhh_set_neighbour_hits(None, None, 0)
+    assert inside[0] == handed_in[0] >= 3 and np.array_equal(inside[1], handed_in[1]) and np.array_equal(inside[2], handed_in[2])
+    assert inside[3] == handed_in[3]
+    q = mh.synth.agreement(sc.gt_label, inside[1])
+    assert q["planes_recovered"] == 3 and q["ari"] > 0.95, q

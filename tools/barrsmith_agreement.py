@@ -79,9 +79,11 @@ def agreement(ours, ref):
     return out
 
 
-def run(route, corr, F, e2, seed=1234, hypotheses=20000, knn=0):
+def run(route, corr, F, e2, seed=1234, hypotheses=20000, knn=0, approx=None):
     host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
     host.mhh_set_neighbourhood(int(knn), C.c_double(0.0))      # 0 = the class default (16 nearest hits within 1 / locality)
+    # approx = (trees, checks): MultiH::SetNeighbourApprox — the reference's radiusMatch as FLANN's default search answers it
+    host.mhh_set_neighbourhood_approx(int(approx[0]) if approx else 0, int(approx[1]) if approx else 32, C.c_ulonglong(0x464c414e4e + seed))
     dp = C.POINTER(C.c_double)
     src, dst, aff = (np.ascontiguousarray(corr[:, a:b]) for a, b in ((0, 2), (2, 4), (4, 8)))
     n = len(src)
@@ -164,6 +166,18 @@ def main():
                     print(f"  sweep {route:12s} k-NN {knn:3d} seed {seed:5d}: {k} planes, ARI inliers {a['ari_reference_inliers']:.3f}, all {a['ari_all']:.3f}, "
                           f"histogram {a['ours_histogram']}", flush=True)
         run("dlt", corr, F, e2, knn=0)
+    # the reference's own neighbourhood rule as FLANN answers it (MultiH::SetNeighbourApprox, 4 trees / 32 checks), three seeds
+    rec["approx_neighbourhood"] = {}
+    for route in ("stable_sets", "dlt"):
+        runs = []
+        for seed in (1234, 7, 99):
+            k, labels, it, en = run(route, corr, F, e2, seed=seed, approx=(4, 32))
+            a = agreement(labels, ref) if k > 0 else {"planes": int(k), "ari_reference_inliers": float("nan"), "ari_all": float("nan")}
+            runs.append({"seed": seed, "planes": int(k), "ari_reference_inliers": a["ari_reference_inliers"], "ari_all": a["ari_all"]})
+        rec["approx_neighbourhood"][route] = runs
+        print(f"approximate neighbourhood (4 trees / 32 checks), {route:12s}: planes {[r['planes'] for r in runs]}, ARI on the reference's inliers "
+              + ", ".join(f"{r['ari_reference_inliers']:.3f}" for r in runs), flush=True)
+    run("dlt", corr, F, e2)                                  # (leaves the default neighbourhood set)
     if os.environ.get("RAW", "1") != "0":
         rec["from_the_raw_input_file"] = raw_route()
     print(json.dumps(rec))

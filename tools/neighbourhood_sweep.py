@@ -31,27 +31,38 @@ def splitmix(z):
 
 
 class Rng:
-    def __init__(self, seed): self.s = seed
+    def __init__(self, seed): self.s = seed & 0xFFFFFFFFFFFFFFFF
     def below(self, n):
         self.s = (self.s + 1) & 0xFFFFFFFFFFFFFFFF
         return splitmix(self.s) % n
 
 
 def build_tree(pv, idx, rng):
-    """FLANN KDTreeIndex::divideTree: leaves hold ONE point; the cut dimension is drawn among the 5 dimensions of largest
-    variance (here all 4) estimated on the first 100 points of the node, the cut value is their mean in it."""
+    """FLANN KDTreeIndex::divideTree (the algorithm of multi-h_amd/host/approx_neighbours.cpp, operation for operation):
+    leaves hold ONE point; the cut dimension is drawn among the 5 dimensions of largest variance (here all 4) estimated on
+    the first 100 points of the node — sequential sums —, the cut value is their mean in it."""
     if len(idx) == 1:
         return ("leaf", int(idx[0]))
-    sample = pv[idx[:100]]
-    var = sample.var(axis=0)
-    top = np.argsort(-var)[:5]
-    dim = int(top[rng.below(len(top))])
-    val = float(sample[:, dim].mean())
-    left = idx[pv[idx, dim] < val]
-    right = idx[pv[idx, dim] >= val]
+    sample = [pv[int(i)] for i in idx[:100]]
+    ns = len(sample)
+    mean, var = [], []
+    for d in range(4):
+        s = 0.0
+        for r in sample: s = s + float(r[d])
+        m = s / ns
+        v = 0.0
+        for r in sample:
+            x = float(r[d]) - m
+            v = v + x * x
+        mean.append(m); var.append(v / ns)
+    order = sorted(range(4), key=lambda d: -var[d])                 # stable: largest variance first
+    dim = order[rng.below(4)]
+    val = mean[dim]
+    left = [int(i) for i in idx if pv[int(i), dim] < val]
+    right = [int(i) for i in idx if not (pv[int(i), dim] < val)]
     if len(left) == 0 or len(right) == 0:                  # all equal in that dimension: halve
         half = len(idx) // 2
-        left, right = idx[:half], idx[half:]
+        left, right = [int(i) for i in idx[:half]], [int(i) for i in idx[half:]]
     return ("node", dim, val, build_tree(pv, left, rng), build_tree(pv, right, rng))
 
 
@@ -61,7 +72,7 @@ def forest_hits(pv, trees_n, checks, radius, seed):
     rng = Rng(seed)
     trees = []
     for t in range(trees_n):
-        perm = np.arange(n)
+        perm = list(range(n))
         for i in range(n - 1, 0, -1):                      # FLANN shuffles the point order per tree
             j = rng.below(i + 1); perm[i], perm[j] = perm[j], perm[i]
         trees.append(build_tree(pv, perm, rng))
@@ -69,27 +80,31 @@ def forest_hits(pv, trees_n, checks, radius, seed):
     rows = []
     for q in range(n):
         v = pv[q]
-        heap, checked, found, count = [], set(), [], 0
+        heap, checked, found = [], set(), []
+        state = {"count": 0, "pushed": 0}
 
         def descend(node, mind):
-            nonlocal count
             while node[0] == "node":
                 _, dim, val, lo, hi = node
-                diff = v[dim] - val
+                diff = float(v[dim]) - val
                 near, far = (lo, hi) if diff < 0 else (hi, lo)
-                heapq.heappush(heap, (mind + diff * diff, id(far), far))
+                heapq.heappush(heap, (mind + diff * diff, state["pushed"], far))     # ties: first pushed, first out
+                state["pushed"] += 1
                 node = near
             p = node[1]
-            if p in checked or count >= checks:
+            if p in checked or state["count"] >= checks:
                 return
-            checked.add(p); count += 1
-            d2 = float(((pv[p] - v) ** 2).sum())
+            checked.add(p); state["count"] += 1
+            d2 = 0.0
+            for d in range(4):
+                x = float(pv[p, d]) - float(v[d])
+                d2 = d2 + x * x
             if d2 <= r2 and p != q:
                 found.append(p)
 
         for t in trees:
             descend(t, 0.0)
-        while heap and count < checks:
+        while heap and state["count"] < checks:
             mind, _, node = heapq.heappop(heap)
             descend(node, mind)
         rows.append(sorted(found))
