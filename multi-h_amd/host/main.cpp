@@ -7,7 +7,8 @@
 //   multih_harness <in_corr.txt> <out_result.txt> [--epipolar <file with F(9) e2x e2y>]
 //                  [--thrF 2.6] [--thrH 2.2] [--locality 0.005] [--lambda 0.5] [--min-inliers 20]
 //                  [--hypotheses 10000] [--max-models 32] [--seed 1234] [--iterations 0]
-//                  [--neighbourhood knn|radius]   (knn, the default: the 16 nearest hits within 1/locality pixels; radius: every hit within it)
+//                  [--neighbourhood knn|radius|approx]   (knn, the default: the 16 nearest hits within 1/locality pixels; radius: every hit within
+//                  it; approx: what FLANN's default search — 4 randomised KD-trees, 32 checks — finds of them, MultiH::SetNeighbourApprox)
 //                  [--ranks N]   one process per GPU (rank r on device r), the hypothesis batches sharded over the ranks and
 //                                exchanged by RCCL (host/rccl_transport.cpp: ncclAllGather on the engine's stream); this
 //                                process becomes rank 0 and starts the others before anything touches the GPU.  Every rank
@@ -68,7 +69,7 @@ int main(int argc, char** argv)
     if (argc < 3) {
         std::cerr << "usage: multih_harness <in_corr.txt> <out_result.txt> [--epipolar file] [--thrF v] [--thrH v] "
                      "[--locality v] [--lambda v] [--min-inliers n] [--hypotheses n] [--max-models n] [--seed n] "
-                     "[--iterations n] [--neighbourhood knn|radius] [--ranks n]\n";
+                     "[--iterations n] [--neighbourhood knn|radius|approx] [--ranks n]\n";
         return 2;
     }
     double thrF = 2.6, thrH = 2.2, locality = 0.005, lambda = 0.5;     // M/main.cpp:55-59
@@ -206,6 +207,7 @@ int main(int argc, char** argv)
         multiH->SetShardingStream(rank, ranks, allgather, comm);
     }
     if (neighbourhood == "radius") multiH->SetNeighbourRadius(1.0 / locality);        // the complete list of M/MultiH.cpp:252-253 (see MultiH.h)
+    else if (neighbourhood == "approx") multiH->SetNeighbourApprox(4, 32, 0x464c414e4eull + seed);   // ... as FLANN's default search answers it
     if (!multiH->Process(srcPointsOrig, dstPointsOrig, origAffines)) { delete multiH; return finish(1); }
     const std::string out_path = rank == 0 ? std::string(argv[2]) : std::string(argv[2]) + ".rank" + std::to_string(rank);
 
