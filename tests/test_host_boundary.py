@@ -23,7 +23,7 @@ def _compile(tmp_path, sources, out, extra=()):
 
 def test_apply_multih_sequence_is_memory_clean_under_opencv_ownership_rules(tmp_path):
     srcs = [os.path.join(ROOT, "tests", "apply_multih_caller.cpp"), os.path.join(ROOT, "tests", "fake_engine.cpp"),
-            os.path.join(HOST, "MultiH.cpp"), os.path.join(HOST, "merge_step.cpp")]
+            os.path.join(HOST, "MultiH.cpp"), os.path.join(HOST, "merge_step.cpp"), os.path.join(HOST, "approx_neighbours.cpp")]
     b = _compile(tmp_path, srcs, "caller")
     if b.returncode != 0 and ("cannot find" in b.stderr or "unrecognized" in b.stderr):
         pytest.skip("sanitizer runtime not installed")
