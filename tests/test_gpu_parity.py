@@ -794,6 +794,37 @@ def test_full_size_properties_50k_x_100k(engine, synth, oracle):
         assert np.array_equal(a[both].view(np.uint64), b[both].view(np.uint64))
 
 
+def test_full_size_symmetric_transfer_50k_x_100k(engine, synth, oracle):
+    """r05: the symmetric transfer error at BASELINE configs[2] size (the 40 GB matrix in MH_RESIDUAL_SYMMETRIC mode): sampled
+    row blocks bit-exactly against the oracle's restatement, fused counts == store-free score == oracle on those rows, every
+    entry >= the forward residual of the same pair (a sum of two squares against one of them), counts <= the forward counts."""
+    N, M = 50000, 100000
+    sc = synth.make_scene(N, 10, seed=1234, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.propose_dlt4(1234, 0, M)
+    H = engine.get_models()
+    _, cnt_fwd = engine.residual_matrix(THR2, fetch_R=False)
+    blocks = [(0, 16), (M // 2 - 5, 16), (M - 16, 16)]
+    fwd = {first: engine.get_residual_rows(first, count) for first, count in blocks}
+    engine.set_residual_mode(True)
+    try:
+        _, cnt = engine.residual_matrix(THR2, fetch_R=False)
+        assert np.array_equal(engine.score(THR2), cnt)
+        assert (cnt <= cnt_fwd).all() and cnt.max() > 1000
+        with np.errstate(all="ignore"):
+            for first, count in blocks:
+                rows = engine.get_residual_rows(first, count)
+                ref = oracle.residual_matrix_sym(sc.src, sc.dst, H[first:first + count])
+                nan = np.isnan(ref)
+                assert np.array_equal(np.isnan(rows), nan)
+                assert np.array_equal(rows[~nan].view(np.uint64), ref[~nan].view(np.uint64))
+                assert np.array_equal(cnt[first:first + count], oracle.score_sym(sc.src, sc.dst, H[first:first + count], THR2))
+                ok = ~nan & ~np.isnan(fwd[first])
+                assert (rows[ok] >= fwd[first][ok]).all()
+    finally:
+        engine.set_residual_mode(False)
+
+
 def test_full_size_labeling_equals_the_reference_gco(engine, synth, oracle):
     """BASELINE's 50 000 correspondences / 10 planes: one LabelingStep on the GPU (data cost, alpha-
     expansion with 0.9 M neighbour hits, label shift) against the reference's own GCoptimization
