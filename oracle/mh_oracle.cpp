@@ -1896,6 +1896,7 @@ static int select_greedy_impl(const double* x1, const double* y1, const double* 
     auto score = symmetric ? mho_score_sym : mho_score;
     int selected = 0;
     std::vector<int> counts(M);
+    std::vector<unsigned char> taken(M, 0);
     for (int round = 0; round < max_models; ++round) {
         // the score of :430-443 for every hypothesis over the support set; the hypotheses are independent, so a large
         // batch is spread over the host's cores (integer counts: the same whatever the number of threads) — at BASELINE
@@ -1905,9 +1906,12 @@ static int select_greedy_impl(const double* x1, const double* y1, const double* 
             for (int m = 0; m < M; ++m) score(x1, y1, x2, y2, N, H + 9 * (size_t)m, 1, thr2, mask, &counts[m]);
         } else
             score(x1, y1, x2, y2, N, H, M, thr2, mask, counts.data());
+        // a hypothesis is selected at most once (without the refit a winner is left with no inlier in the support set, so this only
+        // matters with it: the refit's claim can leave some of the hypothesis' own inliers behind)
         int best = -1, bm = -1;
-        for (int m = 0; m < M; ++m) if (counts[m] > best) { best = counts[m]; bm = m; }
+        for (int m = 0; m < M; ++m) if (!taken[m] && counts[m] > best) { best = counts[m]; bm = m; }
         if (bm < 0 || best < need) break;
+        taken[bm] = 1;
         const double* h = H + 9 * (size_t)bm;
         double hr[9];
         if (refit) {
