@@ -144,7 +144,7 @@ __device__ __forceinline__ void null9_vector(double (*W)[HPW], int hs, double g[
 
 // The r01-r04 form of the proposer: W staged in LDS (78 KB per workgroup, two workgroups per compute unit).  It is what
 // mh_prefetch_dlt4 launches (variant 1 of launch_dlt4): slower alone than the register-resident form below (0.40 against
-// 0.26 ms per 100 000 hypotheses, same bits), but the one of the two that fits beside a resident sweep (capi.hip).
+// 0.26 ms per 100 000 hypotheses, same bits), but the one of the two that fits beside a resident sweep (capi_score.hip, mh_prefetch_dlt4).
 // At most 72 VGPRs: that is what the resident residual sweep leaves free on every SIMD (5 waves of 88 registers), so a
 // workgroup of this kernel fits beside it on any compute unit (residual.hip, k_residual_resident).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(72)))

@@ -1,4 +1,4 @@
-// mh_kernels.hpp — private launch interface between the C-ABI layer (capi.hip)
+// mh_kernels.hpp — private launch interface between the C-ABI layer (capi*.hip)
 // and the gfx950 kernels.  Nothing here is exported.
 #pragma once
 #include <hip/hip_runtime.h>
