@@ -106,6 +106,24 @@ int main(int argc, char** argv)
         const bool ok = multih::Homography3PTLinear(same, same, 3, F, Hd);
         std::printf("degenerate 3PT accepted=%d\n", (int)ok);
     }
+    // the FLANN-like neighbourhood (host/approx_neighbours.cpp): forests over the float32 point vectors, with exact
+    // duplicates and a coordinate shared by many points (the halving rule of the tree build)
+    {
+        const int n = (int)labels.size();
+        std::vector<double> pv(4 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            pv[4 * (size_t)i] = (double)(float)src[2 * i]; pv[4 * (size_t)i + 1] = (double)(float)src[2 * i + 1];
+            pv[4 * (size_t)i + 2] = (double)(float)dst[2 * i]; pv[4 * (size_t)i + 3] = (double)(float)dst[2 * i + 1];
+        }
+        for (int i = 10; i < 40; ++i) for (int d = 0; d < 4; ++d) pv[4 * (size_t)i + d] = pv[40 + d];
+        for (int i = 100; i < 300; ++i) pv[4 * (size_t)i] = 77.0;
+        std::vector<std::vector<int>> hits;
+        multih::ApproxNeighbourHits(pv.data(), n, 4, 32, 200.0, 99, hits);
+        multih::ApproxNeighbourHits(pv.data(), n, 1, 3, 1e9, 5, hits);
+        multih::ApproxNeighbourHits(pv.data(), 1, 4, 32, 200.0, 99, hits);
+        multih::ApproxNeighbourHits(pv.data(), n, 4, 32, 200.0, 99, hits);
+        for (int i = 0; i < n; ++i) sum += (double)hits[i].size();
+    }
     std::printf("checksum %.12g\n", sum);
     return 0;
 }

@@ -1,7 +1,7 @@
 """AddressSanitizer + UBSan and ThreadSanitizer runs of the host-side C++ (multi-h_amd/host/merge_step.cpp)
 through tests/host_sanitize_driver.cpp.  GPU ASan is not available on the MI355X pool, so the CPU build
 is where the sanitizers run; the driver covers the feature map, mean shift, the 3-point solver with its
-LM refinement and the threaded compatibility check."""
+LM refinement, the threaded compatibility check and (r05) the FLANN-like neighbourhood builder (approx_neighbours.cpp)."""
 import os
 import shutil
 import subprocess
@@ -16,7 +16,8 @@ def _build_and_run(tmp_path, san, args=()):
     exe = str(tmp_path / f"driver_{san.replace(',', '_')}")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-ffp-contract=off", f"-fsanitize={san}",
            "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-I" + HOST,
-           os.path.join(ROOT, "tests", "host_sanitize_driver.cpp"), os.path.join(HOST, "merge_step.cpp"), "-o", exe]
+           os.path.join(ROOT, "tests", "host_sanitize_driver.cpp"), os.path.join(HOST, "merge_step.cpp"),
+           os.path.join(HOST, "approx_neighbours.cpp"), "-o", exe]
     b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     if b.returncode != 0 and ("cannot find" in b.stderr or "unrecognized" in b.stderr):
         pytest.skip(f"-fsanitize={san} runtime not installed: {b.stderr[-200:]}")
