@@ -200,6 +200,9 @@ struct mh_engine {
     long long* h_acc_dev = nullptr;
     DevBuf<double> sel_pts[4];               // the active points of a greedy-selection round, packed (select.hip)
     DevBuf<int> sel_pack_count;
+    int tune_knn_grid = 1;                   // key 31: the k-NN table through the grid over the source image (0 = exhaustive pass)
+    DevBuf<int> knn_cell, knn_count, knn_start, knn_orig;
+    DevBuf<float> knn_P;
     DevBuf<int> knn_tmp, knn_part_i;
     DevBuf<float> knn_part_d;
 

@@ -254,6 +254,11 @@ hipError_t launch_pad_scores(const int* counts, int m, int longest, int* scores,
 // --- knn.hip ----------------------------------------------------------------
 constexpr int KNN_MAX_SPLITS = 16;      // slices of the candidate range (knn.hip)
 hipError_t launch_knn(const Points& p, int k, int* nbr_out /* n x k */, int splits, float* part_d, int* part_i, hipStream_t s);
+// r05: the same table through a grid over the source image (cells walked ring by ring until no unexamined point can enter the
+// list).  scratch: cell_of n ints, count G*G ints, start G*G + 1 ints (G = knn_grid_cells(n) <= 256), P4 4n floats, orig n ints;
+// hipErrorInvalidValue when the points' bounding box is not finite (the caller then takes the exhaustive pass).
+int knn_grid_cells(int n);
+hipError_t launch_knn_grid(const Points& p, int k, int* nbr_out, int* cell_of, int* count, int* start, float* P4, int* orig, hipStream_t s);
 hipError_t launch_radius_count(const Points& p, float r2, int* counts /* n */, hipStream_t s);
 hipError_t launch_radius_fill(const Points& p, float r2, const int* rowptr /* n+1 */, int* col /* nnz */, hipStream_t s);
 

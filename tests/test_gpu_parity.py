@@ -565,6 +565,47 @@ def test_knn_builder(engine, synth):
         assert np.array_equal(w[rp[i]:rp[i + 1]], mult[i][js])
 
 
+@pytest.mark.parametrize("case", ["scene", "duplicates", "line", "clusters", "tiny", "ties", "big"])
+def test_knn_through_the_grid_equals_the_exhaustive_pass(engine, synth, case):
+    """r05: the k-NN table through a grid over the source image (k_knn_grid: cells walked ring by ring until no unexamined point
+    can enter the list; mh_set_tuning key 31) against the exhaustive pass (k_knn) — the symmetric graph built from either is the
+    same, entry for entry: ordinary scenes, hundreds of exact duplicates, points on one image row (a grid of zero height),
+    a few dense clusters (thousands of points in one cell), fewer points than a wave, integer coordinates (distance ties
+    everywhere: the index decides), 50 000 points."""
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    n, k, radius = 3000, 16, 0.0
+    if case == "big":
+        n = 50000
+    sc = synth.make_scene(n, 4, seed=19, with_neighbours=False)
+    src, dst = sc.src.copy(), sc.dst.copy()
+    if case == "duplicates":
+        src[100:700] = src[100]; dst[100:700] = dst[100]
+    elif case == "line":
+        src[:, 1] = 250.0
+    elif case == "clusters":
+        c = rng.uniform(100, 900, size=(5, 2))
+        src = c[rng.integers(0, 5, n)] + rng.normal(0, 0.05, size=(n, 2)); dst = src + rng.normal(0, 0.05, size=(n, 2))
+    elif case == "tiny":
+        src, dst, k = src[:20].copy(), dst[:20].copy(), 8
+    elif case == "ties":
+        src = np.floor(src / 25.0) * 25.0; dst = np.floor(dst / 25.0) * 25.0; radius = 60.0
+    engine.set_correspondences(src, dst)
+    got = {}
+    try:
+        for grid in (1, 0):
+            engine.set_tuning(31, grid)
+            if radius > 0:
+                engine.build_neighbors_knn(k, radius=radius)
+            else:
+                engine.build_neighbors_knn(k)
+            got[grid] = engine.get_sym_graph()
+    finally:
+        engine.set_tuning(31, 1)
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a, b), case
+    assert got[1][0][-1] >= src.shape[0] * min(k, 4) or case == "ties"
+
+
 def test_knn_within_the_reference_radius(engine, synth):
     """mh_build_neighbors_knn_radius (the host class's default neighbourhood): the k nearest hits, of which only those
     within the radius survive — checked against a float32 brute force with the kernel's association order."""
