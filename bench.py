@@ -562,6 +562,26 @@ def main():
     alg_bytes = 8.0 * N * M + 32.0 * N + 72.0 * M + 4.0 * M
     achieved = alg_bytes / (avg_res_ms * 1e-3) / 1e9
 
+    # What this box's memory takes from stores alone, measured in this run: hipMemset over the residual matrix itself (the 40 GB
+    # the sweep has just written; a fill kernel of the runtime, no arithmetic).  Context for roofline.frac — the sweep computes
+    # 28 FP64 operations per pair at the board's power cap on top of the same store stream.
+    memset_GBps = None
+    try:
+        ptr_R, bytes_R = eng.device_buffer(2)            # MH_BUF_RESIDUALS
+        if ptr_R and bytes_R >= 8 * N * M:
+            t_R = torch.as_tensor(_DevView(ptr_R, int(bytes_R), "|u1"), device=dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            t_R.zero_()
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(3):
+                t_R.zero_()
+            ev[1].record()
+            torch.cuda.synchronize()
+            memset_GBps = float(bytes_R) * 3 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+    except Exception:
+        memset_GBps = None
+
     fractions = {}
 
     def frac(name: str, value: float) -> float:
@@ -655,6 +675,8 @@ def main():
                          "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_write_ceiling_GBps": HBM_WRITE_CEILING_GBPS,
                          "frac_of_measured_write_ceiling": achieved / HBM_WRITE_CEILING_GBPS,
+                         "memset_of_R_on_this_box_GBps": memset_GBps,
+                         "frac_of_that_memset": (achieved / memset_GBps) if memset_GBps else None,
                          "models_per_launch": M},
             "best_model": head["best_model"], "best_score": head["best_score"], "scores_sha256": head["scores_sha256"],
         }
