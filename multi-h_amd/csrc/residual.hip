@@ -30,6 +30,11 @@
 
 namespace mh {
 
+// A double in global memory, spelt out: the row pointer of the sweep is rebuilt from an integer held in scalar registers, and
+// a plain double* made that way would be a flat pointer (flat_store instead of global_store).
+typedef double __attribute__((address_space(1))) gdouble;
+typedef char __attribute__((address_space(1))) gchar;
+
 // PPL = points per lane (even), MC = models per workgroup.
 // WRITE_R: materialise the matrix.  MASK: per-point activity mask (score only).
 // NT: non-temporal stores for the R stream.  FAST: shared-reciprocal division (mh_device.hpp).
@@ -83,6 +88,13 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
         }
     }
     __syncthreads();
+
+    // The per-model flags as wave-uniform bit masks: the model loop tests them on the scalar unit (one LDS read, two
+    // readfirstlanes and a mask round trip through a VGPR per model less than reading s_hok[mi] / s_far[mi] there).
+    const unsigned hok_bits = (unsigned)__builtin_amdgcn_ballot_w64(lane < MC && s_hok[lane < MC ? lane : 0] != 0);
+    const unsigned far_bits = (unsigned)__builtin_amdgcn_ballot_w64(lane < MC && s_far[lane < MC ? lane : 0] != 0);
+
+    unsigned lane_bytes = (unsigned)lane * 16u;    // (not const: laundered in place inside the model loop)
 
     int cnt = 0;                                // lane mi of each wave counts model m0+mi
     static_assert(MC <= 64, "one counting lane per model");
@@ -158,10 +170,20 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
                              h6 = h[6], h7 = h[7], h8 = h[8];
                 // wave-uniform by construction (every lane reads the same LDS word); readfirstlane tells the compiler so,
                 // which keeps the choice of sweep a scalar branch instead of an exec-mask dance
-                const bool hok = __builtin_amdgcn_readfirstlane(s_hok[mi]) != 0;
-                const bool far = FAST && !CONTRACT && __builtin_amdgcn_readfirstlane(s_far[mi]) != 0;
+                const bool hok = ((hok_bits >> mi) & 1u) != 0;
+                const bool far = FAST && !CONTRACT && ((far_bits >> mi) & 1u) != 0;
                 const bool aok = SYM ? (s_aok[mi] != 0) : false;
                 int c_m = 0;
+                // where row m (or, TILED, this workgroup's block) starts for this wave's first chunk
+                auto row_ptr = [&](int n) -> double* {
+                    if (TILED) return R + ((size_t)bx * ntiles_all + tile_idx) * ((size_t)MC * TILE) + (size_t)mi * TILE + (n - base);
+                    return R + (size_t)m * ldr + n;
+                };
+                // ... as a scalar register pair; the lane's 16 bytes are a 32-bit offset, so the stores address as saddr + voffset and
+                // the model loop advances the row on the scalar unit instead of with a 64-bit vector add per model
+                gchar* row_base = (gchar*)row_ptr(wbase);
+                asm volatile("" : "+v"(lane_bytes));        // (keeps the zero-extension next to the address, where the saddr form is matched)
+                asm volatile("" : "+s"(row_base));          // (opaque: keeps the strength reducer from turning it back into a per-lane pointer)
                 // the chunk loop, once with the per-pair |s| compare and once without (the model's horizon is provably far
                 // from every point): one VALU instruction per pair less on the common path
                 auto sweep = [&](auto schk) {
@@ -201,14 +223,13 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
                         }
                         if (WRITE_R) {
                             const int n = wbase + c * 128 + lane * 2;
-                            double* dstp = TILED ? R + ((size_t)bx * ntiles_all + tile_idx) * ((size_t)MC * TILE) + (size_t)mi * TILE + (n - base)
-                                                 : R + (size_t)m * ldr + n;
+                            gdouble* dstp = reinterpret_cast<gdouble*>(row_base + lane_bytes) + c * 128;
                             if (n + 1 < N) {
                                 if (NT) {
                                     __builtin_nontemporal_store(d0s, dstp);
                                     __builtin_nontemporal_store(d1s, dstp + 1);
                                 } else {
-                                    *reinterpret_cast<double2*>(dstp) = make_double2(d0s, d1s);
+                                    dstp[0] = d0s; dstp[1] = d1s;
                                 }
                             } else if (n < N) {
                                 dstp[0] = d0s;
@@ -218,24 +239,20 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
                         c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d1s < thr2) & okm[2 * c + 1]);
                     }
                 };
-                // where row m (or, TILED, this workgroup's block) starts for this wave's first chunk
-                auto row_ptr = [&](int n) -> double* {
-                    if (TILED) return R + ((size_t)bx * ntiles_all + tile_idx) * ((size_t)MC * TILE) + (size_t)mi * TILE + (n - base);
-                    return R + (size_t)m * ldr + n;
-                };
                 // The lean sweep: all PPL residuals first, then the stores and the counts.  `far` models (the horizon provably
                 // clear of every point) need no check at all; for the others ONE wave-wide test per model — did any of the
                 // PPL x 64 denominators leave the fast division's range? — replaces the per-pair branch, and the rare wave
                 // that says yes redoes this model through the checked sweep (nothing has been stored or counted yet).
                 bool lean_done = false;
                 if (LEAN && FAST && !SYM && !CONTRACT && !CALIB && tile_lean && hok && (SEMI || far)) {
-                    double dl[PPL];
+                    double dl[PPL], sq[PPL];
                     unsigned long long bad = 0ull;          // lanes whose denominator is out of range (or NaN), any of the PPL pairs
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) {
-                        double sq;
-                        dl[q] = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[q], py[q], qx[q], qy[q], sq);
-                        if (!far) bad |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sq) >= 0x1p-255));
+                    for (int q = 0; q < PPL; ++q)
+                        dl[q] = fwd_d2_lean(h0, h1, h2, h3, h4, h5, h6, h7, h8, px[q], py[q], qx[q], qy[q], sq[q]);
+                    if (!far) {                             // one scalar branch per model, not one per pair
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) bad |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sq[q]) >= 0x1p-255));
                     }
                     if (bad == 0ull) {
                         lean_done = true;
@@ -243,7 +260,7 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
                         for (int c = 0; c < CH; ++c) {
                             const double d0 = dl[2 * c], d1 = dl[2 * c + 1];
                             if (WRITE_R) {
-                                double* dstp = row_ptr(wbase + c * 128 + lane * 2);
+                                gdouble* dstp = reinterpret_cast<gdouble*>(row_base + lane_bytes) + c * 128;
                                 if (SF != 0) {          // measurement builds: cache-policy bits of the store spelt out
                                     typedef double d2v __attribute__((ext_vector_type(2)));
                                     const d2v val = { d0, d1 };
@@ -255,7 +272,7 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
                                     __builtin_nontemporal_store(d0, dstp);
                                     __builtin_nontemporal_store(d1, dstp + 1);
                                 } else {
-                                    *reinterpret_cast<double2*>(dstp) = make_double2(d0, d1);
+                                    dstp[0] = d0; dstp[1] = d1;
                                 }
                             }
                             c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 < thr2));
