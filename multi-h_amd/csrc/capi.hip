@@ -754,6 +754,8 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
     if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }
+    if (key == 32 && (value == 0 || value == 1)) { e->tune_ms_indexed = value; return MH_OK; }     // mean shift: indexed climbs (1, default) or the launched / persistent schedule (0): same modes
+    if (key == 33 && value >= 0 && value <= (1 << 20)) { e->tune_ms_dense = value; return MH_OK; }     // ... and the member count beyond which an indexed climb is handed on
     if (key == 30 && (value == 0 || value == 1)) { e->tune_select_refine = value; return MH_OK; }
     if (key == 31 && (value == 0 || value == 1)) { e->tune_knn_grid = value; return MH_OK; }        // k-NN through the grid (1, default) or exhaustively (0): same table     // NOT schedule-only: changes what mh_select_greedy selects       // mean shift: persistent tail below this many climbs (0 = off)
     if (key == 8 && value >= 0 && value <= (1 << 20)) { e->trace_moves = value; return MH_OK; }

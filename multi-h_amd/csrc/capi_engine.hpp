@@ -167,6 +167,11 @@ struct mh_engine {
     int tune_select_refine = 0;              // key 30: mh_select_greedy refits each round's winner to its inliers before the claim (0 = off)
     DevBuf<double> sel_refit;                // the refit (9 doubles) and its inlier count
     DevBuf<int> sel_refit_ctr;
+    DevBuf<double> ms_rs;                    // the mean-shift index of one call (meanshift.hip, k_ms_indexed): rows in cell order,
+    DevBuf<int> ms_order, ms_cells, ms_cursor, ms_cellcount;   // position -> row, cell starts, scatter cursors, cell counts
+    int tune_ms_indexed = 1;                 // key 32: climbs through the index, a workgroup each, a launch per batch (0: the launched / persistent schedule)
+    int tune_ms_dense = 8;                  // key 33: an indexed climb that meets more members than this in an iteration is handed to the per-group kernels
+    long long ms_indexed_launches = 0;
     int tune_ms_persist = 12;                // key 29: the tail runs persistently once at most this many climbs are left (0 = never)
     long long ms_persist_launches = 0, ms_persist_fallbacks = 0, ms_rounds = 0;
 

@@ -236,6 +236,42 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     int* const starts = reinterpret_cast<int*>(e->h_ms + B);
     const int* const starts_dev = reinterpret_cast<const int*>(e->h_ms_dev + B);
 
+    // r05: the index of this call's rows (k_ms_indexed).  The coordinate with the widest spread of its ordinary values (rows
+    // parked at 1e300 and non-finite ones aside) is binned in cells of bandWidth^2 (1 + 2^-20) — wider if that would take
+    // more cells than the index holds.  The choice affects speed only: any coordinate, any lo, any w >= that bound is exact.
+    const bool indexed = e->tune_ms_indexed != 0 && ms_indexed_supported(n, d);
+    MeanShiftIndex ix{};
+    if (indexed) {
+        double lo[16], hi[16];
+        for (int j = 0; j < d; ++j) { lo[j] = 1e300; hi[j] = -1e300; }
+        for (int i = 0; i < n; ++i) {
+            const double* row = data + (size_t)i * d;
+            for (int j = 0; j < d; ++j) {
+                const double x = row[j];
+                if (x > -1e299 && x < 1e299) { lo[j] = x < lo[j] ? x : lo[j]; hi[j] = x > hi[j] ? x : hi[j]; }
+            }
+        }
+        int coord = 0;
+        double spread = -1.0;
+        for (int j = 0; j < d; ++j) { const double sp = hi[j] >= lo[j] ? hi[j] - lo[j] : 0.0; if (sp > spread) { spread = sp; coord = j; } }
+        double width = band_sq * (1.0 + 0x1p-20);
+        if (!(width > 0.0) || !(width < 1e299)) width = 1.0;                  // (a degenerate band: one cell does)
+        const int max_cells = ms_index_max_cells();
+        if (!(spread >= 0.0) || !(spread < 1e299)) spread = 0.0;
+        if (spread / width > (double)(max_cells - 2)) width = spread / (double)(max_cells - 2);
+        ix.cells = std::max(1, std::min(max_cells, (int)(spread / width) + 2));
+        ix.coord = coord;
+        ix.lo = hi[coord] >= lo[coord] ? lo[coord] : 0.0;
+        ix.inv_w = 1.0 / width;
+        HIPCHK(e->ms_rs.reserve((size_t)n * d));
+        HIPCHK(e->ms_order.reserve((size_t)n));
+        HIPCHK(e->ms_cells.reserve((size_t)ix.cells + 1));
+        HIPCHK(e->ms_cursor.reserve((size_t)ix.cells));
+        HIPCHK(e->ms_cellcount.reserve((size_t)ix.cells));
+        ix.rs = e->ms_rs.p; ix.order = e->ms_order.p; ix.cell_start = e->ms_cells.p;
+        HIPCHK(launch_ms_index_build(e->ms_data.p, n, d, ix, e->ms_cellcount.p, e->ms_cursor.p, e->ms_cells.p, e->ms_order.p, e->ms_rs.p, e->stream));
+    }
+
     // `init` of the reference (:125-130) is the ascending list of unvisited rows, rebuilt after every
     // climb; a Fenwick tree over the unvisited flags answers "the k-th unvisited row" in O(log n).
     std::vector<int> fen(n + 1, 0), visited(n, 0), list;
@@ -260,7 +296,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     const auto t_call = std::chrono::steady_clock::now();
     long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0, st_G = 0;
     std::vector<std::pair<int, int>> st_climbs;              // (iterations, rows touched) of every climb
-    if (ms_stats) { HIPCHK(e->ms_ticks.reserve(5)); HIPCHK(hipMemsetAsync(e->ms_ticks.p, 0, sizeof(unsigned long long) * 5, e->stream)); }
+    if (ms_stats) { HIPCHK(e->ms_ticks.reserve(13)); HIPCHK(hipMemsetAsync(e->ms_ticks.p, 0, sizeof(unsigned long long) * 13, e->stream)); }
     std::vector<double> cent;                                       // modes, d values each
     int n_cent = 0;
     std::vector<std::vector<std::pair<int, int>>> votes;            // per mode: (row, votes), unordered
@@ -311,7 +347,20 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             ++e->ms_rounds;
             const auto t_round = std::chrono::steady_clock::now();
             const int active_in = n_active;
-            if (G > 0) {
+            if (indexed && round == 0) {
+                // every climb of the batch from its seed; the dense ones come back running and go on below (persistent
+                // when few enough, launched rounds otherwise)
+                int keep = 0;                                  // climbs the persistent kernel can take over at once
+                if (persist_ok && e->tune_ms_persist > 0 && ms_persist_supported(n, d)) {
+                    int& per_cu = d == 10 ? e->ms_persist_per_cu : e->ms_persist_per_cu6;
+                    if (per_cu < 0) { const int q = ms_persist_occupancy(d); if (q > 0) per_cu = q; }
+                    const int room = std::max(0, per_cu) * e->cu_count * 7 / 8;
+                    keep = std::min(e->tune_ms_persist, room / std::min(64, (n + 255) / 256));
+                }
+                HIPCHK(launch_ms_indexed(w, active, n_active, starts_dev, ix, band_sq, stop_thresh, 1 << 20, e->tune_ms_dense,
+                                         keep, e->ms_ctl.p, e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream, ms_stats ? e->ms_ticks.p + 5 : nullptr));
+                ++e->ms_indexed_launches;
+            } else if (G > 0) {
                 HIPCHK(launch_ms_persist(w, active, n_active, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
                                          e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream, ms_stats ? e->ms_ticks.p : nullptr));
                 ++e->ms_persist_launches;
@@ -448,6 +497,15 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         (void)hipMemcpy(tk, e->ms_ticks.p, sizeof(tk), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mh_mean_shift] persistent kernel, first climb's first workgroup: gate %.1f ms, row load %.1f ms, sweep + tree + partial stores %.1f ms, barrier %.1f ms, "
                         "new mean %.1f ms; mean G %.1f\n", tk[4] * 1e-5, tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, st_persist_rounds ? (double)st_G / st_persist_rounds : 0.0);
+    }
+    if (ms_stats && indexed) {
+        unsigned long long tk[8] = {};
+        (void)hipMemcpy(tk, e->ms_ticks.p + 5, sizeof(tk), hipMemcpyDeviceToHost);
+        for (int o = 0; o < 8; o += 4)
+            if (tk[o + 3])
+                fprintf(stderr, "[mh_mean_shift] indexed climbs, iterations with %s members: %llu; per iteration: candidates %.2f us, group sums %.2f us, new mean %.2f us\n",
+                        o ? "> 64" : "<= 64", tk[o + 3], tk[o] * 0.01 / tk[o + 3], tk[o + 1] * 0.01 / tk[o + 3], tk[o + 2] * 0.01 / tk[o + 3]);
+        fprintf(stderr, "[mh_mean_shift] index: coordinate %d, %d cells\n", ix.coord, ix.cells);
     }
     if (ms_stats && !st_climbs.empty()) {
         // how long the climbs are and how many rows they touch: is the tail made of dense or of sparse climbs?

@@ -133,6 +133,24 @@ hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& acti
                              int* heads_dev, int list_prefix, hipStream_t s, unsigned long long* ticks = nullptr);
 bool ms_persist_supported(int n, int d);
 int ms_persist_occupancy(int d);
+// r05: a climb per workgroup, from seed to published result in one launch; the rows reached through a one-coordinate index
+// (meanshift.hip, k_ms_indexed).  The index is built once per call; cell width w >= bandWidth^2 (1 + 2^-20) is the caller's
+// duty (the three-cell window is exact only then).
+struct MeanShiftIndex {
+    const double* rs;        // [d][n] the rows in cell order, component-major
+    const int* order;        // [n] position in cell order -> row
+    const int* cell_start;   // [cells + 1]
+    int cells, coord;
+    double lo, inv_w;        // cell(x) = clamp(floor((x - lo) * inv_w), 0, cells - 1)
+};
+bool ms_indexed_supported(int n, int d);
+int ms_index_max_cells();
+hipError_t launch_ms_index_build(const double* data, int n, int d, const MeanShiftIndex& ix, int* count, int* cursor, int* cell_start,
+                                 int* order, double* rs, hipStream_t s);
+hipError_t launch_ms_indexed(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev,
+                             const MeanShiftIndex& ix, double band_sq, double stop_thresh, int max_iters, int dense_limit,
+                             int keep, int* running, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix, hipStream_t s,
+                             unsigned long long* ticks = nullptr);
 // compacts and clears the votes of all `climbs` climbs, ended or not
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s);
 

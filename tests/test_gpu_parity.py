@@ -1315,16 +1315,69 @@ def test_gpu_mean_shift_schedules_agree(engine, oracle, d):
     with np.errstate(all="ignore"):
         modes_o, assign_o, k_o = oracle.mean_shift(data, 2.2, 31)
     try:
-        for persist, per_round in ((12, 6), (0, 6), (1, 6), (12, 1), (64, 3)):
+        # (indexed, persist, per_round): key 32 = climbs through the one-coordinate index, a workgroup each, a launch per
+        # batch (the default where it exists: d = 6 / 10); 0 = the launched / persistent schedule of keys 29 and 7
+        for indexed, persist, per_round in ((1, 12, 6), (0, 12, 6), (0, 0, 6), (0, 1, 6), (0, 12, 1), (0, 64, 3)):
+            engine.set_tuning(32, indexed)
             engine.set_tuning(29, persist)
             engine.set_tuning(7, per_round)
             modes, assign, k = engine.mean_shift(data, 2.2, 31)
-            assert k == k_o, (persist, per_round)
-            assert np.array_equal(assign, assign_o), (persist, per_round)
-            assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64)), (persist, per_round)
+            assert k == k_o, (indexed, persist, per_round)
+            assert np.array_equal(assign, assign_o), (indexed, persist, per_round)
+            assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64)), (indexed, persist, per_round)
     finally:
+        engine.set_tuning(32, 1)
         engine.set_tuning(29, 12)
         engine.set_tuning(7, 6)
+
+
+@pytest.mark.parametrize("case", ["one_cell", "wide", "slots", "boundary", "nan", "tiny_band"])
+def test_gpu_mean_shift_index_edges(engine, oracle, case):
+    """r05, k_ms_indexed: the index only narrows where members are LOOKED for.  Inputs that strain that: every row in one
+    cell; a spread that takes more cells than the index holds (cells widen, far rows clamp into the last); more rows
+    than the 16 384 slots of the definition (a slot sums several rows, in ascending order); rows exactly one band away
+    from a seed on the indexed coordinate (in / out by one ulp); NaN coordinates; a band so narrow that every row is its
+    own mode.  Modes and assignment equal the oracle's bit for bit."""
+    rng = np.random.default_rng(7)
+    d, bw, n = 10, 2.2, 3000
+    if case == "one_cell":
+        data = rng.uniform(0, 3.0, size=(n, d))
+    elif case == "wide":
+        data = rng.uniform(-40, 40, size=(n, d))
+        data[:, 2] = np.concatenate([rng.uniform(-4e6, 4e6, size=n - 600), rng.uniform(0, 3, size=600)])
+        data[-600:] = data[-600] + rng.normal(0, 0.3, size=(600, d))
+    elif case == "slots":
+        n = 40000
+        centres = rng.uniform(-30, 30, size=(25, d))
+        data = np.concatenate([c + rng.normal(0, 0.4, size=(1200, d)) for c in centres])
+        data = np.concatenate([data, rng.uniform(-30, 30, size=(n - len(data), d))])
+        data = data[rng.permutation(n)]
+    elif case == "boundary":
+        data = rng.uniform(-100, 100, size=(n, d))
+        band_sq = bw * bw
+        for q in range(40):                                   # pairs that differ on ONE coordinate by band^2 -/+ a few ulps
+            a = data[10 * q].copy()
+            b = a.copy()
+            step = band_sq
+            for _ in range(q % 5): step = np.nextafter(step, 0.0 if q % 2 else 1e9)
+            b[q % d] = a[q % d] + (step if q % 3 else -step)
+            data[10 * q + 1] = b
+    elif case == "nan":
+        data = rng.uniform(-20, 20, size=(n, d))
+        data[5:25, 0] = np.nan
+        data[40:50, 3] = np.nan
+        data[60:70] = np.inf
+        data[80:90, 1] = -1e300
+    else:
+        bw = 1e-3
+        data = rng.uniform(-5, 5, size=(600, d))
+    data = np.ascontiguousarray(data)
+    with np.errstate(all="ignore"):
+        modes_o, assign_o, k_o = oracle.mean_shift(data, bw, 5)
+    modes, assign, k = engine.mean_shift(data, bw, 5)
+    assert k == k_o
+    assert np.array_equal(assign, assign_o)
+    assert np.array_equal(modes.view(np.uint64), modes_o.view(np.uint64))
 
 
 def test_process_with_reference_style_initialisation(mh, engine_lib, synth):

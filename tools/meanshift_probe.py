@@ -19,6 +19,10 @@ for n, planes in ((int(v), SIZES[int(v)]) for v in os.environ.get("SIZES", "500,
         e.set_tuning(7, int(os.environ["MS_ITERS"]))
     if os.environ.get("MS_PERSIST"):                       # key 29: 0 = a launch per iteration throughout (the r04 schedule)
         e.set_tuning(29, int(os.environ["MS_PERSIST"]))
+    if os.environ.get("MS_INDEXED"):                       # key 32: 0 = the launched / persistent schedule (no index)
+        e.set_tuning(32, int(os.environ["MS_INDEXED"]))
+    if os.environ.get("MS_DENSE"):                         # key 33: members per iteration beyond which an indexed climb is handed on
+        e.set_tuning(33, int(os.environ["MS_DENSE"]))
     best = 1e9
     for _ in range(3):
         t = time.perf_counter()
