@@ -199,7 +199,8 @@ struct mh_engine {
     int* h_flags = nullptr;
     MeanShiftResultBlock* h_ms = nullptr;      // mapped pinned result block of the mean-shift climbs
     MeanShiftResultBlock* h_ms_dev = nullptr;
-    int* h_ms_list = nullptr;                  // pinned staging for the first MS_LIST_PREFIX (row, votes) pairs of every climb of a batch
+    int* h_ms_list = nullptr;                  // pinned: the (row, votes) lists of a batch's climbs, packed (grows with the need)
+    size_t h_ms_list_pairs = 0;
     long long* h_acc = nullptr;
     int* h_flags_dev = nullptr;
     long long* h_acc_dev = nullptr;

@@ -221,13 +221,19 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                      e->ms_partial.p, e->ms_pcnt.p };
     const double band_sq = band_width * band_width;                 // MeanShiftClustering.h:31
     const double stop_thresh = 1e-3 * band_width;                   // :48
-    constexpr int MS_LIST_PREFIX = 2048;      // pairs per climb that can travel in the batch's one copy; longer lists fetch their rest
-    if (!e->h_ms) {                                                 // B result blocks, then the B seed rows
-        HIPCHK(hipHostMalloc((void**)&e->h_ms, sizeof(MeanShiftResultBlock) * B + sizeof(int) * B, hipHostMallocMapped));
+    if (!e->h_ms) {                                                 // B result blocks, then the B seed rows, list offsets and list lengths
+        HIPCHK(hipHostMalloc((void**)&e->h_ms, sizeof(MeanShiftResultBlock) * B + sizeof(int) * 3 * B, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_ms_dev, e->h_ms, 0));
     }
-    if (!e->h_ms_list) HIPCHK(hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * MS_LIST_PREFIX * B, hipHostMallocDefault));
-    HIPCHK(e->ms_heads.reserve((size_t)B * 2 * MS_LIST_PREFIX));
+    // the (row, votes) lists of a batch travel packed, in one copy of exactly their pairs; the pinned buffer grows with the need
+    auto list_room = [&](size_t pairs) -> hipError_t {
+        if (pairs <= e->h_ms_list_pairs) return hipSuccess;
+        size_t want = std::max<size_t>(pairs, std::max<size_t>(1 << 16, 2 * e->h_ms_list_pairs));
+        if (e->h_ms_list) { (void)hipHostFree(e->h_ms_list); e->h_ms_list = nullptr; e->h_ms_list_pairs = 0; }
+        const hipError_t he = hipHostMalloc((void**)&e->h_ms_list, sizeof(int) * 2 * want, hipHostMallocDefault);
+        if (he == hipSuccess) e->h_ms_list_pairs = want;
+        return he;
+    };
     HIPCHK(e->ms_tickets.reserve((size_t)B));
     HIPCHK(e->ms_ctl.reserve((size_t)3 * B));
     HIPCHK(e->ms_partial2.reserve((size_t)B * 2 * 64 * 16));
@@ -235,6 +241,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     HIPCHK(hipMemsetAsync(e->ms_tickets.p, 0, sizeof(int) * (size_t)B, e->stream));
     int* const starts = reinterpret_cast<int*>(e->h_ms + B);
     const int* const starts_dev = reinterpret_cast<const int*>(e->h_ms_dev + B);
+    int* const list_off = starts + B;
+    int* const list_len = starts + 2 * B;
 
     // r05: the index of this call's rows (k_ms_indexed).  The coordinate with the widest spread of its ordinary values (rows
     // parked at 1e300 and non-finite ones aside) is binned in cells of bandWidth^2 (1 + 2^-20) — wider if that would take
@@ -274,7 +282,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
 
     // `init` of the reference (:125-130) is the ascending list of unvisited rows, rebuilt after every
     // climb; a Fenwick tree over the unvisited flags answers "the k-th unvisited row" in O(log n).
-    std::vector<int> fen(n + 1, 0), visited(n, 0), list;
+    std::vector<int> fen(n + 1, 0), visited(n, 0);
     for (int i = 1; i <= n; ++i) { fen[i] += 1; const int j = i + (i & -i); if (j <= n) fen[j] += fen[i]; }
     int top = 1;
     while (top * 2 <= n) top *= 2;
@@ -292,7 +300,7 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     int unvisited = n;
     // MULTIH_MS_STATS=1: where the call's time goes (a line on stderr at the end) — diagnostic
     const bool ms_stats = std::getenv("MULTIH_MS_STATS") != nullptr;
-    double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0, st_apply_us = 0;
+    double st_persist_us = 0, st_launch_us = 0, st_tail_us = 0, st_apply_us = 0, st_merge_us = 0;
     const auto t_call = std::chrono::steady_clock::now();
     long long st_persist_iters = 0, st_persist_rounds = 0, st_persist_climbs = 0, st_launch_rounds = 0, st_tail_climbs = 0, st_batches = 0, st_G = 0;
     std::vector<std::pair<int, int>> st_climbs;              // (iterations, rows touched) of every climb
@@ -358,16 +366,16 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                     keep = std::min(e->tune_ms_persist, room / std::min(64, (n + 255) / 256));
                 }
                 HIPCHK(launch_ms_indexed(w, active, n_active, starts_dev, ix, band_sq, stop_thresh, 1 << 20, e->tune_ms_dense,
-                                         keep, e->ms_ctl.p, e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream, ms_stats ? e->ms_ticks.p + 5 : nullptr));
+                                         keep, e->ms_ctl.p, e->h_ms_dev, e->stream, ms_stats ? e->ms_ticks.p + 5 : nullptr));
                 ++e->ms_indexed_launches;
             } else if (G > 0) {
                 HIPCHK(launch_ms_persist(w, active, n_active, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
-                                         e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->stream, ms_stats ? e->ms_ticks.p : nullptr));
+                                         e->h_ms_dev, e->stream, ms_stats ? e->ms_ticks.p : nullptr));
                 ++e->ms_persist_launches;
                 st_G += G;
             } else {
                 HIPCHK(launch_ms_climb(w, active, n_active, round == 0 ? starts_dev : nullptr, band_sq, stop_thresh, e->tune_ms_batch,
-                                       e->h_ms_dev, e->ms_heads.p, MS_LIST_PREFIX, e->ms_tickets.p, e->stream));
+                                       e->h_ms_dev, e->ms_tickets.p, e->stream));
             }
             HIPCHK(hipStreamSynchronize(e->stream));
             if (ms_stats) {
@@ -395,12 +403,22 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             HIPCHK(hipStreamSynchronize(e->stream));
             return fail(MH_ERR_INVALID, "mean shift: a climb did not converge within 20000 rounds of iterations");
         }
-        // the heads of all lists in one copy: staged as [position][climb], so the first `longest` pairs of every climb are
-        // one contiguous range
+        // all lists in one copy: packed one behind the other on the device (the lengths are in the published results)
         int longest = 0;
-        for (int b = 0; b < climbs; ++b) longest = std::max(longest, std::min(e->h_ms[b].out[2], MS_LIST_PREFIX));
-        if (longest > 0) {
-            HIPCHK(hipMemcpyAsync(e->h_ms_list, e->ms_heads.p, sizeof(int) * 2 * (size_t)B * longest, hipMemcpyDeviceToHost, e->stream));
+        size_t total = 0;
+        for (int b = 0; b < climbs; ++b) {
+            const int len = std::max(0, e->h_ms[b].out[2]);
+            list_off[b] = (int)total;
+            list_len[b] = len;
+            total += (size_t)len;
+            longest = std::max(longest, len);
+        }
+        if (total > 0) {
+            if (total > (size_t)0x3fffffff) return fail(MH_ERR_INVALID, "mean shift: the lists of one batch exceed 2^30 pairs");
+            HIPCHK(e->ms_heads.reserve(2 * total));
+            HIPCHK(list_room(total));
+            HIPCHK(launch_ms_pack(w, climbs, longest, starts_dev + B, starts_dev + 2 * B, e->ms_heads.p, e->stream));
+            HIPCHK(hipMemcpyAsync(e->h_ms_list, e->ms_heads.p, sizeof(int) * 2 * total, hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
         }
         // apply the climbs in draw order; one whose seed an earlier climb of the batch has visited never started in
@@ -414,23 +432,15 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
             const int* out = e->h_ms[b].out;
             const double* mean = e->h_ms[b].mean;
             const int len = out[2];
-            list.resize(2 * (size_t)len);
-            const int head = std::min(len, MS_LIST_PREFIX);
-            for (int k = 0; k < head; ++k) {
-                const int* pr = e->h_ms_list + ((size_t)k * B + b) * 2;
-                list[2 * k] = pr[0];
-                list[2 * k + 1] = pr[1];
-            }
-            if (len > head) {
-                HIPCHK(hipMemcpyAsync(list.data() + 2 * (size_t)head, e->ms_list.p + (size_t)b * 2 * n + 2 * (size_t)head,
-                                      sizeof(int) * 2 * (size_t)(len - head), hipMemcpyDeviceToHost, e->stream));
-                HIPCHK(hipStreamSynchronize(e->stream));
-            }
+            const int* list = e->h_ms_list + 2 * (size_t)list_off[b];
             std::vector<std::pair<int, int>> mine(len);
             for (int k = 0; k < len; ++k) {
                 mine[k] = { list[2 * k], list[2 * k + 1] };
                 if (!visited[list[2 * k]]) { mark_visited(list[2 * k]); --unvisited; }
             }
+            const auto t_merge = std::chrono::steady_clock::now();
+            struct MergeClock { double* acc; std::chrono::steady_clock::time_point t0; ~MergeClock() { if (acc) *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } }
+                merge_clock{ ms_stats ? &st_merge_us : nullptr, t_merge };
             // (r05: the lists stay in the order the device compacted them — nothing below depends on it; sorting them was a
             // third of the host's share of a call at 50 000 rows)
             if (!out[1]) {
@@ -522,8 +532,8 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         }
     }
     if (ms_stats)
-        fprintf(stderr, "[mh_mean_shift] host: applying the batches' climbs (lists, visited set, vote merging) %.1f ms; final assignment %.1f ms; whole call %.1f ms\n",
-                st_apply_us * 1e-3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_final).count(),
+        fprintf(stderr, "[mh_mean_shift] host: applying the batches' climbs (lists, visited set, vote merging) %.1f ms, of which centroid search and vote merging %.1f ms; final assignment %.1f ms; whole call %.1f ms\n",
+                st_apply_us * 1e-3, st_merge_us * 1e-3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_final).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
     if (ms_stats)
         fprintf(stderr, "[mh_mean_shift] n %d: %lld batches; launched rounds %lld (%.1f ms, of which rounds after the first %.1f ms on %lld climb-rounds); "

@@ -557,7 +557,7 @@ template <int D, bool TIMED>
 __global__ void __launch_bounds__(MSX_THREADS)
 k_ms_indexed(MeanShiftWork all, MeanShiftActive active, const int* __restrict__ starts, MeanShiftIndex ix, double band_sq,
              double stop_thresh, int max_iters, int dense_limit, int keep, int* running, MeanShiftResultBlock* results,
-             int* __restrict__ heads, int prefix, unsigned long long* ticks)
+             unsigned long long* ticks)
 {
     const int climb = active.climb[blockIdx.x];
     const MeanShiftWork w = ms_climb(all, climb);
@@ -776,11 +776,6 @@ k_ms_indexed(MeanShiftWork all, MeanShiftActive active, const int* __restrict__ 
                 const int pos = atomicAdd(&s_len, 1);
                 w.list[2 * pos] = i;
                 w.list[2 * pos + 1] = v;
-                if (pos < prefix) {
-                    int* h = heads + ((size_t)pos * MS_BATCH + climb) * 2;
-                    h[0] = i;
-                    h[1] = v;
-                }
                 w.votes[i] = 0;
             }
         }
@@ -824,11 +819,9 @@ k_ms_seed(MeanShiftWork all, MeanShiftActive active, const int* __restrict__ sta
     if (j < 4) w.out[j] = 0;
 }
 
-// k_ms_collect, run only once the climb has ended (converged or dead end); the head of the list also goes into a staging
-// array laid out [position][climb], so that the first k pairs of ALL climbs are one contiguous range: the host fetches
-// them with ONE copy per batch (k = the longest head) instead of one per climb
+// k_ms_collect, run only once the climb has ended (converged or dead end)
 __global__ void __launch_bounds__(256)
-k_ms_collect_if_done(MeanShiftWork all, MeanShiftActive active, int* __restrict__ heads, int prefix)
+k_ms_collect_if_done(MeanShiftWork all, MeanShiftActive active)
 {
     const int b = active.climb[blockIdx.y];
     const MeanShiftWork w = ms_climb(all, b);
@@ -840,11 +833,6 @@ k_ms_collect_if_done(MeanShiftWork all, MeanShiftActive active, int* __restrict_
         const int pos = atomicAdd(&w.out[2], 1);
         w.list[2 * pos] = i;
         w.list[2 * pos + 1] = v;
-        if (pos < prefix) {
-            int* h = heads + ((size_t)pos * MS_BATCH + b) * 2;
-            h[0] = i;
-            h[1] = v;
-        }
         w.votes[i] = 0;
     }
 }
@@ -861,8 +849,7 @@ k_ms_publish(MeanShiftWork all, MeanShiftActive active, MeanShiftResultBlock* re
 }
 
 hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev, double band_sq,
-                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix,
-                           int* tickets, hipStream_t s)
+                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* tickets, hipStream_t s)
 {
     if (w.d > MS_MAXD || n_active < 1 || n_active > MS_BATCH) return hipErrorInvalidValue;
     const int groups = std::min(MS_GROUPS, (w.n + 255) / 256);
@@ -870,7 +857,7 @@ hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active
     for (int it = 0; it < iterations; ++it) {
         hipLaunchKernelGGL(k_ms_iterate, dim3(groups, n_active), dim3(256), 0, s, w, active, groups, band_sq, stop_thresh, tickets);
     }
-    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
+    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active);
     hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
     return hipGetLastError();
 }
@@ -880,7 +867,7 @@ hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active
 // here.  hipErrorNotSupported: no persistent form for this input (d other than 6 / 10, more than 4 rows per thread).
 hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, double band_sq, double stop_thresh,
                              int max_iters, int* ctl, double* partial2, int* partial_cnt2, MeanShiftResultBlock* result_dev,
-                             int* heads_dev, int list_prefix, hipStream_t s, unsigned long long* ticks)
+                             hipStream_t s, unsigned long long* ticks)
 {
     if (w.d > MS_MAXD || n_active < 1 || n_active > MS_BATCH) return hipErrorInvalidValue;
     if (!ms_persist_supported(w.n, w.d)) return hipErrorNotSupported;
@@ -894,7 +881,7 @@ hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& acti
     else if (w.d == 10) hipLaunchKernelGGL((k_ms_persist<10, false>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
     else if (ticks) hipLaunchKernelGGL((k_ms_persist<6, true>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
     else hipLaunchKernelGGL((k_ms_persist<6, false>), grid, dim3(256), 0, s, w, active, ps, groups, band_sq, stop_thresh, max_iters, gate_timeout);
-    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active, heads_dev, list_prefix);
+    hipLaunchKernelGGL(k_ms_collect_if_done, dim3((w.n + 255) / 256, n_active), dim3(256), 0, s, w, active);
     hipLaunchKernelGGL(k_ms_publish, dim3(n_active), dim3(64), 0, s, w, active, result_dev);
     return hipGetLastError();
 }
@@ -934,18 +921,40 @@ hipError_t launch_ms_index_build(const double* data, int n, int d, const MeanShi
 // come back running.
 hipError_t launch_ms_indexed(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev,
                              const MeanShiftIndex& ix, double band_sq, double stop_thresh, int max_iters, int dense_limit,
-                             int keep, int* running, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix, hipStream_t s,
-                             unsigned long long* ticks)
+                             int keep, int* running, MeanShiftResultBlock* result_dev, hipStream_t s, unsigned long long* ticks)
 {
     if (n_active < 1 || n_active > MS_BATCH || !running) return hipErrorInvalidValue;
     if (!ms_indexed_supported(w.n, w.d)) return hipErrorNotSupported;
     const hipError_t he = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(running), n_active, 1, s);    // the climbs still running
     if (he != hipSuccess) return he;
     const dim3 grid(n_active), block(MSX_THREADS);
-    if (w.d == 10 && ticks) hipLaunchKernelGGL((k_ms_indexed<10, true>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, heads_dev, list_prefix, ticks);
-    else if (w.d == 10) hipLaunchKernelGGL((k_ms_indexed<10, false>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, heads_dev, list_prefix, ticks);
-    else if (ticks) hipLaunchKernelGGL((k_ms_indexed<6, true>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, heads_dev, list_prefix, ticks);
-    else hipLaunchKernelGGL((k_ms_indexed<6, false>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, heads_dev, list_prefix, ticks);
+    if (w.d == 10 && ticks) hipLaunchKernelGGL((k_ms_indexed<10, true>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, ticks);
+    else if (w.d == 10) hipLaunchKernelGGL((k_ms_indexed<10, false>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, ticks);
+    else if (ticks) hipLaunchKernelGGL((k_ms_indexed<6, true>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, ticks);
+    else hipLaunchKernelGGL((k_ms_indexed<6, false>), grid, block, 0, s, w, active, starts_dev, ix, band_sq, stop_thresh, max_iters, dense_limit, keep, running, result_dev, ticks);
+    return hipGetLastError();
+}
+
+// The lists of a batch's climbs, one behind the other: pair k of climb b -> packed[offsets[b] + k].  The host, which knows
+// the lengths from the published results, sets the offsets and fetches exactly the pairs there are with one copy (a
+// staging array of the lists' HEADS, [position][climb], made that copy 4 MB whenever one climb of the batch was long,
+// and every longer list a copy of its own).
+__global__ void __launch_bounds__(256)
+k_ms_pack(MeanShiftWork all, const int* __restrict__ offsets, const int* __restrict__ lengths, int* __restrict__ packed)
+{
+    const int b = blockIdx.y;
+    const int len = lengths[b];
+    const int* list = all.list + (size_t)b * 2 * all.n;
+    int* dst = packed + 2 * (size_t)offsets[b];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < 2 * len; k += gridDim.x * 256) dst[k] = list[k];
+}
+
+hipError_t launch_ms_pack(const MeanShiftWork& w, int climbs, int longest, const int* offsets_dev, const int* lengths_dev, int* packed,
+                          hipStream_t s)
+{
+    if (climbs < 1 || longest < 1) return hipSuccess;
+    const int gx = std::max(1, std::min(64, (2 * longest + 255) / 256));
+    hipLaunchKernelGGL(k_ms_pack, dim3(gx, climbs), dim3(256), 0, s, w, offsets_dev, lengths_dev, packed);
     return hipGetLastError();
 }
 

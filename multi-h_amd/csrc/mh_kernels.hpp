@@ -115,13 +115,11 @@ struct MeanShiftResultBlock { int out[4]; double mean[16]; };
 struct MeanShiftActive { unsigned char climb[MS_BATCH]; };       // the climbs a round still works on, passed by value
 // The climbs active[0..n_active) side by side without host round trips in between: seed the means with the rows
 // starts_dev[climb] (null: continue the running climbs), `iterations` climb iterations (no-ops for a climb that has
-// ended), compact the votes of the climbs that have ended — the first `list_prefix` (row, votes) pairs of each also into
-// heads_dev[position][climb] (pairs of ints, MS_BATCH climbs per position: the first k pairs of all climbs are one
-// contiguous range the host fetches once per batch) — then publish
+// ended), compact the votes of the climbs that have ended into their lists, then publish
 // every active climb's control words and mean to result_dev[climb] (mapped pinned).  Workgroups beyond the rows
 // (n < 256 * MS_GROUPS) are not launched: their partial sums are +0, which the running sum never notices.
 hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev, double band_sq,
-                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix,
+                           double stop_thresh, int iterations, MeanShiftResultBlock* result_dev,
                            int* tickets /* MS_BATCH ints, zero */, hipStream_t s);
 // r05: the same for the FEW climbs that are still running after the first rounds — to their end (or max_iters) in one
 // launch, one workgroup per group of the definition with the thread's rows in registers and a barrier of the climb's own
@@ -130,7 +128,7 @@ hipError_t launch_ms_climb(const MeanShiftWork& w, const MeanShiftActive& active
 // doubles; partial_cnt2: MS_BATCH x 2 x 64 ints.  Needs n_active x min(64, ceil(n / 256)) workgroups resident at once.
 hipError_t launch_ms_persist(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, double band_sq, double stop_thresh,
                              int max_iters, int* ctl, double* partial2, int* partial_cnt2, MeanShiftResultBlock* result_dev,
-                             int* heads_dev, int list_prefix, hipStream_t s, unsigned long long* ticks = nullptr);
+                             hipStream_t s, unsigned long long* ticks = nullptr);
 bool ms_persist_supported(int n, int d);
 int ms_persist_occupancy(int d);
 // r05: a climb per workgroup, from seed to published result in one launch; the rows reached through a one-coordinate index
@@ -149,8 +147,11 @@ hipError_t launch_ms_index_build(const double* data, int n, int d, const MeanShi
                                  int* order, double* rs, hipStream_t s);
 hipError_t launch_ms_indexed(const MeanShiftWork& w, const MeanShiftActive& active, int n_active, const int* starts_dev,
                              const MeanShiftIndex& ix, double band_sq, double stop_thresh, int max_iters, int dense_limit,
-                             int keep, int* running, MeanShiftResultBlock* result_dev, int* heads_dev, int list_prefix, hipStream_t s,
+                             int keep, int* running, MeanShiftResultBlock* result_dev, hipStream_t s,
                              unsigned long long* ticks = nullptr);
+// the lists of climbs 0 .. climbs-1 packed one behind the other (lengths / offsets: `climbs` ints each, device-visible)
+hipError_t launch_ms_pack(const MeanShiftWork& w, int climbs, int longest, const int* offsets_dev, const int* lengths_dev, int* packed,
+                          hipStream_t s);
 // compacts and clears the votes of all `climbs` climbs, ended or not
 hipError_t launch_ms_collect(const MeanShiftWork& w, int climbs, hipStream_t s);
 
