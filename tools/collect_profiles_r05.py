@@ -41,6 +41,7 @@ strip(os.path.join(E, "loop_timing_reference_init.txt"), "r05_loop_timing_refere
 strip(os.path.join(E, "loop_reproposal.txt"), "r05_loop_reproposal.txt")
 strip(os.path.join(E, "meanshift_probe.txt"), "r05_meanshift_probe.txt")
 strip(os.path.join(E, "meanshift_probe_r04_schedule.txt"), "r05_meanshift_probe_r04_schedule.txt")
+strip(os.path.join(E, "meanshift_probe_persistent_schedule.txt"), "r05_meanshift_probe_persistent_schedule.txt")
 strip(os.path.join(E, "barrsmith.txt"), "r05_barrsmith_agreement.txt", drop=DROP + r"|^\{")
 strip(os.path.join(E, "at_size_init.txt"), "r05_at_size_alternation.txt")
 strip(os.path.join(E, "tests.log"), "r05_gpu_tests.txt")

@@ -29,7 +29,8 @@ MULTIH_TIMING=1 python tools/loop_bench.py > $E/loop_timing.txt 2>&1
 MULTIH_TIMING=1 INIT=stable python tools/loop_bench.py > $E/loop_timing_reference_init.txt 2>&1
 ITER_HYP=100000 python tools/loop_bench.py > $E/loop_reproposal.txt 2>&1
 python tools/small_scene_bench.py > $E/small_scenes.txt 2>&1
-MS_PERSIST=0 python tools/meanshift_probe.py > $E/meanshift_probe_r04_schedule.txt 2>&1
+MS_INDEXED=0 MS_PERSIST=0 python tools/meanshift_probe.py > $E/meanshift_probe_r04_schedule.txt 2>&1
+MS_INDEXED=0 python tools/meanshift_probe.py > $E/meanshift_probe_persistent_schedule.txt 2>&1
 MULTIH_MS_STATS=1 python tools/meanshift_probe.py > $E/meanshift_probe.txt 2>&1
 python tools/barrsmith_agreement.py > $E/barrsmith.txt 2>&1
 python tools/at_size_alternation.py > $E/at_size_init.txt 2>&1
