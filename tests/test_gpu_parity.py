@@ -1331,7 +1331,7 @@ def test_gpu_mean_shift_schedules_agree(engine, oracle, d):
         engine.set_tuning(7, 6)
 
 
-@pytest.mark.parametrize("case", ["one_cell", "wide", "slots", "boundary", "nan", "tiny_band"])
+@pytest.mark.parametrize("case", ["one_cell", "wide", "slots", "boundary", "nan", "tiny_band", "split_halves", "dense_walk", "dense_walk_k3"])
 def test_gpu_mean_shift_index_edges(engine, oracle, case):
     """r05, k_ms_indexed: the index only narrows where members are LOOKED for.  Inputs that strain that: every row in one
     cell; a spread that takes more cells than the index holds (cells widen, far rows clamp into the last); more rows
@@ -1362,6 +1362,13 @@ def test_gpu_mean_shift_index_edges(engine, oracle, case):
             for _ in range(q % 5): step = np.nextafter(step, 0.0 if q % 2 else 1e9)
             b[q % d] = a[q % d] + (step if q % 3 else -step)
             data[10 * q + 1] = b
+    elif case in ("split_halves", "dense_walk", "dense_walk_k3"):
+        # one blob that every climb's ball swallows whole: every group of the definition gets n / 64 members per iteration —
+        # 94 (two half-trees of a wave each), 312 and 625 (more than a wave holds: the dense walk over the slots; with
+        # 40 000 rows a slot sums three rows) — plus scattered rows; the blob's noise makes the ORDER of the sums show
+        n = {"split_halves": 6000, "dense_walk": 20000, "dense_walk_k3": 40000}[case]
+        data = rng.uniform(-50, 50, size=(1, d)) + rng.normal(0, 0.05, size=(n, d))
+        data[::97] = rng.uniform(-50, 50, size=(len(data[::97]), d))
     elif case == "nan":
         data = rng.uniform(-20, 20, size=(n, d))
         data[5:25, 0] = np.nan
