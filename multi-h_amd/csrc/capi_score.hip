@@ -188,7 +188,7 @@ int mh_residual_matrix(mh_engine* e, double thr2, double* R_host, int* counts)
     // free on every compute unit, which is what a workgroup of the DLT solve needs.  Key 19: -1 = hardware dispatch,
     // h >= 0 = leave h more workgroup slots free.
     int resident = 0;
-    if (e->tune_sweep_headroom >= 0 && e->residual_mode != MH_RESIDUAL_SYMMETRIC && e->tune_residual_variant == 0) {
+    if (e->tune_sweep_headroom >= 0 && e->residual_mode != MH_RESIDUAL_SYMMETRIC && (e->tune_residual_variant == 0 || (e->tune_residual_variant >= 50 && e->tune_residual_variant <= 52))) {     // (50-52: the product sweep at other work-item sizes, tuning builds)
         if (e->sweep_wg_per_cu < 0) e->sweep_wg_per_cu = residual_workgroups_per_cu();
         // With a stream-ordered transport over several ranks, RCCL's own kernel (one or two workgroups for an exchange of this
         // size) has to find room while the NEXT sweep is resident: 32 slots are left free for it unless the caller chose.

@@ -91,8 +91,8 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
 
     // The per-model flags as wave-uniform bit masks: the model loop tests them on the scalar unit (one LDS read, two
     // readfirstlanes and a mask round trip through a VGPR per model less than reading s_hok[mi] / s_far[mi] there).
-    const unsigned hok_bits = (unsigned)__builtin_amdgcn_ballot_w64(lane < MC && s_hok[lane < MC ? lane : 0] != 0);
-    const unsigned far_bits = (unsigned)__builtin_amdgcn_ballot_w64(lane < MC && s_far[lane < MC ? lane : 0] != 0);
+    const unsigned long long hok_bits = __builtin_amdgcn_ballot_w64(lane < MC && s_hok[lane < MC ? lane : 0] != 0);
+    const unsigned long long far_bits = __builtin_amdgcn_ballot_w64(lane < MC && s_far[lane < MC ? lane : 0] != 0);
 
     unsigned lane_bytes = (unsigned)lane * 16u;    // (not const: laundered in place inside the model loop)
 
@@ -170,8 +170,8 @@ residual_wg(const double* __restrict__ x1, const double* __restrict__ y1,
                              h6 = h[6], h7 = h[7], h8 = h[8];
                 // wave-uniform by construction (every lane reads the same LDS word); readfirstlane tells the compiler so,
                 // which keeps the choice of sweep a scalar branch instead of an exec-mask dance
-                const bool hok = ((hok_bits >> mi) & 1u) != 0;
-                const bool far = FAST && !CONTRACT && ((far_bits >> mi) & 1u) != 0;
+                const bool hok = ((hok_bits >> mi) & 1ull) != 0;
+                const bool far = FAST && !CONTRACT && ((far_bits >> mi) & 1ull) != 0;
                 const bool aok = SYM ? (s_aok[mi] != 0) : false;
                 int c_m = 0;
                 // where row m (or, TILED, this workgroup's block) starts for this wave's first chunk
@@ -401,7 +401,7 @@ static hipError_t launch_rs(const Points& p, const double* H, int M, double thr2
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);
         if (e != hipSuccess) return e;
     }
-    constexpr bool PRODUCT_SWEEP = WRITE_R && !MASK && NT && FAST && !CALIB && HSGPR && !SYM && !CONTRACT && LEAN && !TILED && SF == 0 && SEMI && MINW == 1 && PPL == 4 && MC == 16;
+    constexpr bool PRODUCT_SWEEP = WRITE_R && !MASK && NT && FAST && !CALIB && HSGPR && !SYM && !CONTRACT && LEAN && !TILED && SF == 0 && SEMI && MINW == 1 && PPL == 4 && (MC == 16 || MC == 32 || MC == 64);
     if constexpr (PRODUCT_SWEEP)
     if (resident_grid > 0 && resident_ctl && !contiguous && !swapxy && gx * psplit > resident_grid) {
         hipLaunchKernelGGL((k_residual_resident<PPL, MC, WRITE_R, MASK, NT, FAST, CALIB, HSGPR, SYM, CONTRACT, LEAN, TILED, SF, SEMI, MINW>),
@@ -430,7 +430,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     // per launch than plain ones, profiles/r03_energy.json)
     // ... and the nine coefficients of the current model through the scalar unit (s_load from H, uniform address) instead
     // of LDS broadcasts into VGPRs: the twelve linear-form operations then read one operand from SGPRs; 2.5 % less energy.
-    if (variant == 0) return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
+    if (variant == 0) return launch_rs<4, 64, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
     if (variant == -1) return launch_rs<4, 16, true, false, true, true, false, true, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);   // nt stores, forward coefficients through the scalar unit
 #ifdef MH_TUNING
     if (variant == -2)          // symmetric mode at PPL 2 (PPL 4 measured 3 % faster)
@@ -450,6 +450,10 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     if (variant >= 100)         // 100 + psplit: default kernel with a forced point split
         return launch_rs<4, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s, variant - 100);
     switch (variant) {
+    // 50 / 51 / 52: the product sweep with 16 / 32 / 64 models per work item (the product: 64 since r05), resident grid and all
+    case 50: return launch_rs<4, 16, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
+    case 51: return launch_rs<4, 32, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
+    case 52: return launch_rs<4, 64, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);
     case 1: return launch_rs<2, 16, true, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);                // PPL 2
     case 2: return launch_rs<4, 16, true, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s);                 // nt stores
     case 3: return launch_rs<4, 16, true, false, false, false>(p, H, M, thr2, R, ldr, counts, nullptr, s);         // compiler IEEE division
@@ -498,7 +502,7 @@ int residual_workgroups_per_cu()
 {
     int n = 0;
     const hipError_t he = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &n, (const void*)k_residual_resident<4, 16, true, false, true, true, false, true, false, false, true>, 256, 0);
+        &n, (const void*)k_residual_resident<4, 64, true, false, true, true, false, true, false, false, true>, 256, 0);
     return he == hipSuccess && n > 0 ? n : 0;
 }
 

@@ -835,6 +835,20 @@ def test_full_size_properties_50k_x_100k(engine, synth, oracle):
         assert np.array_equal(a[both].view(np.uint64), b[both].view(np.uint64))
 
 
+def test_full_size_every_stored_entry_is_recounted_on_the_device():
+    """The whole 40 GB matrix, not samples of it: torch (plumbing — a zero-copy view of the engine's buffer) counts, row by
+    row, the stored entries below thr^2 and the entries that are not NaN; the first must equal the kernel's fused counts for
+    all 100 000 rows — a row segment that was never stored, or stored in the wrong row, cannot hide behind the sampled
+    blocks of the test above (r05: the work item went from 16 to 64 models) — and with the matrix pre-filled with NaN the
+    second shows every entry written.  A process of its own (tests/full_matrix_recount_worker.py): torch has to initialise
+    its HIP runtime before the engine's library is loaded."""
+    import subprocess, sys
+    pytest.importorskip("torch")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "full_matrix_recount_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RECOUNT OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_full_size_symmetric_transfer_50k_x_100k(engine, synth, oracle):
     """r05: the symmetric transfer error at BASELINE configs[2] size (the 40 GB matrix in MH_RESIDUAL_SYMMETRIC mode): sampled
     row blocks bit-exactly against the oracle's restatement, fused counts == store-free score == oracle on those rows, every

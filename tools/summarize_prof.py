@@ -13,7 +13,8 @@ def materialising(name):
     """the residual kernel with WRITE_R = true (third template argument), demangled or mangled — the hardware-dispatched
     form (k_residual, r01-r03) or the resident grid (k_residual_resident, r04)"""
     return any(k in name for k in ("k_residual<4, 16, true", "k_residualILi4ELi16ELb1", "k_residual_resident<4, 16, true",
-                                   "k_residual_residentILi4ELi16ELb1"))
+                                   "k_residual_residentILi4ELi16ELb1", "k_residual<4, 64, true", "k_residualILi4ELi64ELb1",
+                                   "k_residual_resident<4, 64, true", "k_residual_residentILi4ELi64ELb1"))
 def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 for f in find("trace", "*kernel_stats.csv"):

@@ -18,6 +18,12 @@ def run(name, reps=10):
     e.synchronize(); n, ms = e.profile_get(1); e.profile_enable(False)
     ms /= max(n, 1)
     print(f"{name:40s} {ms:8.3f} ms   {8.0 * N * M / ms / 1e6:8.1f} GB/s", flush=True)
+if os.environ.get("MODELS_PER_ITEM"):                 # variants 50 / 51 / 52 of the tuning library: the product sweep with 16 / 32 / 64 models per item
+    for rep in range(int(os.environ.get("REPS", 3))):
+        for v, mc in ((50, 16), (51, 32), (52, 64)):
+            e.set_tuning(0, v)
+            run(f"{mc} models per work item")
+    sys.exit(0)
 for rep in range(2):
     for s in [int(x) for x in os.environ.get("SLICES", "0,3,6,12,24,49").split(",")]:
         e.set_tuning(26, s)
