@@ -564,7 +564,7 @@ def main():
 
     # What this box's memory takes from stores alone, measured in this run: hipMemset over the residual matrix itself (the 40 GB
     # the sweep has just written; a fill kernel of the runtime, no arithmetic).  Context for roofline.frac — the sweep computes
-    # 28 FP64 operations per pair at the board's power cap on top of the same store stream.
+    # 28 FP64 operations per pair at the board's power cap on top of the same store stream.  A reference, not a ceiling.
     memset_GBps = None
     try:
         ptr_R, bytes_R = eng.device_buffer(2)            # MH_BUF_RESIDUALS
@@ -674,9 +674,11 @@ def main():
                          "frac": frac("roofline.frac", achieved / HBM_PEAK_GBPS), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_residual", "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_write_ceiling_GBps": HBM_WRITE_CEILING_GBPS,
-                         "frac_of_measured_write_ceiling": achieved / HBM_WRITE_CEILING_GBPS,
+                         "frac_of_measured_write_ceiling": frac("roofline.frac_of_measured_write_ceiling", achieved / HBM_WRITE_CEILING_GBPS),
+                         # a same-box REFERENCE, not a ceiling (the runtime's fill kernel is not the fastest store stream: a ratio
+                         # slightly above 1 is possible and has been measured since the sweep handles 64 models per work item)
                          "memset_of_R_on_this_box_GBps": memset_GBps,
-                         "frac_of_that_memset": (achieved / memset_GBps) if memset_GBps else None,
+                         "ratio_to_that_memset": (achieved / memset_GBps) if memset_GBps else None,
                          "models_per_launch": M},
             "best_model": head["best_model"], "best_score": head["best_score"], "scores_sha256": head["scores_sha256"],
         }
