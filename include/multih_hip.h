@@ -347,7 +347,9 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  * the source image (1, default) or by the exhaustive pass (0) — the same table, schedule only, 32 mean shift: a workgroup per
  * climb through a one-coordinate index, one launch per batch (1, default, for 6- and 10-dimensional rows up to 131 072 of them;
  * 0: the launched / persistent schedule of keys 7 and 29) and 33 the members per iteration beyond which such a climb counts as
- * dense and is handed to the persistent kernel once the batch has drained (default 8) — same modes, schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
+ * dense and is handed to the persistent kernel once the batch has drained (default 8) — same modes, schedule only, 36 the
+ * rounds of mh_select_greedy after the first count their candidates on the points the last claim took out of the support set
+ * and subtract (1, default) or count them again on what is left (0) — the same selection, schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
  * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
  * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);

@@ -406,6 +406,8 @@ void mh_destroy(mh_engine* e)
     e->knn_cell.release(); e->knn_count.release(); e->knn_start.release(); e->knn_P.release(); e->knn_orig.release();
     for (int c = 0; c < 4; ++c) e->sel_pts[c].release();
     e->sel_pack_count.release();
+    for (int c = 0; c < 4; ++c) e->sel_gone[c].release();
+    e->sel_carried[0].release(); e->sel_carried[1].release(); e->sel_left.release();
     e->gb_deg.release(); e->gb_start.release(); e->gb_cursor.release(); e->gb_raw.release(); e->gb_mult.release();
     e->gb_uniq.release(); e->gb_info.release(); e->gb_hits_rp.release(); e->gb_hits_col.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
@@ -755,6 +757,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
     if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }
     if (key == 32 && (value == 0 || value == 1)) { e->tune_ms_indexed = value; return MH_OK; }     // mean shift: indexed climbs (1, default) or the launched / persistent schedule (0): same modes
+    if (key == 36 && (value == 0 || value == 1)) { e->tune_select_decrement = value; return MH_OK; }     // greedy selection: decremental rounds (1, default) — schedule only
     if (key == 33 && value >= 0 && value <= (1 << 20)) { e->tune_ms_dense = value; return MH_OK; }     // ... and the member count beyond which an indexed climb is handed on
     if (key == 30 && (value == 0 || value == 1)) { e->tune_select_refine = value; return MH_OK; }
     if (key == 31 && (value == 0 || value == 1)) { e->tune_knn_grid = value; return MH_OK; }        // k-NN through the grid (1, default) or exhaustively (0): same table     // NOT schedule-only: changes what mh_select_greedy selects       // mean shift: persistent tail below this many climbs (0 = off)

@@ -96,7 +96,7 @@ struct mh_engine {
     DevBuf<int> cp_begin, cp_tri;
     DevBuf<unsigned char> cp_ok;
     // greedy selection (select.hip): two candidate lists, control words, exchange buffers
-    DevBuf<int> sel_orig[2], sel_counts, sel_rec, sel_scores, sel_gathered;
+    DevBuf<int> sel_orig[2], sel_counts, sel_carried[2], sel_left, sel_rec, sel_scores, sel_gathered;     // (sel_carried / sel_left: r05, the decremental rounds of mh_select_greedy)
     DevBuf<double> sel_cand_H[2], sel_out_H;
     DevBuf<SelRecord> sel_records;             // [0] this rank's offer, [1 .. world] the gathered offers
     DevBuf<long long> sel_counter;
@@ -206,6 +206,8 @@ struct mh_engine {
     long long* h_acc_dev = nullptr;
     DevBuf<double> sel_pts[4];               // the active points of a greedy-selection round, packed (select.hip)
     DevBuf<int> sel_pack_count;
+    DevBuf<double> sel_gone[4];              // the points the last claim of a greedy-selection round took out of the support set, packed
+    int tune_select_decrement = 1;           // key 36: rounds count their candidates on the points that LEFT and subtract (1, default) or count again on what is left (0): same selection
     int tune_knn_grid = 1;                   // key 31: the k-NN table through the grid over the source image (0 = exhaustive pass)
     DevBuf<int> knn_cell, knn_count, knn_start, knn_orig;
     DevBuf<float> knn_P;

@@ -141,6 +141,16 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     if (point_mask) { active = 0; for (int i = 0; i < n; ++i) active += point_mask[i] != 0 ? 1 : 0; }
     for (int c = 0; c < 4; ++c) HIPCHK(e->sel_pts[c].reserve((size_t)n + 2));
     HIPCHK(e->sel_pack_count.reserve(1));
+    // r05: from the second round on a candidate's count is what it was minus what it counted on the points the last claim
+    // took out of the support set — the same integer as counting again on what is left, for a sweep over the few thousand
+    // points that left instead of the tens of thousands that stay (key 36; whichever set is smaller is swept).
+    const bool decrement = e->tune_select_decrement != 0;
+    if (decrement) {
+        for (int c = 0; c < 4; ++c) HIPCHK(e->sel_gone[c].reserve((size_t)n + 2));
+        for (int b = 0; b < 2; ++b) HIPCHK(e->sel_carried[b].reserve(cap));
+        HIPCHK(e->sel_left.reserve(cap));
+    }
+    int gone = 0;                                         // points the last claim took out
 
     int Mc = M, cur = 0, selected = 0, packed_as = -1;
     bool first = true;
@@ -153,6 +163,20 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
                 return fail(MH_ERR_HIP, "greedy selection: injected rank-local failure (test hook, mh_set_tuning key 18)");
             if (Mc <= 0) return MH_OK;
             ScopedTimer t(e, MH_K_SCORE);
+            if (decrement && !first && gone <= active) {
+                // the candidates' counts of the last round came along with them (k_sel_compact); subtract what left
+                if (gone == 0) {
+                    HIPCHK(hipMemcpyAsync(e->sel_counts.p, e->sel_carried[cur].p, sizeof(int) * (size_t)Mc, hipMemcpyDeviceToDevice, s));
+                    return MH_OK;
+                }
+                Points left = e->pts();                       // (same bounding box: a superset's is valid)
+                left.x1 = e->sel_gone[0].p; left.y1 = e->sel_gone[1].p; left.x2 = e->sel_gone[2].p; left.y2 = e->sel_gone[3].p;
+                left.n = gone;
+                const int rcs = score_models(e, left, Hs, Mc, thr2, nullptr, e->sel_left.p);
+                if (rcs) return rcs;
+                HIPCHK(launch_sel_subtract(e->sel_carried[cur].p, e->sel_left.p, Mc, e->sel_counts.p, s));
+                return MH_OK;
+            }
             if (active == n) return score_models(e, e->pts(), Hs, Mc, thr2, nullptr, e->sel_counts.p);     // every point is in the support set: no mask to read
             if (active > 0) {
                 HIPCHK(launch_sel_pack_points(e->pts(), e->mask.p, e->sel_pts[0].p, e->sel_pts[1].p, e->sel_pts[2].p, e->sel_pts[3].p,
@@ -188,7 +212,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
             if (rc) return rc;
         }
         HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, records, world, my_off, e->sel_orig[cur ^ 1].p,
-                                  e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, s));
+                                  e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, decrement ? e->sel_carried[cur ^ 1].p : nullptr, s));
         const double* refit = nullptr;
         if (refine) {
             // every rank holds all the points and the same records: the refit is computed redundantly, identically
@@ -198,7 +222,9 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
             refit = e->sel_refit.p;
         }
         HIPCHK(launch_sel_claim(e->pts(), records, world, gather_scores && !local_err ? key_check : nullptr, thr2, need, e->mask.p, e->sel_rec.p,
-                                e->sel_out_H.p, e->sel_counter.p, max_models, s, symmetric, refit));
+                                e->sel_out_H.p, e->sel_counter.p, max_models, s, symmetric, refit,
+                                decrement ? e->sel_gone[0].p : nullptr, decrement ? e->sel_gone[1].p : nullptr,
+                                decrement ? e->sel_gone[2].p : nullptr, decrement ? e->sel_gone[3].p : nullptr));
         HIPCHK(launch_sel_publish(e->sel_rec.p, e->sel_keys.p, my_record, need, e->h_sel_dev, s));
         HIPCHK(hipStreamSynchronize(s));                 // five control words through mapped memory: no copy
         if (local_rc != MH_OK) return fail(local_rc, local_msg);     // (the others have read this rank's error word by now)
@@ -211,7 +237,8 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         if (best < need) break;
         if (counts_out) counts_out[selected] = best;
         ++selected;
-        active -= e->h_sel[5];                            // what the claim took out of the support set (the winner's inliers, or its refit's)
+        gone = e->h_sel[5];
+        active -= gone;                                   // what the claim took out of the support set (the winner's inliers, or its refit's)
         Mc = e->h_sel[2];
         cur ^= 1;
         first = false;

@@ -254,10 +254,14 @@ hipError_t launch_sel_argmax_gathered(const int* gathered, int world, int longes
 hipError_t launch_sel_record(const int* counts, const int* orig, const double* Hs, int Mc, unsigned int my_off,
                              const unsigned long long* key_local, int err, int mode, SelRecord* record, hipStream_t s);
 hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need, const SelRecord* records,
-                              int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, hipStream_t s);
+                              int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, int* next_counts, hipStream_t s);
+// counts[c] = carried[c] - left[c] (r05: a round of the greedy selection counts its candidates on the points the last claim
+// took away and subtracts, instead of counting them again on everything that is left)
+hipError_t launch_sel_subtract(const int* carried, const int* left, int Mc, int* counts, hipStream_t s);
 hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
-                            hipStream_t s, int symmetric = 0, const double* refit = nullptr);
+                            hipStream_t s, int symmetric = 0, const double* refit = nullptr,
+                            double* cx1 = nullptr, double* cy1 = nullptr, double* cx2 = nullptr, double* cy2 = nullptr /* the points that leave, packed */);
 // r05 (mh_set_tuning key 30): the round's winner refitted to its inliers in the support set by the per-label HAF least squares
 // (one label); refit = 9 doubles + the refit's inlier count; launch_sel_claim takes it in the winner's place when it is finite and
 // explains at least as many points.  labels: n ints, counter / label_count: one int each (scratch).

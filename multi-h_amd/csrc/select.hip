@@ -109,15 +109,16 @@ __device__ __forceinline__ unsigned long long sel_winner(const SelRecord* __rest
 __global__ void __launch_bounds__(256)
 k_sel_compact(const int* __restrict__ counts, const int* __restrict__ orig, const double* __restrict__ Hs, int Mc, int need,
               const SelRecord* __restrict__ records, int world, unsigned int my_off, int* __restrict__ next_orig,
-              double* __restrict__ next_H, int* __restrict__ rec)
+              double* __restrict__ next_H, int* __restrict__ rec, int* __restrict__ next_counts)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const unsigned long long kg = sel_winner(records, world, nullptr);
     bool keep = false;
-    int o = 0;
+    int o = 0, cnt_c = 0;
     if (c < Mc) {
         o = orig ? orig[c] : c;
         const int cnt = counts[c];
+        cnt_c = cnt;
         const bool is_winner = kg && cnt >= 0 && sel_key(cnt, my_off + (unsigned int)o) == kg;
         keep = cnt >= need && !is_winner;
     }
@@ -132,6 +133,7 @@ k_sel_compact(const int* __restrict__ counts, const int* __restrict__ orig, cons
     if (keep) {
         const int pos = s_base + off;
         next_orig[pos] = o;
+        if (next_counts) next_counts[pos] = cnt_c;       // what the candidate counts on the support set of THIS round: the next round subtracts what leaves
         const double* h = Hs + 9 * (size_t)c;
         for (int q = 0; q < 9; ++q) next_H[9 * (size_t)pos + q] = h[q];
     }
@@ -144,7 +146,8 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
             const double* __restrict__ y2, int N, const SelRecord* __restrict__ records, int world,
             const unsigned long long* __restrict__ key_check, double thr2, int need, unsigned char* __restrict__ mask,
             int* __restrict__ rec, double* __restrict__ sel_H, long long* __restrict__ sel_counter, int max_models, int symmetric,
-            const double* __restrict__ refit /* nullable: 9 doubles + the refit's inlier count as a double */)
+            const double* __restrict__ refit /* nullable: 9 doubles + the refit's inlier count as a double */,
+            double* __restrict__ cx1, double* __restrict__ cy1, double* __restrict__ cx2, double* __restrict__ cy2 /* nullable: the points that leave, packed */)
 {
     int wr = 0;
     const unsigned long long kg = sel_winner(records, world, &wr);
@@ -189,9 +192,25 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
         leaves = d2 < thr2;
         if (leaves) mask[n] = 0;
     }
-    // rec[5]: how many points left the support set (the winner's count — or its refit's: the host keeps the size of the set)
+    // rec[5]: how many points left the support set (the winner's count — or its refit's: the host keeps the size of the set);
+    // the points themselves are packed (any order) for the next round, which subtracts what every candidate counted on them
     const unsigned long long lm = __ballot(leaves);
-    if ((threadIdx.x & 63) == 0 && lm) atomicAdd(&rec[5], (int)__popcll(lm));
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && lm) base = atomicAdd(&rec[5], (int)__popcll(lm));
+    base = __shfl(base, 0, 64);
+    if (leaves && cx1) {
+        const int at = base + (int)__popcll(lm & ((1ull << lane) - 1ull));
+        cx1[at] = x1[n]; cy1[at] = y1[n]; cx2[at] = x2[n]; cy2[at] = y2[n];
+    }
+}
+
+// counts[c] = carried[c] - left[c]: what candidate c counts on the support set once the points of the last claim are gone
+__global__ void __launch_bounds__(256)
+k_sel_subtract(const int* __restrict__ carried, const int* __restrict__ left, int Mc, int* __restrict__ counts)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < Mc) counts[c] = carried[c] - left[c];
 }
 
 // ---- the winner refitted to its inliers before it claims them (r05, mh_set_tuning key 30) --------------------------------
@@ -388,20 +407,27 @@ hipError_t launch_sel_record(const int* counts, const int* orig, const double* H
 }
 
 hipError_t launch_sel_compact(const int* counts, const int* orig, const double* Hs, int Mc, int need, const SelRecord* records,
-                              int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, hipStream_t s)
+                              int world, unsigned int my_off, int* next_orig, double* next_H, int* rec, int* next_counts, hipStream_t s)
 {
     if (Mc <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_sel_compact, dim3((Mc + 255) / 256), dim3(256), 0, s, counts, orig, Hs, Mc, need, records, world, my_off,
-                       next_orig, next_H, rec);
+                       next_orig, next_H, rec, next_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_sel_subtract(const int* carried, const int* left, int Mc, int* counts, hipStream_t s)
+{
+    if (Mc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sel_subtract, dim3((Mc + 255) / 256), dim3(256), 0, s, carried, left, Mc, counts);
     return hipGetLastError();
 }
 
 hipError_t launch_sel_claim(const Points& p, const SelRecord* records, int world, const unsigned long long* key_check, double thr2,
                             int need, unsigned char* mask, int* rec, double* sel_H, long long* sel_counter, int max_models,
-                            hipStream_t s, int symmetric, const double* refit)
+                            hipStream_t s, int symmetric, const double* refit, double* cx1, double* cy1, double* cx2, double* cy2)
 {
     hipLaunchKernelGGL(k_sel_claim, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, records, world,
-                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models, symmetric, refit);
+                       key_check, thr2, need, mask, rec, sel_H, sel_counter, max_models, symmetric, refit, cx1, cy1, cx2, cy2);
     return hipGetLastError();
 }
 

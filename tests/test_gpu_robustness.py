@@ -176,6 +176,44 @@ def test_greedy_selection_with_refitted_winners(mh, engine, synth, oracle):
         e2.close()
 
 
+@pytest.mark.parametrize("refit", [0, 1])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_greedy_selection_rounds_by_subtraction_or_by_recount(mh, engine, synth, oracle, refit, symmetric):
+    """r05 (mh_set_tuning key 36): from the second round on a candidate's count is what it was minus what it counts on the
+    points the last claim took out of the support set — the same integer as counting it again on what is left.  A
+    schedule: models, positions, counts and support mask are the same with the key on and off, for plain and refitted
+    winners, in both residual modes, from a support mask with holes; and, in the forward mode, equal the oracle's."""
+    sc = mh.synth.make_scene(9000, 5, seed=21, with_neighbours=False)
+    engine.set_correspondences(sc.src, sc.dst, sc.aff)
+    engine.set_epipolar(sc.F, sc.e2)
+    thr2 = 2.2 ** 2
+    holes = np.ones(sc.n, np.uint8)
+    holes[::7] = 0
+    got = {}
+    try:
+        if symmetric: engine.set_residual_mode(True)
+        engine.set_tuning(30, refit)
+        for dec in (1, 0):
+            engine.set_tuning(36, dec)
+            engine.propose_dlt4(17, 0, 6000)
+            got[dec] = engine.select_greedy(thr2, 25, 10, holes.copy())
+    finally:
+        engine.set_tuning(36, 1)
+        engine.set_tuning(30, 0)
+        if symmetric: engine.set_residual_mode(False)
+    (H1, i1, c1, m1), (H0, i0, c0, m0) = got[1], got[0]
+    assert len(i1) >= 4
+    assert np.array_equal(i1, i0) and np.array_equal(c1, c0) and np.array_equal(m1, m0)
+    assert np.array_equal(H1.view(np.uint64), H0.view(np.uint64))
+    assert (c1[1:] <= c1[:-1] + 0).all() or refit            # (plain winners: counts never rise from round to round)
+    if not symmetric and not refit:
+        engine.propose_dlt4(17, 0, 6000)
+        H = engine.get_models()
+        with np.errstate(all="ignore"):
+            ref = oracle.select_greedy(sc.src, sc.dst, H, thr2, 25, 10, holes.copy())
+        assert np.array_equal(i1, ref[1]) and np.array_equal(c1, ref[2]) and np.array_equal(m1, ref[3])
+
+
 def test_refitted_selection_stress_against_the_oracle():
     """tools/stress_select_refit.py: random scenes, batch sizes, thresholds, support masks with holes, duplicate and collinear
     points — every refitted selection equal to the oracle's, model for model and bit for bit.  (Its first run found that the
