@@ -39,47 +39,65 @@ k_haf_reestimate(const double* __restrict__ x1, const double* __restrict__ y1,
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.0;
     int cnt = 0;
-    // A lane's members are added up in index order (the oracle's order).  The loop is latency bound — one dependent
-    // trip to memory per point — so the loads of UNROLL points are issued together; the additions keep their order.
-    constexpr int UNROLL = 4;
-    for (int n0 = t; n0 < N; n0 += 256 * UNROLL) {
-        int lb[UNROLL];
-        double in[UNROLL][8];
+    // A lane's members are added up in index order (the oracle's order).  The loop is latency bound, and most points
+    // carry another label: the labels of 32 of the lane's points are fetched together (one trip to memory), the
+    // correspondences and affinities only of those that match, four at a time (r05; before: all eight doubles of EVERY
+    // point, four points per trip — 85 of the launch's 110 us at 50 000 points, whatever the label's size).  The additions
+    // keep their order.
+    auto add_point = [&](const double (&in)[8]) {
+        const double a11 = in[0], a12 = in[1], a21 = in[2], a22 = in[3];
+        const double px = in[4], py = in[5], qx = in[6], qy = in[7];
+        double r[6][4];
+        r[0][0] = a11 * px + qx - ex; r[0][1] = a11 * py;           r[0][2] = a11; r[0][3] = -F[3];
+        r[1][0] = a12 * px;           r[1][1] = a12 * py + qx - ex; r[1][2] = a12; r[1][3] = -F[4];
+        r[2][0] = a21 * px + qy - ey; r[2][1] = a21 * py;           r[2][2] = a21; r[2][3] = F[0];
+        r[3][0] = a22 * px;           r[3][1] = a22 * py + qy - ey; r[3][2] = a22; r[3][3] = F[1];
+        r[4][0] = ex * px - qx * px;  r[4][1] = ex * py - qx * py;  r[4][2] = ex - qx;
+        r[4][3] = px * F[3] + py * F[4] + F[5];
+        r[5][0] = ey * px - qy * px;  r[5][1] = ey * py - qy * py;  r[5][2] = ey - qy;
+        r[5][3] = -(px * F[0] + py * F[1] + F[2]);
+        int k = 0;
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = i; jj < 4; ++jj) {
+                double s = r[0][i] * r[0][jj];
+#pragma unroll
+                for (int q = 1; q < 6; ++q) s = s + r[q][i] * r[q][jj];
+                acc[k] = acc[k] + s;
+                ++k;
+            }
+        ++cnt;
+    };
+    constexpr int BATCH = 32, UNROLL = 4;
+    for (int n0 = t; n0 < N; n0 += 256 * BATCH) {
+        int lb[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {                    // 32 independent loads in flight
             const int n = n0 + 256 * j;
-            const bool ok = n < N;
-            const int m = ok ? n : 0;
-            lb[j] = ok ? labels[m] : -2;
-            in[j][0] = a11p[m]; in[j][1] = a12p[m]; in[j][2] = a21p[m]; in[j][3] = a22p[m];
-            in[j][4] = x1[m]; in[j][5] = y1[m]; in[j][6] = x2[m]; in[j][7] = y2[m];
+            lb[j] = labels[n < N ? n : 0];
         }
+        unsigned match = 0;                                  // bit j: point n0 + 256 j carries label l
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
-            if (lb[j] != l) continue;
-            const double a11 = in[j][0], a12 = in[j][1], a21 = in[j][2], a22 = in[j][3];
-            const double px = in[j][4], py = in[j][5], qx = in[j][6], qy = in[j][7];
-            double r[6][4];
-            r[0][0] = a11 * px + qx - ex; r[0][1] = a11 * py;           r[0][2] = a11; r[0][3] = -F[3];
-            r[1][0] = a12 * px;           r[1][1] = a12 * py + qx - ex; r[1][2] = a12; r[1][3] = -F[4];
-            r[2][0] = a21 * px + qy - ey; r[2][1] = a21 * py;           r[2][2] = a21; r[2][3] = F[0];
-            r[3][0] = a22 * px;           r[3][1] = a22 * py + qy - ey; r[3][2] = a22; r[3][3] = F[1];
-            r[4][0] = ex * px - qx * px;  r[4][1] = ex * py - qx * py;  r[4][2] = ex - qx;
-            r[4][3] = px * F[3] + py * F[4] + F[5];
-            r[5][0] = ey * px - qy * px;  r[5][1] = ey * py - qy * py;  r[5][2] = ey - qy;
-            r[5][3] = -(px * F[0] + py * F[1] + F[2]);
-            int k = 0;
+        for (int j = 0; j < BATCH; ++j) match |= (n0 + 256 * j < N && lb[j] == l) ? 1u << j : 0u;
+        while (match) {                                      // ascending j = ascending point index
+            int idx[UNROLL];
+            double in[UNROLL][8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = i; jj < 4; ++jj) {
-                    double s = r[0][i] * r[0][jj];
-#pragma unroll
-                    for (int q = 1; q < 6; ++q) s = s + r[q][i] * r[q][jj];
-                    acc[k] = acc[k] + s;
-                    ++k;
+            for (int u = 0; u < UNROLL; ++u) {
+                idx[u] = -1;
+                if (match) {
+                    const int j = __builtin_ctz(match);
+                    match &= match - 1u;
+                    idx[u] = n0 + 256 * j;
                 }
-            ++cnt;
+                const int m = idx[u] >= 0 ? idx[u] : 0;
+                in[u][0] = a11p[m]; in[u][1] = a12p[m]; in[u][2] = a21p[m]; in[u][3] = a22p[m];
+                in[u][4] = x1[m]; in[u][5] = y1[m]; in[u][6] = x2[m]; in[u][7] = y2[m];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (idx[u] >= 0) add_point(in[u]);
         }
     }
 

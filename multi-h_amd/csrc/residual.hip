@@ -567,16 +567,29 @@ k_moments(const double* __restrict__ x1, const double* __restrict__ y1,
                  h7 = h[7], h8 = h[8];
     double acc[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
     int cnt = 0;
-    for (int n = t; n < N; n += 256) {
-        const double x = x1[n], y = y1[n];
-        const double d2 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, x, y, x2[n], y2[n]);
-        if (d2 < thr2) {
-            acc[0] = acc[0] + x;
-            acc[1] = acc[1] + y;
-            acc[2] = acc[2] + x * x;
-            acc[3] = acc[3] + x * y;
-            acc[4] = acc[4] + y * y;
-            ++cnt;
+    // (latency bound — a trip to memory per point and lane —: the coordinates of eight of the lane's points are fetched
+    // together; the additions keep their order)
+    constexpr int UNROLL = 8;
+    for (int n0 = t; n0 < N; n0 += 256 * UNROLL) {
+        double px[UNROLL], py[UNROLL], qx[UNROLL], qy[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int n = n0 + 256 * j, mm = n < N ? n : 0;
+            px[j] = x1[mm]; py[j] = y1[mm]; qx[j] = x2[mm]; qy[j] = y2[mm];
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            if (n0 + 256 * j >= N) continue;
+            const double x = px[j], y = py[j];
+            const double d2 = fwd_d2(h0, h1, h2, h3, h4, h5, h6, h7, h8, x, y, qx[j], qy[j]);
+            if (d2 < thr2) {
+                acc[0] = acc[0] + x;
+                acc[1] = acc[1] + y;
+                acc[2] = acc[2] + x * x;
+                acc[3] = acc[3] + x * y;
+                acc[4] = acc[4] + y * y;
+                ++cnt;
+            }
         }
     }
     __shared__ double sv[256][5];
