@@ -101,6 +101,17 @@ MH_API int mh_get_sym_graph(mh_engine* e, int* rowptr, int* col, int* w, int* nn
  * engine's own GPU version of that step (normalised 8-point hypotheses from counter-RNG 8-tuples,
  * Sampson-distance scoring, least-squares refit on the inliers); results are inputs for
  * mh_set_epipolar.  They do not touch the homography model set. */
+/* What "distance to the epipolar geometry" means in mh_score_sampson / mh_refit_fundamental / mh_estimate_fundamental
+ * (r06; part of the result's definition, so an entry point of its own and not an mh_set_tuning key):
+ *   MH_FUND_SAMPSON       e^2 / (a^2 + b^2 + a'^2 + b'^2)            — the engine's default since r02
+ *   MH_FUND_EPIPOLAR_MAX  max(e^2 / (a^2 + b^2), e^2 / (a'^2 + b'^2)) — the squared point-to-epipolar-line distance, the
+ *                         larger of the two images: what cv::findFundamentalMat compares with its threshold (OpenCV 3.1.0
+ *                         FMEstimatorCallback::computeError; the call sites are M/main.cpp:400 at 2.0 px and
+ *                         M/MultiH.cpp:775 at threshold_fundamental_matrix).  At least twice the Sampson value at equal F (equal when both line normals have the same length).
+ * Stays set until changed; mh_set_correspondences does not reset it. */
+#define MH_FUND_SAMPSON 0
+#define MH_FUND_EPIPOLAR_MAX 1
+MH_API int mh_set_fundamental_metric(mh_engine* e, int metric);
 MH_API int mh_propose_fund8(mh_engine* e, unsigned long long seed, long long first, int m);
 MH_API int mh_get_fund_hypotheses(mh_engine* e, double* F /* m x 9 */, int* idx /* m x 8, nullable */);
 MH_API int mh_score_sampson(mh_engine* e, double thr2, int* counts /* m */);
@@ -122,6 +133,13 @@ MH_API int mh_epipoles(mh_engine* e, const double F[9], double e1[2], double e2[
  * keep (n): 1 where the point survives; refined (n x 8): x1 y1 x2 y2 a11 a12 a21 a22 of survivors. */
 MH_API int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2], const double e2[2],
                               const unsigned char* in_mask, unsigned char* keep, double* refined);
+/* r06: at which stage of M/MultiH.cpp:807-838 each row of the LAST mh_refine_correspondences call left (n = its row count):
+ * the stage table of the harness (rows after the RANSAC mask, after OptimalTriangulation, after distanceError > 1). */
+#define MH_REFINE_KEPT 0
+#define MH_REFINE_NOT_IN_MASK 1          /* :809  mask[i] == 0 */
+#define MH_REFINE_TRIANGULATION 2        /* :815-817  OptimalTriangulation failed (optimum at infinity, :1170-1175) */
+#define MH_REFINE_AFFINE_TEST 3          /* :826  distanceError > 1 (a NaN is dropped here too) */
+MH_API int mh_get_refine_reasons(mh_engine* e, unsigned char* reason /* n */, int n);
 
 /* ---- reference-style initialisation ------------- */
 /* ComputeLocalHomographies (M/MultiH.cpp:696-717, GetHomographyHAF :850-911): one homography per
@@ -313,7 +331,11 @@ MH_API int mh_device_buffer(mh_engine* e, int which, void** ptr_dev, unsigned lo
 /* Per-kernel HIP-event timing on the engine's stream.  When enabled every launch of the
  * instrumented kernels is bracketed by events; stats are resolved at the next synchronize. */
 enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K_EXPAND = 4,
-       MH_K_REESTIMATE = 5, MH_K_COSTMATRIX = 6, MH_K_COUNT_ = 7 };
+       MH_K_REESTIMATE = 5, MH_K_COSTMATRIX = 6,
+       /* r06: what mh_select_best enqueues on the exchange stream — the all-gather of the scores (when a transport is set)
+        * and the arg-max launch behind it — from the moment the batch's sweep has ended to the end of that launch: a rank's
+        * wait for its peers plus the wire time, per exchange */
+       MH_K_EXCHANGE = 7, MH_K_COUNT_ = 8 };
 MH_API int mh_profile_enable(mh_engine* e, int on);
 MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);

@@ -28,6 +28,12 @@ __attribute__((visibility("default"))) int mhr_allgather(void* comm, const void*
 __attribute__((visibility("default"))) void mhr_destroy(mhr_comm* c);
 __attribute__((visibility("default"))) const char* mhr_last_error(void);
 __attribute__((visibility("default"))) long long mhr_calls(const mhr_comm* c);      // collectives enqueued so far (tests, logs)
+// r06: what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank) — read back into every bench line
+// and harness log, so that a multi-GPU number states how many ranks the collective really spanned — and the library's
+// version code (ncclGetVersion: major * 10000 + minor * 100 + patch).  -1 on failure (mhr_last_error).
+__attribute__((visibility("default"))) int mhr_count(const mhr_comm* c);
+__attribute__((visibility("default"))) int mhr_rank(const mhr_comm* c);
+__attribute__((visibility("default"))) int mhr_version(void);
 
 #ifdef __cplusplus
 }

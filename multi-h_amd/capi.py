@@ -23,8 +23,8 @@ K_DLT4, K_RESIDUAL, K_SCORE, K_DATACOST, K_EXPAND, K_REESTIMATE, K_COSTMATRIX = 
 SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_create", "mh_destroy", "mh_set_params",
     "mh_set_stream", "mh_synchronize", "mh_set_correspondences", "mh_set_epipolar",
-    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_build_neighbors_knn_radius", "mh_build_neighbors_radius", "mh_get_sym_graph", "mh_propose_fund8",
-    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences",
+    "mh_set_neighbors_csr", "mh_build_neighbors_knn", "mh_build_neighbors_knn_radius", "mh_build_neighbors_radius", "mh_get_sym_graph", "mh_set_fundamental_metric", "mh_propose_fund8",
+    "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences", "mh_get_refine_reasons",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_get_score_stats", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_compat_trial_stats", "mh_inlier_moments", "mh_data_cost", "mh_expand",
@@ -183,6 +183,10 @@ class Engine:
                                                   _p(out, C.c_double), _p(mask, C.c_ubyte), C.byref(inl)))
         return out, mask, inl.value
 
+    def set_fundamental_metric(self, metric: int) -> None:
+        """0 = Sampson (default), 1 = the larger squared point-to-epipolar-line distance (cv::findFundamentalMat's)."""
+        self._check(self.lib.mh_set_fundamental_metric(self._h, int(metric)))
+
     def estimate_fundamental(self, seed: int, hypotheses: int, thr: float):
         F = np.empty(9, dtype=np.float64)
         e2 = np.empty(2, dtype=np.float64)
@@ -210,6 +214,12 @@ class Engine:
         self._check(self.lib.mh_refine_correspondences(self._h, _p(F, C.c_double), _p(e1, C.c_double), _p(e2, C.c_double),
                                                        mp, _p(keep, C.c_ubyte), _p(out, C.c_double)))
         return keep, out
+
+    def refine_reasons(self):
+        """Per row of the last refine_correspondences call: 0 kept, 1 not in the mask, 2 triangulation, 3 affine test."""
+        r = np.empty(self.n, dtype=np.uint8)
+        self._check(self.lib.mh_get_refine_reasons(self._h, _p(r, C.c_ubyte), int(self.n)))
+        return r
 
     # -- reference-style initialisation ------------------------------------------
     def local_homographies(self, locality: float):

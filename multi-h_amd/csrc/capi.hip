@@ -731,6 +731,7 @@ int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms)
     if (!e || kernel < 0 || kernel >= MH_K_COUNT_) return fail(MH_ERR_INVALID, "bad kernel id");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->xchg_stream) HIPCHK(hipStreamSynchronize(e->xchg_stream));      // MH_K_EXCHANGE's events live there
     resolve_timers(e);
     if (launches) *launches = e->timers[kernel].launches;
     if (total_ms) *total_ms = e->timers[kernel].total_ms;

@@ -152,9 +152,11 @@ struct mh_engine {
 
     // epipolar front half
     int fm = 0;
+    int fund_metric = 0;                       // mh_set_fundamental_metric: MH_FUND_SAMPSON / MH_FUND_EPIPOLAR_MAX (changes results: not a tuning key)
     DevBuf<double> fund, fund_one;
     DevBuf<int> fund_samples, fund_counts, fund_inl;
-    DevBuf<unsigned char> fund_mask, ref_keep, ref_in;
+    DevBuf<unsigned char> fund_mask, ref_keep, ref_in, ref_reason;
+    int ref_reason_n = 0;                      // rows of the last mh_refine_correspondences (mh_get_refine_reasons)
     DevBuf<double> ref_out;
 
     // reference-style initialisation

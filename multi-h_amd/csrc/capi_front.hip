@@ -65,13 +65,24 @@ int mh_get_fund_hypotheses(mh_engine* e, double* F, int* idx)
     });
 }
 
+int mh_set_fundamental_metric(mh_engine* e, int metric)
+{
+    return guarded([&]() -> int {
+    int rc = enter(e);
+    if (rc) return rc;
+    if (metric != MH_FUND_SAMPSON && metric != MH_FUND_EPIPOLAR_MAX) return fail(MH_ERR_INVALID, "unknown epipolar error definition");
+    e->fund_metric = metric;
+    return MH_OK;
+    });
+}
+
 int mh_score_sampson(mh_engine* e, double thr2, int* counts)
 {
     return guarded([&]() -> int {
     int rc = require_points(e);
     if (rc) return rc;
     if (e->fm <= 0) return fail(MH_ERR_NOT_SET, "no fundamental-matrix hypotheses; call mh_propose_fund8");
-    HIPCHK(launch_sampson_score(e->pts(), e->fund.p, e->fm, thr2, e->fund_counts.p, e->stream));
+    HIPCHK(launch_sampson_score(e->pts(), e->fund.p, e->fm, thr2, e->fund_counts.p, e->stream, e->fund_metric));
     if (counts) {
         HIPCHK(hipMemcpyAsync(counts, e->fund_counts.p, sizeof(int) * e->fm, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -94,7 +105,7 @@ int mh_refit_fundamental(mh_engine* e, const double F_in[9], double thr2, int it
     for (int it = 0; it < iterations; ++it) {
         double* in = e->fund_one.p + 9 * (it & 1);
         double* out = e->fund_one.p + 9 * ((it + 1) & 1);
-        HIPCHK(launch_fund_refit(e->pts(), in, thr2, out, e->fund_mask.p, e->fund_inl.p, e->stream));
+        HIPCHK(launch_fund_refit(e->pts(), in, thr2, out, e->fund_mask.p, e->fund_inl.p, e->stream, e->fund_metric));
     }
     HIPCHK(hipMemcpyAsync(F_out, e->fund_one.p + 9 * (iterations & 1), sizeof(double) * 9, hipMemcpyDeviceToHost, e->stream));
     if (inlier_mask) HIPCHK(hipMemcpyAsync(inlier_mask, e->fund_mask.p, e->n, hipMemcpyDeviceToHost, e->stream));
@@ -165,6 +176,8 @@ int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2
     if (!e->have_aff) return fail(MH_ERR_NOT_SET, "affinities are not set");
     HIPCHK(e->ref_keep.reserve((size_t)e->n + 2));
     HIPCHK(e->ref_out.reserve((size_t)e->n * 8));
+    HIPCHK(e->ref_reason.reserve((size_t)e->n + 2));
+    e->ref_reason_n = 0;
     const unsigned char* dmask = nullptr;
     if (in_mask) {
         HIPCHK(e->ref_in.reserve((size_t)e->n + 2));
@@ -173,9 +186,24 @@ int mh_refine_correspondences(mh_engine* e, const double F[9], const double e1[2
     }
     HIPCHK(hipMemsetAsync(e->ref_out.p, 0, sizeof(double) * 8 * (size_t)e->n, e->stream));
     Affines a{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
-    HIPCHK(launch_refine_points(e->pts(), a, F, e1, e2, dmask, e->ref_keep.p, e->ref_out.p, e->stream));
+    HIPCHK(launch_refine_points(e->pts(), a, F, e1, e2, dmask, e->ref_keep.p, e->ref_out.p, e->ref_reason.p, e->stream));
     HIPCHK(hipMemcpyAsync(keep, e->ref_keep.p, e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(refined, e->ref_out.p, sizeof(double) * 8 * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ref_reason_n = e->n;
+    return MH_OK;
+    });
+}
+
+int mh_get_refine_reasons(mh_engine* e, unsigned char* reason, int n)
+{
+    return guarded([&]() -> int {
+    int rc = enter(e);
+    if (rc) return rc;
+    if (!reason) return fail(MH_ERR_INVALID, "null argument");
+    if (e->ref_reason_n <= 0) return fail(MH_ERR_NOT_SET, "no mh_refine_correspondences call to report on");
+    if (n != e->ref_reason_n) return fail(MH_ERR_INVALID, "the last mh_refine_correspondences call had another number of rows");
+    HIPCHK(hipMemcpyAsync(reason, e->ref_reason.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
     });

@@ -357,12 +357,15 @@ int mh_select_best(mh_engine* e, long long total_m, long long* best_index, int* 
         const bool rotate = !fetch && local_rc == MH_OK;
         int* clear = rotate ? e->counts.p : nullptr;
         const int clear_count = rotate ? (int)e->counts.cap : 0;     // (all of it: the next batch it serves may be larger)
-        if (sharded) {
-            rc = exchange(e, e->counts.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, x);      // north_star's all-gather
-            if (rc) return rc;
-            HIPCHK(launch_best_fused(e->sel_gathered.p, world, longest, base, rem, e->h_best_dev, clear, clear_count, x));
-        } else {
-            HIPCHK(launch_best_fused(e->counts.p, 1, e->m, 0, 0, e->h_best_dev, clear, clear_count, x));
+        {
+            ScopedTimer t(e, MH_K_EXCHANGE, x);
+            if (sharded) {
+                rc = exchange(e, e->counts.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, x);      // north_star's all-gather
+                if (rc) return rc;
+                HIPCHK(launch_best_fused(e->sel_gathered.p, world, longest, base, rem, e->h_best_dev, clear, clear_count, x));
+            } else {
+                HIPCHK(launch_best_fused(e->counts.p, 1, e->m, 0, 0, e->h_best_dev, clear, clear_count, x));
+            }
         }
         const int par = (int)(e->xchg_calls % 3);
         HIPCHK(hipEventRecord(e->ev_x[par], x));

@@ -9,13 +9,22 @@
 //     a' = (f0 u + f3 v) + f6     b' = (f1 u + f4 v) + f7                                  (F^T p2)
 //     e = (u a + v b) + c         d = (e*e) / (((a*a + b*b) + a'*a') + b'*b')
 // inlier <=> d < thr^2 (strict).  Compiled with -ffp-contract=off like everything else.
+//
+// r06: a second error definition, selected per engine (mh_set_fundamental_metric): the one cv::findFundamentalMat
+// thresholds (OpenCV 3.1.0 calib3d, FMEstimatorCallback::computeError — published source outside /root/reference, restated;
+// parity unpinned): the squared distance of each point to the epipolar line of the other, the LARGER of the two,
+//     d = max((e*e) / (a*a + b*b), (e*e) / (a'*a' + b'*b'))
+// with e, a, b, a', b' as above (e is the same bilinear form seen from either image).  At equal F it is at least twice the
+// Sampson distance (e^2 / min(A, B) against e^2 / (A + B)), so a threshold in pixels means what the reference's caller means by it (M/main.cpp:400: 2.0 px,
+// M/MultiH.cpp:775: threshold_fundamental_matrix).
 
 #include "mh_kernels.hpp"
 #include "mh_device.hpp"
 
 namespace mh {
 
-__device__ __forceinline__ double sampson_d(const double* f, double x, double y, double u, double v)
+template <int METRIC>
+__device__ __forceinline__ double epipolar_d(const double* f, double x, double y, double u, double v)
 {
     const double a = f[0] * x + f[1] * y + f[2];
     const double b = f[3] * x + f[4] * y + f[5];
@@ -23,12 +32,15 @@ __device__ __forceinline__ double sampson_d(const double* f, double x, double y,
     const double a2 = f[0] * u + f[3] * v + f[6];
     const double b2 = f[1] * u + f[4] * v + f[7];
     const double e = u * a + v * b + c;
-    return (e * e) / (a * a + b * b + a2 * a2 + b2 * b2);
+    if (METRIC == 0) return (e * e) / (a * a + b * b + a2 * a2 + b2 * b2);
+    const double d2 = (e * e) / (a * a + b * b);          // p2 to the line F p1
+    const double d1 = (e * e) / (a2 * a2 + b2 * b2);      // p1 to the line F^T p2
+    return d1 > d2 ? d1 : d2;
 }
 
 // Same decomposition as k_residual: a workgroup owns MC hypotheses (coefficients in LDS) and sweeps
 // all points held PPL per lane in registers; counts via ballot + s_bcnt1, finished in the workgroup.
-template <int PPL, int MC>
+template <int PPL, int MC, int METRIC>
 __global__ void __launch_bounds__(256)
 k_sampson(const double* __restrict__ x1, const double* __restrict__ y1,
           const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -62,7 +74,7 @@ k_sampson(const double* __restrict__ x1, const double* __restrict__ y1,
             int c_m = 0;
 #pragma unroll
             for (int c = 0; c < PPL; ++c) {
-                const double d = sampson_d(f, px[c], py[c], qx[c], qy[c]);
+                const double d = epipolar_d<METRIC>(f, px[c], py[c], qx[c], qy[c]);
                 c_m += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[c] && d < thr2));
             }
             cnt += (lane == mi) ? c_m : 0;
@@ -78,11 +90,15 @@ k_sampson(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 hipError_t launch_sampson_score(const Points& p, const double* F, int M, double thr2, int* counts,
-                                hipStream_t s)
+                                hipStream_t s, int metric)
 {
     if (M <= 0 || p.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((k_sampson<4, 16>), dim3((M + 15) / 16), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2,
-                       p.n, F, M, thr2, counts);
+    if (metric == 0)
+        hipLaunchKernelGGL((k_sampson<4, 16, 0>), dim3((M + 15) / 16), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2,
+                           p.n, F, M, thr2, counts);
+    else
+        hipLaunchKernelGGL((k_sampson<4, 16, 1>), dim3((M + 15) / 16), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2,
+                           p.n, F, M, thr2, counts);
     return hipGetLastError();
 }
 
@@ -109,6 +125,7 @@ __device__ __forceinline__ void tree_reduce(double (*sv)[K], int t)
     }
 }
 
+template <int METRIC>
 __global__ void __launch_bounds__(256)
 k_fund_refit(const double* __restrict__ x1, const double* __restrict__ y1,
              const double* __restrict__ x2, const double* __restrict__ y2, int N,
@@ -128,7 +145,7 @@ k_fund_refit(const double* __restrict__ x1, const double* __restrict__ y1,
         int cnt = 0;
         for (int n = t; n < N; n += 256) {
             const double x = x1[n], y = y1[n], u = x2[n], v = y2[n];
-            const bool in = sampson_d(f, x, y, u, v) < thr2;
+            const bool in = epipolar_d<METRIC>(f, x, y, u, v) < thr2;
             if (mask_out) mask_out[n] = in ? 1 : 0;
             if (in) { a0 = a0 + x; a1 = a1 + y; a2 = a2 + u; a3 = a3 + v; ++cnt; }
         }
@@ -162,7 +179,7 @@ k_fund_refit(const double* __restrict__ x1, const double* __restrict__ y1,
         double d1 = 0.0, d2 = 0.0;
         for (int n = t; n < N; n += 256) {
             const double x = x1[n], y = y1[n], u = x2[n], v = y2[n];
-            if (sampson_d(f, x, y, u, v) < thr2) {
+            if (epipolar_d<METRIC>(f, x, y, u, v) < thr2) {
                 const double ax = x - cx1, ay = y - cy1, bx = u - cx2, by = v - cy2;
                 d1 = d1 + sqrt(ax * ax + ay * ay);
                 d2 = d2 + sqrt(bx * bx + by * by);
@@ -189,7 +206,7 @@ k_fund_refit(const double* __restrict__ x1, const double* __restrict__ y1,
         for (int k = 0; k < 45; ++k) acc[k] = 0.0;
         for (int n = t; n < N; n += 256) {
             const double x0 = x1[n], y0 = y1[n], u0 = x2[n], v0 = y2[n];
-            if (sampson_d(f, x0, y0, u0, v0) < thr2) {
+            if (epipolar_d<METRIC>(f, x0, y0, u0, v0) < thr2) {
                 const double x = (x0 - cx1) * s1, y = (y0 - cy1) * s1, u = (u0 - cx2) * s2, v = (v0 - cy2) * s2;
                 const double r[9] = { u * x, u * y, u, v * x, v * y, v, x, y, 1.0 };
                 int k = 0;
@@ -255,10 +272,14 @@ k_fund_refit(const double* __restrict__ x1, const double* __restrict__ y1,
 }
 
 hipError_t launch_fund_refit(const Points& p, const double* F_in, double thr2, double* F_out,
-                             unsigned char* mask_out, int* count_out, hipStream_t s)
+                             unsigned char* mask_out, int* count_out, hipStream_t s, int metric)
 {
-    hipLaunchKernelGGL(k_fund_refit, dim3(1), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, F_in, thr2,
-                       F_out, mask_out, count_out);
+    if (metric == 0)
+        hipLaunchKernelGGL(k_fund_refit<0>, dim3(1), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, F_in, thr2,
+                           F_out, mask_out, count_out);
+    else
+        hipLaunchKernelGGL(k_fund_refit<1>, dim3(1), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2, p.n, F_in, thr2,
+                           F_out, mask_out, count_out);
     return hipGetLastError();
 }
 

@@ -72,11 +72,12 @@ hipError_t launch_fund8(const Points& p, unsigned long long seed, long long firs
                         int* idx_out /* M x 8 */, double* F_out, hipStream_t s);
 
 // --- fund.hip ---------------------------------------------------------------
+// metric: MH_FUND_SAMPSON (0) or MH_FUND_EPIPOLAR_MAX (1), see fund.hip
 hipError_t launch_sampson_score(const Points& p, const double* F, int M, double thr2, int* counts,
-                                hipStream_t s);
-// Least-squares 8-point refit of F on the Sampson inliers of F_in (one workgroup).
+                                hipStream_t s, int metric);
+// Least-squares 8-point refit of F on the inliers of F_in under `metric` (one workgroup).
 hipError_t launch_fund_refit(const Points& p, const double* F_in, double thr2, double* F_out,
-                             unsigned char* mask_out, int* count_out, hipStream_t s);
+                             unsigned char* mask_out, int* count_out, hipStream_t s, int metric);
 
 // --- datacost.hip -----------------------------------------------------------
 // the data cost of every model against every point, int32, model-major with pitch ldc (datacost.hip)
@@ -97,7 +98,7 @@ hipError_t launch_haf_point(const Points& p, const Affines& a, const Epipolar& e
 // --- refine.hip -------------------------------------------------------------
 hipError_t launch_refine_points(const Points& p, const Affines& a, const double F[9], const double e1[2],
                                 const double e2[2], const unsigned char* in_mask, unsigned char* keep,
-                                double* out /* n x 8 */, hipStream_t s);
+                                double* out /* n x 8 */, unsigned char* reason /* n: MH_REFINE_* */, hipStream_t s);
 
 // --- meanshift.hip ----------------------------------------------------------
 constexpr int MS_BATCH = 256;   // climbs per batch: part of the definition of the seed order (meanshift.hip; the oracle draws alike)

@@ -67,12 +67,15 @@ k_refine_points(const double* __restrict__ x1, const double* __restrict__ y1,
                 const double* __restrict__ a11p, const double* __restrict__ a12p,
                 const double* __restrict__ a21p, const double* __restrict__ a22p, int N, RefineGeom g,
                 const unsigned char* __restrict__ in_mask, unsigned char* __restrict__ keep,
-                double* __restrict__ out /* N x 8: x1 y1 x2 y2 a11 a12 a21 a22 */)
+                double* __restrict__ out /* N x 8: x1 y1 x2 y2 a11 a12 a21 a22 */,
+                unsigned char* __restrict__ reason /* N: MH_REFINE_* — which stage of :807-838 a row left at */)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     keep[n] = 0;
+    reason[n] = 1;                                             // MH_REFINE_NOT_IN_MASK
     if (in_mask && !in_mask[n]) return;                        // :809 (F-RANSAC mask)
+    reason[n] = 2;                                             // MH_REFINE_TRIANGULATION until it succeeds
     const double* F = g.F;
     const double px = x1[n], py = y1[n], qx = x2[n], qy = y2[n];
 
@@ -133,6 +136,7 @@ k_refine_points(const double* __restrict__ x1, const double* __restrict__ y1,
     }
     const double valInf = 1 / f12 + (c * c) / (a * a + f22 * c * c);
     if (valInf < bestS) return;                                // :1170-1175 -> dropped at :816-817
+    reason[n] = 3;                                             // MH_REFINE_AFFINE_TEST until it passes
     // point1 = (0, bestT, 1); line2 = F3 point1; point2 = (-l0 l2, -l1 l2, l0^2 + l1^2) / (l0^2 + l1^2)
     const double l0 = F3[1] * bestT + F3[2], l1 = F3[4] * bestT + F3[5], l2 = F3[7] * bestT + F3[8];
     const double w2 = l0 * l0 + l1 * l1;
@@ -180,18 +184,19 @@ k_refine_points(const double* __restrict__ x1, const double* __restrict__ y1,
     o[0] = ux; o[1] = uy; o[2] = vx; o[3] = vy;
     o[4] = A11 + ppx * lam1; o[5] = A12 + ppx * lam2; o[6] = A21 + ppy * lam1; o[7] = A22 + ppy * lam2;
     keep[n] = 1;
+    reason[n] = 0;                                             // MH_REFINE_KEPT
 }
 
 hipError_t launch_refine_points(const Points& p, const Affines& a, const double F[9], const double e1[2],
                                 const double e2[2], const unsigned char* in_mask, unsigned char* keep,
-                                double* out, hipStream_t s)
+                                double* out, unsigned char* reason, hipStream_t s)
 {
     if (p.n <= 0) return hipSuccess;
     RefineGeom g;
     for (int i = 0; i < 9; ++i) g.F[i] = F[i];
     g.e1x = e1[0]; g.e1y = e1[1]; g.e2x = e2[0]; g.e2y = e2[1];
     hipLaunchKernelGGL(k_refine_points, dim3((p.n + 255) / 256), dim3(256), 0, s, p.x1, p.y1, p.x2, p.y2,
-                       a.a11, a.a12, a.a21, a.a22, p.n, g, in_mask, keep, out);
+                       a.a11, a.a12, a.a21, a.a22, p.n, g, in_mask, keep, out, reason);
     return hipGetLastError();
 }
 

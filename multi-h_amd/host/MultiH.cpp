@@ -154,9 +154,67 @@ bool MultiH::EnsureEngine()
     if (!Check(mh_set_transport(engine, shard_rank, std::max(shard_world, 1), shard_stream_allgather, shard_allgather, shard_ctx),
                "mh_set_transport"))
         return false;
+    if (!Check(mh_set_fundamental_metric(engine, fundamental_metric), "mh_set_fundamental_metric")) return false;   // (sticky, and engines are reused)
     return Check(mh_set_params(engine, threshold_fundamental_matrix, threshold_homography,
                                locality_lambda, energy_lambda, minimum_inlier_number),
                  "mh_set_params");
+}
+
+namespace {
+// an engine for a helper outside any MultiH object: from the pool when one is idle on `device`
+mh_engine* BorrowEngine(int device)
+{
+    if (engine_pool_enabled()) {
+        EnginePool& p = engine_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        for (size_t i = 0; i < p.idle.size(); ++i)
+            if (p.idle[i].first == device) { mh_engine* e = p.idle[i].second; p.idle.erase(p.idle.begin() + (long)i); return e; }
+    }
+    mh_engine* e = nullptr;
+    return Check(mh_create(&e, device), "mh_create") ? e : nullptr;
+}
+void ReturnEngine(int device, mh_engine* e)
+{
+    if (!e) return;
+    if (engine_pool_enabled() && mh_synchronize(e) == MH_OK) {
+        EnginePool& p = engine_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        if (p.idle.size() < 2) { p.idle.emplace_back(device, e); return; }
+    }
+    mh_destroy(e);
+}
+} // namespace
+
+bool multih::FilterCorrespondencesByEpipolarGeometry(std::vector<cv::Point2d>& srcPoints, std::vector<cv::Point2d>& dstPoints,
+                                                     std::vector<cv::Mat>& affines, double threshold, uint64_t seed,
+                                                     int hypotheses, int metric, int device, std::vector<unsigned char>* mask_out)
+{
+    const size_t n = srcPoints.size();
+    if (n < 8 || dstPoints.size() != n || affines.size() != n) return false;
+    mh_engine* e = BorrowEngine(device);
+    if (!e) return false;
+    std::vector<double> s(2 * n), d(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        s[2 * i] = srcPoints[i].x; s[2 * i + 1] = srcPoints[i].y;
+        d[2 * i] = dstPoints[i].x; d[2 * i + 1] = dstPoints[i].y;
+    }
+    std::vector<unsigned char> mask(n, 0);
+    double F[9], e2[2];
+    int inl = 0;
+    const bool ok = Check(mh_set_fundamental_metric(e, metric), "mh_set_fundamental_metric") &&
+                    Check(mh_set_correspondences(e, s.data(), d.data(), nullptr, (int)n), "mh_set_correspondences") &&
+                    Check(mh_estimate_fundamental(e, seed, hypotheses, threshold, F, e2, mask.data(), &inl), "mh_estimate_fundamental");
+    ReturnEngine(device, e);
+    if (!ok) return false;
+    if (mask_out) *mask_out = mask;
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (mask[i]) {
+            if (k != i) { srcPoints[k] = srcPoints[i]; dstPoints[k] = dstPoints[i]; affines[k] = affines[i]; }
+            ++k;
+        }
+    srcPoints.resize(k); dstPoints.resize(k); affines.resize(k);
+    return true;
 }
 
 bool MultiH::Process()
@@ -186,6 +244,8 @@ bool MultiH::Process()
     labeling.clear();
 
     const int N = static_cast<int>(src_points.size());
+    front_stages = FrontStages();
+    front_stages.input = front_stages.in_ransac_mask = front_stages.triangulated = front_stages.affine_consistent = N;
     std::vector<double> s(2 * (size_t)N), d(2 * (size_t)N), a(4 * (size_t)N);
     for (int i = 0; i < N; ++i) {
         s[2 * i] = src_points[i].x; s[2 * i + 1] = src_points[i].y;
@@ -224,6 +284,14 @@ bool MultiH::Process()
                                                  refined.data()),
                        "mh_refine_correspondences"))
                 return false;
+            std::vector<unsigned char> reason(N, 0);
+            if (!Check(mh_get_refine_reasons(engine, reason.data(), N), "mh_get_refine_reasons")) return false;
+            front_stages.in_ransac_mask = front_stages.triangulated = front_stages.affine_consistent = 0;
+            for (int i = 0; i < N; ++i) {
+                if (reason[i] != MH_REFINE_NOT_IN_MASK) ++front_stages.in_ransac_mask;
+                if (reason[i] == MH_REFINE_KEPT || reason[i] == MH_REFINE_AFFINE_TEST) ++front_stages.triangulated;
+                if (reason[i] == MH_REFINE_KEPT) ++front_stages.affine_consistent;
+            }
             std::vector<cv::Point2d> s2, d2;
             std::vector<cv::Mat> a2;
             for (int i = 0; i < N; ++i)
@@ -234,6 +302,9 @@ bool MultiH::Process()
                     a2.push_back(OwnedMat(2, 2, r + 4));
                 }
             printf("[Multi-H] %d points kept from the initial %d after filtering.\n", (int)s2.size(), N);   // :840
+            if (log_to_console)
+                printf("[Multi-H]   stages: %d in the RANSAC mask at %.2f px, %d after OptimalTriangulation, %d after distanceError <= 1\n",
+                       front_stages.in_ransac_mask, threshold_fundamental_matrix, front_stages.triangulated, front_stages.affine_consistent);
             if (s2.size() < 8) {
                 degenerate_case = true;
                 printf("[Multi-H] Degenerate case, not enough points remained.\n");                         // :845
@@ -554,6 +625,7 @@ void MultiH::ClusterMergingAndLabeling()
     labeling.resize(N, -1);                                                             // :263
     double lastEnergy = INT_MAX;
     int not_changed_number = 0;
+    labeling_steps_run = 0;
 
     const bool timing = std::getenv("MULTIH_TIMING") != nullptr;                        // diagnostic: where the loop's time goes
     double merge_s = 0.0, label_s = 0.0;
@@ -590,6 +662,7 @@ void MultiH::ClusterMergingAndLabeling()
         const auto t_label = std::chrono::system_clock::now();
         const bool labelled = LabelingStep(energy, changed);
         label_s += seconds_since(t_label);
+        if (labelled) ++labeling_steps_run;
         if (timing) {
             long long st[24] = {};
             (void)mh_get_expand_stats(engine, st);
@@ -806,6 +879,34 @@ static std::vector<std::pair<int, int>> g_tuning;
 extern "C" __attribute__((visibility("default")))
 void mhh_set_engine_tuning(int key, int value) { if (key < 0) g_tuning.clear(); else g_tuning.emplace_back(key, value); }
 
+// LabelingSteps the last mhh_run_process ran (MultiH::GetLabelingStepsRun)
+static int g_labeling_steps = 0;
+extern "C" __attribute__((visibility("default")))
+int mhh_get_labeling_steps() { return g_labeling_steps; }
+// MultiH::SetFundamentalMetric for the next mhh_run_process calls (< 0: the class default), and the stage table of the last one
+static int g_fund_metric = -1;
+static int g_front_stages[4] = { 0, 0, 0, 0 };
+extern "C" __attribute__((visibility("default")))
+void mhh_set_fundamental_metric(int metric) { g_fund_metric = metric; }
+extern "C" __attribute__((visibility("default")))
+void mhh_get_front_stages(int out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_front_stages[i]; }
+// multih::FilterCorrespondencesByEpipolarGeometry on plain arrays: mask (n flags) out; returns the number kept, -1 on failure
+extern "C" __attribute__((visibility("default")))
+int mhh_filter_correspondences(const double* src_xy, const double* dst_xy, int n, double threshold, unsigned long long seed,
+                               int hypotheses, int metric, int device, unsigned char* mask)
+{
+    std::vector<cv::Point2d> s(n), d(n);
+    std::vector<cv::Mat> a(n);
+    for (int i = 0; i < n; ++i) {
+        s[i] = cv::Point2d(src_xy[2 * i], src_xy[2 * i + 1]);
+        d[i] = cv::Point2d(dst_xy[2 * i], dst_xy[2 * i + 1]);
+    }
+    std::vector<unsigned char> m;
+    if (!multih::FilterCorrespondencesByEpipolarGeometry(s, d, a, threshold, seed, hypotheses, metric, device, &m)) return -1;
+    for (int i = 0; i < n; ++i) mask[i] = m[i];
+    return (int)s.size();
+}
+
 // multih::CompatibilityCheck with the trials' order statistics from an engine (mh_compat_trial_stats), as Process() runs
 // it, returning the per-cluster median-of-medians too; -1 if the engine fails.  For the GPU tests.
 extern "C" __attribute__((visibility("default")))
@@ -848,6 +949,7 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     mh.SetDevice(g_device);
     mh.SetCompatibilityCheck(g_post_filter != 0);
     mh.SetProposalRefit(g_proposal_refit != 0);
+    if (g_fund_metric >= 0) mh.SetFundamentalMetric(g_fund_metric);
     for (const auto& kv : g_tuning) mh.SetEngineTuning(kv.first, kv.second);
     if (g_radius > 0.0 && g_max_hits > 0) { mh.SetNeighbourRadius(g_radius, g_max_hits); if (g_knn > 0) mh.SetFallbackK(g_knn); }
     else if (g_radius > 0.0) mh.SetNeighbourRadius(g_radius);
@@ -861,6 +963,10 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
         mh.SetInitialHomographies(hs);
     }
     if (!mh.Process(s, d, a)) return -1;
+    {
+        const MultiH::FrontStages st = mh.GetFrontStages();
+        g_front_stages[0] = st.input; g_front_stages[1] = st.in_ransac_mask; g_front_stages[2] = st.triangulated; g_front_stages[3] = st.affine_consistent;
+    }
     std::vector<int> lab;
     mh.GetLabels(lab);
     for (size_t i = 0; i < lab.size() && i < (size_t)n; ++i) labels_out[i] = lab[i];
@@ -872,5 +978,6 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
     if (iterations) *iterations = mh.GetIterationNumber();
     if (energy) *energy = mh.GetEnergy();
     if (loop_seconds) *loop_seconds = mh.GetLastLoopSeconds();
+    g_labeling_steps = mh.GetLabelingStepsRun();
     return k;
 }

@@ -103,9 +103,13 @@ public:
     // Propose step used when no initial models are given: `hypotheses` random 4-tuples ->
     // DLT -> greedy selection of at most `max_models` models with >= max(min inliers, 8).
     void SetProposal(uint64_t seed, int hypotheses, int max_models);
-    // north_star C5 runs a fixed number of propose-expand iterations instead of the
-    // convergence test; 0 restores the reference's stop rule (:295).
+    // A CAP on the loop's iterations (north_star configs[4]: "20 propose-expand iterations"): with n > 0 the loop also stops
+    // after its n-th LabelingStep.  The reference's own stop rule (:295: no change and the same energy, or more than ten
+    // unchanged iterations) stays in force — a loop that has converged after three iterations runs three, not n.  0 = the
+    // reference's rule alone.  How many LabelingSteps the last Process() ran: GetLabelingStepsRun() (GetIterationNumber()
+    // is the reference's iteration_number - 1, :311, i.e. one less when the loop ended behind a LabelingStep).
     void SetFixedIterations(int n) { fixed_iterations = n; }
+    int GetLabelingStepsRun() const { return labeling_steps_run; }
     // PEARL-style re-proposal (north_star "propose-expand iterations"; the reference proposes only
     // once, before the loop): every iteration samples `hypotheses` fresh DLT hypotheses, scores them
     // on the points currently labelled outlier and appends at most `max_new` models that gather
@@ -136,6 +140,18 @@ public:
     void SetShardingStream(int rank, int world, StreamAllGatherFn fn, void* ctx);
     // Number of 8-point hypotheses of the GPU F estimation used when SetEpipolarGeometry was not called.
     void SetFundamentalHypotheses(int n) { fundamental_hypotheses = n; }
+    // r06: what the F estimation compares with threshold_fundamental_matrix — FUND_EPIPOLAR_MAX: the squared distance of a
+    // point to the epipolar line of its partner, the larger of the two images, which is what the reference's
+    // cv::findFundamentalMat(CV_FM_RANSAC, thr) thresholds (M/MultiH.cpp:775; OpenCV 3.1.0, restated); FUND_SAMPSON: the
+    // Sampson distance (at most half of it at equal F — the build's definition until r05: at 2.6 px it let through what the
+    // reference's call rejects from 1.84 px on).  include/multih_hip.h, mh_set_fundamental_metric.
+    enum { FUND_SAMPSON = 0, FUND_EPIPOLAR_MAX = 1 };
+    void SetFundamentalMetric(int m) { fundamental_metric = m; }
+    // r06: how many correspondences each stage of GetFundamentalMatrixAndRefineData (M/MultiH.cpp:770-848) let through in
+    // the last Process(): the input, the RANSAC mask (:809), OptimalTriangulation (:815-817), distanceError <= 1 (:826).
+    // All equal to the input when the caller supplied F (SetEpipolarGeometry): the points are then taken as they are.
+    struct FrontStages { int input = 0, in_ransac_mask = 0, triangulated = 0, affine_consistent = 0; };
+    FrontStages GetFrontStages() const { return front_stages; }
     // The post-filter of Process() (HomographyCompatibilityCheck, M/MultiH.cpp:78-86) can be switched off to look at
     // what the merge <-> label loop itself produced (parity tests against the oracle of that loop).
     void SetCompatibilityCheck(bool on) { run_compatibility_check = on; }
@@ -183,11 +199,14 @@ protected:
     int fixed_iterations = 0;
     int iter_hypotheses = 0, iter_max_new = 4;
     int fundamental_hypotheses = 4000;
+    int fundamental_metric = FUND_EPIPOLAR_MAX;
+    FrontStages front_stages;
     int init_mode = INIT_DLT;
     bool run_compatibility_check = true;
     bool post_filter_failed = false;             // the engine's part of HomographyCompatibilityCheck returned an error
     uint64_t merge_rng_counter = 0;
     double loop_seconds = 0.0;
+    int labeling_steps_run = 0;
     std::vector<cv::Mat> initial_homographies;
     int shard_rank = 0, shard_world = 1;
     AllGatherFn shard_allgather = nullptr;
@@ -207,3 +226,19 @@ protected:
     void ComputeInliersOfHomography(int idx);          // :743-768
     void HandleDegenerateCase();                       // :719-741 (single best DLT model)
 };
+
+namespace multih {
+// r06: the load-time filter of the reference's CALLER — LoadPointsFromFile, M/main.cpp:399-409:
+//     findFundamentalMat(srcPoints, dstPoints, CV_FM_RANSAC, 2.0, 0.99, mask);   then every row with mask[i] == 0 is erased
+// — through the engine's own estimator (mh_estimate_fundamental: `hypotheses` normalised 8-point fits from counter-RNG
+// 8-tuples, the best-supported one refitted twice to its inliers; cv::findFundamentalMat itself — 7-point samples, at most
+// 1 000 of them, its own RNG, no refit — is outside /root/reference and not reproduced).  `metric` as
+// MultiH::SetFundamentalMetric.  Erases the rejected rows from all three vectors (order kept, as the reference's backward
+// erase loop keeps it) and returns false — leaving them untouched — when there are fewer than 8 rows, the sizes differ or the
+// engine fails.  mask_out (nullable): one flag per INPUT row.
+bool FilterCorrespondencesByEpipolarGeometry(std::vector<cv::Point2d>& srcPoints, std::vector<cv::Point2d>& dstPoints,
+                                             std::vector<cv::Mat>& affines, double threshold = 2.0,
+                                             uint64_t seed = 1234, int hypotheses = 4000,
+                                             int metric = MultiH::FUND_EPIPOLAR_MAX, int device = 0,
+                                             std::vector<unsigned char>* mask_out = nullptr);
+}

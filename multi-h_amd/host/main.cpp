@@ -9,6 +9,13 @@
 //                  [--hypotheses 10000] [--max-models 32] [--seed 1234] [--iterations 0]
 //                  [--neighbourhood knn|radius|approx]   (knn, the default: the 16 nearest hits within 1/locality pixels; radius: every hit within
 //                  it; approx: what FLANN's default search — 4 randomised KD-trees, 32 checks — finds of them, MultiH::SetNeighbourApprox)
+//                  [--load-filter 2.0]   r06: the filter of the reference's LoadPointsFromFile (M/main.cpp:399-409:
+//                                findFundamentalMat(CV_FM_RANSAC, 2.0, 0.99) and the erase loop) through the engine's own estimator
+//                                (multih::FilterCorrespondencesByEpipolarGeometry); the value is the threshold in pixels, 0 switches
+//                                the filter off (what the harness did until r05)
+//                  [--f-metric opencv|sampson]   what the two F estimations compare with their thresholds (MultiH::SetFundamentalMetric)
+//                  [--stages <file>]   write the stage table as one JSON object: rows loaded, after the load filter, in
+//                                Process()'s RANSAC mask, after OptimalTriangulation, after distanceError <= 1 (M/MultiH.cpp:807-838)
 //                  [--ranks N]   one process per GPU (rank r on device r), the hypothesis batches sharded over the ranks and
 //                                exchanged by RCCL (host/rccl_transport.cpp: ncclAllGather on the engine's stream); this
 //                                process becomes rank 0 and starts the others before anything touches the GPU.  Every rank
@@ -33,8 +40,11 @@
 #include "MultiH.h"
 #include "multih_rccl.h"
 
+// M/main.cpp:380-412.  filter_threshold > 0: the load-time F-RANSAC filter of :399-409 (see MultiH.h,
+// multih::FilterCorrespondencesByEpipolarGeometry); *loaded = rows read from the file.
 static bool LoadPointsFromFile(std::vector<cv::Point2d>& srcPoints, std::vector<cv::Point2d>& dstPoints,
-                               std::vector<cv::Mat>& affines, const char* file)
+                               std::vector<cv::Mat>& affines, const char* file, double filter_threshold,
+                               unsigned long long seed, int metric, int device, int* loaded)
 {
     std::ifstream infile(file);
     if (!infile.is_open()) return false;
@@ -47,8 +57,11 @@ static bool LoadPointsFromFile(std::vector<cv::Point2d>& srcPoints, std::vector<
         for (int q = 0; q < 4; ++q) A.at<double>(q / 2, q % 2) = a[q];
         affines.push_back(A);
     }
-    // The reference also drops F-RANSAC outliers here (findFundamentalMat, :399-409): OpenCV
-    // front end, out of scope (§8(f) row 4).
+    if (loaded) *loaded = (int)srcPoints.size();
+    if (filter_threshold > 0.0 && srcPoints.size() >= 8 &&
+        !multih::FilterCorrespondencesByEpipolarGeometry(srcPoints, dstPoints, affines, filter_threshold,
+                                                         seed ^ 0x10adf117e4ull, 4000, metric, device))
+        return false;
     return true;
 }
 
@@ -69,14 +82,17 @@ int main(int argc, char** argv)
     if (argc < 3) {
         std::cerr << "usage: multih_harness <in_corr.txt> <out_result.txt> [--epipolar file] [--thrF v] [--thrH v] "
                      "[--locality v] [--lambda v] [--min-inliers n] [--hypotheses n] [--max-models n] [--seed n] "
-                     "[--iterations n] [--neighbourhood knn|radius|approx] [--ranks n]\n";
+                     "[--iterations n] [--neighbourhood knn|radius|approx] [--load-filter px] [--f-metric opencv|sampson] "
+                     "[--stages file] [--ranks n]\n";
         return 2;
     }
     double thrF = 2.6, thrH = 2.2, locality = 0.005, lambda = 0.5;     // M/main.cpp:55-59
     int min_inliers = 20, hypotheses = 10000, max_models = 32, iterations = 0;
     unsigned long long seed = 1234;
     int ranks = 0;
-    std::string epi, neighbourhood = "knn";
+    double load_filter = 2.0;                                          // M/main.cpp:400
+    int f_metric = MultiH::FUND_EPIPOLAR_MAX;
+    std::string epi, neighbourhood = "knn", stages_path;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
         const char* v = argv[i + 1];
@@ -92,6 +108,13 @@ int main(int argc, char** argv)
         else if (k == "--iterations") iterations = atoi(v);
         else if (k == "--neighbourhood") neighbourhood = v;
         else if (k == "--ranks") ranks = atoi(v);
+        else if (k == "--load-filter") load_filter = atof(v);
+        else if (k == "--f-metric") {
+            if (std::string(v) == "sampson") f_metric = MultiH::FUND_SAMPSON;
+            else if (std::string(v) == "opencv") f_metric = MultiH::FUND_EPIPOLAR_MAX;
+            else { std::cerr << "--f-metric: opencv or sampson\n"; return 2; }
+        }
+        else if (k == "--stages") stages_path = v;
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
 
@@ -184,11 +207,14 @@ int main(int argc, char** argv)
 
     std::vector<cv::Point2d> srcPointsOrig, dstPointsOrig;
     std::vector<cv::Mat> origAffines;
-    if (!LoadPointsFromFile(srcPointsOrig, dstPointsOrig, origAffines, argv[1])) {
-        std::cerr << "cannot read " << argv[1] << "\n";
+    int rows_loaded = 0;
+    if (!LoadPointsFromFile(srcPointsOrig, dstPointsOrig, origAffines, argv[1], epi.empty() ? load_filter : 0.0, seed, f_metric,
+                            comm ? rank : 0, &rows_loaded)) {
+        std::cerr << "cannot read " << argv[1] << " (or the load filter failed)\n";
         return finish(1);
     }
     printf("Found %d matches.\n", (int)srcPointsOrig.size());
+    const int rows_after_load_filter = (int)srcPointsOrig.size();
 
     MultiH* multiH = new MultiH(thrF, thrH, locality, lambda, min_inliers);
     if (!epi.empty()) {
@@ -200,6 +226,7 @@ int main(int argc, char** argv)
         if (!ok) { std::cerr << "cannot read epipolar geometry from " << epi << "\n"; return finish(1); }
         multiH->SetEpipolarGeometry(F, e2);
     }
+    multiH->SetFundamentalMetric(f_metric);
     multiH->SetProposal(seed, hypotheses, max_models);
     multiH->SetFixedIterations(iterations);
     if (comm) {
@@ -210,6 +237,22 @@ int main(int argc, char** argv)
     else if (neighbourhood == "approx") multiH->SetNeighbourApprox(4, 32, 0x464c414e4eull + seed);   // ... as FLANN's default search answers it
     if (!multiH->Process(srcPointsOrig, dstPointsOrig, origAffines)) { delete multiH; return finish(1); }
     const std::string out_path = rank == 0 ? std::string(argv[2]) : std::string(argv[2]) + ".rank" + std::to_string(rank);
+    {
+        // the stage table: where the rows of the input file go before the loop sees them
+        const MultiH::FrontStages st = multiH->GetFrontStages();
+        printf("[Multi-H] stages: %d loaded, %d after the load filter (%.2f px), %d in Process()'s RANSAC mask (%.2f px), "
+               "%d after OptimalTriangulation, %d after distanceError <= 1\n",
+               rows_loaded, rows_after_load_filter, epi.empty() ? load_filter : 0.0, st.in_ransac_mask, thrF, st.triangulated,
+               st.affine_consistent);
+        if (!stages_path.empty() && rank == 0) {
+            std::ofstream sf(stages_path);
+            sf << "{\"loaded\": " << rows_loaded << ", \"after_load_filter\": " << rows_after_load_filter
+               << ", \"load_filter_px\": " << (epi.empty() ? load_filter : 0.0) << ", \"in_ransac_mask\": " << st.in_ransac_mask
+               << ", \"ransac_px\": " << thrF << ", \"after_optimal_triangulation\": " << st.triangulated
+               << ", \"after_distance_error\": " << st.affine_consistent << ", \"f_metric\": \""
+               << (f_metric == MultiH::FUND_SAMPSON ? "sampson" : "opencv") << "\"}\n";
+        }
+    }
 
     std::vector<int> labeling;
     multiH->GetLabels(labeling);

@@ -99,6 +99,32 @@ int mhr_allgather(void* comm, const void* send_dev, void* recv_dev, unsigned lon
 
 long long mhr_calls(const mhr_comm* c) { return c ? c->calls : 0; }
 
+int mhr_count(const mhr_comm* c)
+{
+    if (!c || !c->comm) { fail("mhr_count", "no communicator"); return -1; }
+    int n = -1;
+    const ncclResult_t r = ncclCommCount(c->comm, &n);
+    if (r != ncclSuccess) { fail("ncclCommCount", ncclGetErrorString(r)); return -1; }
+    return n;
+}
+
+int mhr_rank(const mhr_comm* c)
+{
+    if (!c || !c->comm) { fail("mhr_rank", "no communicator"); return -1; }
+    int n = -1;
+    const ncclResult_t r = ncclCommUserRank(c->comm, &n);
+    if (r != ncclSuccess) { fail("ncclCommUserRank", ncclGetErrorString(r)); return -1; }
+    return n;
+}
+
+int mhr_version(void)
+{
+    int v = -1;
+    const ncclResult_t r = ncclGetVersion(&v);
+    if (r != ncclSuccess) { fail("ncclGetVersion", ncclGetErrorString(r)); return -1; }
+    return v;
+}
+
 void mhr_destroy(mhr_comm* c)
 {
     if (!c) return;

@@ -1034,6 +1034,13 @@ MHO_API int mho_mean_shift(const double* data, int n, int d, double bw, unsigned
 // 9b. Epipolar front half — own definition, "parity unpinned": the
 //     reference calls cv::findFundamentalMat(RANSAC) (M/MultiH.cpp:775), OpenCV 3.1.0 calib3d.
 // ---------------------------------------------------------------------------
+// Two definitions of the distance to the epipolar geometry (the product's mh_set_fundamental_metric):
+//   0  Sampson                       e^2 / (a^2 + b^2 + a'^2 + b'^2)
+//   1  what cv::findFundamentalMat compares with its threshold (OpenCV 3.1.0 FMEstimatorCallback::computeError, published
+//      source outside /root/reference, restated): the squared distance of each point to the epipolar line of the other,
+//      the larger of the two.  The call sites: M/main.cpp:400 (2.0 px), M/MultiH.cpp:775 (threshold_fundamental_matrix).
+static int g_fund_metric = 0;
+MHO_API void mho_set_fundamental_metric(int metric) { g_fund_metric = metric; }
 static inline double sampson_d(const double* f, double x, double y, double u, double v)
 {
     const double a = f[0] * x + f[1] * y + f[2];
@@ -1042,7 +1049,10 @@ static inline double sampson_d(const double* f, double x, double y, double u, do
     const double a2 = f[0] * u + f[3] * v + f[6];
     const double b2 = f[1] * u + f[4] * v + f[7];
     const double e = u * a + v * b + c;
-    return (e * e) / (a * a + b * b + a2 * a2 + b2 * b2);
+    if (g_fund_metric == 0) return (e * e) / (a * a + b * b + a2 * a2 + b2 * b2);
+    const double d2 = (e * e) / (a * a + b * b);
+    const double d1 = (e * e) / (a2 * a2 + b2 * b2);
+    return d1 > d2 ? d1 : d2;
 }
 
 // null vector g (normalised frame) -> rank-2 F in pixel coordinates, unit Frobenius, F[8] >= 0
@@ -1282,15 +1292,19 @@ MHO_API void mho_poly_roots(const double* c, int n, double* re, double* im)
     for (int i = 0; i < n; ++i) { re[i] = z[i].re; im[i] = z[i].im; }
 }
 
-MHO_API void mho_refine_points(const double* x1, const double* y1, const double* x2, const double* y2,
-                               const double* aff, int N, const double* F, const double* e1, const double* e2,
-                               const unsigned char* in_mask, unsigned char* keep, double* out /* N*8 */)
+// reason (nullable, N): the stage a row left at — 0 kept, 1 not in the mask (:809), 2 OptimalTriangulation failed (:815-817),
+// 3 distanceError > 1 (:826) — the product's mh_get_refine_reasons.
+MHO_API void mho_refine_points_ex(const double* x1, const double* y1, const double* x2, const double* y2,
+                                  const double* aff, int N, const double* F, const double* e1, const double* e2,
+                                  const unsigned char* in_mask, unsigned char* keep, double* out /* N*8 */, unsigned char* reason)
 {
     const double e1x = e1[0], e1y = e1[1], e2x = e2[0], e2y = e2[1];
     for (int n = 0; n < N; ++n) {
         keep[n] = 0;
         for (int q = 0; q < 8; ++q) out[8 * (size_t)n + q] = 0.0;
+        if (reason) reason[n] = 1;
         if (in_mask && !in_mask[n]) continue;
+        if (reason) reason[n] = 2;
         const double px = x1[n], py = y1[n], qx = x2[n], qy = y2[n];
         double G[9], F2[9], M2[9], F3[9];
         for (int r = 0; r < 3; ++r) {
@@ -1337,6 +1351,7 @@ MHO_API void mho_refine_points(const double* x1, const double* y1, const double*
         }
         const double valInf = 1 / f12 + (c * c) / (a * a + f22 * c * c);
         if (valInf < bestS) continue;
+        if (reason) reason[n] = 3;
         const double l0 = F3[1] * bestT + F3[2], l1 = F3[4] * bestT + F3[5], l2 = F3[7] * bestT + F3[8];
         const double w2 = l0 * l0 + l1 * l1;
         const double iw = 1.0 / w2;
@@ -1372,7 +1387,15 @@ MHO_API void mho_refine_points(const double* x1, const double* y1, const double*
         o[0] = ux; o[1] = uy; o[2] = vx; o[3] = vy;
         o[4] = A11 + ppx * lam1; o[5] = A12 + ppx * lam2; o[6] = A21 + ppy * lam1; o[7] = A22 + ppy * lam2;
         keep[n] = 1;
+        if (reason) reason[n] = 0;
     }
+}
+
+MHO_API void mho_refine_points(const double* x1, const double* y1, const double* x2, const double* y2,
+                               const double* aff, int N, const double* F, const double* e1, const double* e2,
+                               const unsigned char* in_mask, unsigned char* keep, double* out /* N*8 */)
+{
+    mho_refine_points_ex(x1, y1, x2, y2, aff, N, F, e1, e2, in_mask, keep, out, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -2171,15 +2194,15 @@ MHO_API void mho_epipoles(const double* F, double* e1, double* e2)
 
 // The front half as the build defines it where the reference calls cv::findFundamentalMat(RANSAC) (:775; OpenCV is outside
 // /root/reference — parity unpinned): `hypotheses` normalised 8-point fits from counter-RNG 8-tuples
-// (seed, counters 0..), Sampson inlier counts at thr_f^2, the best-supported (lowest index on ties), two rounds of
+// (seed, counters 0..), inlier counts at thr_f^2 (Sampson's distance, or — mho_set_fundamental_metric(1) — the point-to-epipolar-line distance), the best-supported (lowest index on ties), two rounds of
 // {inliers -> least-squares 8-point -> rank 2}, the inlier mask of the result; then the reference's own steps: the
 // degenerate test ||F|| < 1e-5 (:779), the epipoles (:786-799), and per masked correspondence the Hartley-Sturm
 // correction, the affine-consistency filter and the optimal affinity (:807-838, mho_refine_points).
 // keep: N flags; refined: N x 8 (x1 y1 x2 y2 a11 a12 a21 a22 of the survivors, zero elsewhere).  Returns the number kept,
 // or -1 in the degenerate case.
-MHO_API int mho_front_half(const double* x1, const double* y1, const double* x2, const double* y2, const double* aff, int N,
-                           uint64_t seed, int hypotheses, double thr_f, double* F_out, double* e1_out, double* e2_out,
-                           unsigned char* keep, double* refined)
+MHO_API int mho_front_half_ex(const double* x1, const double* y1, const double* x2, const double* y2, const double* aff, int N,
+                              uint64_t seed, int hypotheses, double thr_f, double* F_out, double* e1_out, double* e2_out,
+                              unsigned char* keep, double* refined, unsigned char* reason /* nullable: mho_refine_points_ex */)
 {
     std::vector<int> idx(8 * (size_t)hypotheses), counts(hypotheses);
     std::vector<double> Fh(9 * (size_t)hypotheses);
@@ -2200,10 +2223,17 @@ MHO_API int mho_front_half(const double* x1, const double* y1, const double* x2,
     double nrm = 0.0;
     for (int i = 0; i < 9; ++i) nrm += Fb[i] * Fb[i];
     if (!(sqrt(nrm) >= 1e-5) || !std::isfinite(e2_out[0]) || !std::isfinite(e2_out[1])) return -1;     // :779
-    mho_refine_points(x1, y1, x2, y2, aff, N, Fb, e1_out, e2_out, mask.data(), keep, refined);
+    mho_refine_points_ex(x1, y1, x2, y2, aff, N, Fb, e1_out, e2_out, mask.data(), keep, refined, reason);
     int kept = 0;
     for (int i = 0; i < N; ++i) kept += keep[i] ? 1 : 0;
     return kept;
+}
+
+MHO_API int mho_front_half(const double* x1, const double* y1, const double* x2, const double* y2, const double* aff, int N,
+                           uint64_t seed, int hypotheses, double thr_f, double* F_out, double* e1_out, double* e2_out,
+                           unsigned char* keep, double* refined)
+{
+    return mho_front_half_ex(x1, y1, x2, y2, aff, N, seed, hypotheses, thr_f, F_out, e1_out, e2_out, keep, refined, nullptr);
 }
 
 MHO_API int mho_abi_version(void) { return 3; }

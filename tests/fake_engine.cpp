@@ -35,6 +35,8 @@ int mh_set_epipolar(mh_engine*, const double*, const double*) { return MH_OK; }
 int mh_set_neighbors_csr(mh_engine*, const int*, const int*, int) { return MH_OK; }
 int mh_build_neighbors_knn(mh_engine*, int) { return MH_OK; }
 int mh_build_neighbors_radius(mh_engine*, double, long long, long long* hits) { if (hits) *hits = 0; return MH_OK; }
+int mh_set_fundamental_metric(mh_engine*, int) { return MH_OK; }
+int mh_get_refine_reasons(mh_engine*, unsigned char* r, int n) { for (int i = 0; i < n; ++i) r[i] = (i % 10 < 2) ? 3 : 0; return MH_OK; }
 int mh_estimate_fundamental(mh_engine* e, unsigned long long, int, double, double F[9], double e2[2], unsigned char* mask, int* inl)
 {
     const double f[9] = { 0, -1, 2000, 1, 0, -1000, -2000, 1000, 0 };      // [e2]_x, e2 = (1000, 2000, 1)

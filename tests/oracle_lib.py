@@ -219,18 +219,19 @@ def poly_roots(coeffs):
     return re + 1j * im
 
 
-def refine_points(src, dst, aff, F, e1, e2, in_mask=None):
+def refine_points(src, dst, aff, F, e1, e2, in_mask=None, with_reasons=False):
     x1, y1, x2, y2 = soa(src, dst)
     aff, F, e1, e2 = f64(aff), f64(F), f64(e1), f64(e2)
     keep = np.empty(x1.size, dtype=np.uint8)
     out = np.empty((x1.size, 8))
+    reason = np.empty(x1.size, dtype=np.uint8)
     mp = None
     if in_mask is not None:
         in_mask = np.ascontiguousarray(in_mask, dtype=np.uint8)
         mp = in_mask.ctypes.data_as(C.POINTER(C.c_ubyte))
-    lib().mho_refine_points(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(F), _d(e1), _d(e2), mp,
-                            keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(out))
-    return keep, out
+    lib().mho_refine_points_ex(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, _d(F), _d(e1), _d(e2), mp,
+                               keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(out), reason.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return (keep, out, reason) if with_reasons else (keep, out)
 
 
 def haf_point(src, dst, aff, F, e2, locality):
@@ -264,6 +265,11 @@ def fund8(src, dst, idx):
     F = np.empty((idx.shape[0], 9))
     lib().mho_fund8(_d(x1), _d(y1), _d(x2), _d(y2), _i(idx), idx.shape[0], _d(F))
     return F
+
+
+def set_fundamental_metric(metric):
+    """0 = Sampson, 1 = the larger squared point-to-epipolar-line distance (what cv::findFundamentalMat thresholds)."""
+    lib().mho_set_fundamental_metric(int(metric))
 
 
 def sampson_score(src, dst, F, thr2):
@@ -473,13 +479,16 @@ def epipoles(F):
     return e1, e2
 
 
-def front_half(src, dst, aff, seed, hypotheses, thr_f):
-    """mho_front_half: (kept or -1, F, e1, e2, keep mask, refined [n,8])."""
+def front_half(src, dst, aff, seed, hypotheses, thr_f, with_reasons=False):
+    """mho_front_half: (kept or -1, F, e1, e2, keep mask, refined [n,8]); with_reasons: + the stage each row left at
+    (0 kept, 1 not in the RANSAC mask, 2 OptimalTriangulation, 3 distanceError > 1)."""
     x1, y1, x2, y2 = soa(src, dst)
     aff = f64(aff)
     F, e1, e2 = np.zeros(9), np.zeros(2), np.zeros(2)
     keep = np.zeros(x1.size, dtype=np.uint8)
     refined = np.zeros((x1.size, 8))
-    k = lib().mho_front_half(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, C.c_ulonglong(seed), int(hypotheses), C.c_double(thr_f),
-                             _d(F), _d(e1), _d(e2), keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(refined))
-    return int(k), F, e1, e2, keep, refined
+    reason = np.zeros(x1.size, dtype=np.uint8)
+    k = lib().mho_front_half_ex(_d(x1), _d(y1), _d(x2), _d(y2), _d(aff), x1.size, C.c_ulonglong(seed), int(hypotheses), C.c_double(thr_f),
+                                _d(F), _d(e1), _d(e2), keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(refined),
+                                reason.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return (int(k), F, e1, e2, keep, refined, reason) if with_reasons else (int(k), F, e1, e2, keep, refined)

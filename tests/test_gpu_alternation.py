@@ -47,8 +47,10 @@ def _initial_models(sc, seed, duplicates, strays):
     return np.ascontiguousarray(np.concatenate(H, axis=0))
 
 
-def _run_process(mh, sc, seed, *, H0=None, hypotheses=0, max_models=0, stable_sets=False, post_filter=True, min_inliers=20, raw=False):
-    """Process() of the host class (multi-h_amd/host/MultiH.cpp) through its C hook, F given."""
+def _run_process(mh, sc, seed, *, H0=None, hypotheses=0, max_models=0, stable_sets=False, post_filter=True, min_inliers=20, raw=False,
+                 fund_metric=-1):
+    """Process() of the host class (multi-h_amd/host/MultiH.cpp) through its C hook, F given (raw: estimated by the class,
+    with fund_metric as MultiH::SetFundamentalMetric, -1 = the class default)."""
     host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
     dp = C.POINTER(C.c_double)
     n = sc.n
@@ -59,6 +61,7 @@ def _run_process(mh, sc, seed, *, H0=None, hypotheses=0, max_models=0, stable_se
     F, e2 = np.ascontiguousarray(sc.F), np.ascontiguousarray(sc.e2)
     H0c = None if H0 is None else np.ascontiguousarray(H0)
     host.mhh_set_post_filter(1 if post_filter else 0)
+    host.mhh_set_fundamental_metric(fund_metric)
     try:
         k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.ctypes.data_as(dp), n,
                                  None if raw else F.ctypes.data_as(dp), None if raw else e2.ctypes.data_as(dp), C.c_double(2.6), C.c_double(THR),
@@ -68,6 +71,7 @@ def _run_process(mh, sc, seed, *, H0=None, hypotheses=0, max_models=0, stable_se
                                  C.byref(en), None, 0, -1 if stable_sets else 4)
     finally:
         host.mhh_set_post_filter(1)
+        host.mhh_set_fundamental_metric(-1)
     return k, labels, Hout[:max(k, 0)].copy(), it.value, en.value
 
 
@@ -221,7 +225,8 @@ def test_one_merging_step_equals_the_oracles_bit_for_bit(mh, engine, synth, orac
 
 
 @pytest.mark.parametrize("n,planes,seed,outliers", [(3000, 3, 5, 0.25), (5000, 4, 11, 0.15)])
-def test_process_from_raw_correspondences_equals_the_oracle(mh, engine, synth, oracle, n, planes, seed, outliers):
+@pytest.mark.parametrize("metric", [1, 0], ids=["epipolar_max", "sampson"])
+def test_process_from_raw_correspondences_equals_the_oracle(mh, engine, synth, oracle, n, planes, seed, outliers, metric):
     """VERDICT r03 item 5 / missing 4: Process() WITHOUT SetEpipolarGeometry, end to end against the oracle
     (oracle/mh_oracle.cpp section 13 + 12): F from 4 000 8-point hypotheses, Sampson scores, two refits; the epipoles; the
     per-correspondence Hartley-Sturm correction, affine-consistency filter and optimal affinity (M/MultiH.cpp:770-848);
@@ -229,26 +234,44 @@ def test_process_from_raw_correspondences_equals_the_oracle(mh, engine, synth, o
     points.  The kept-point mask EQUAL, F to 1e-9, labels / models / iterations / energy EQUAL."""
     from types import SimpleNamespace
     sc = synth.make_scene(n, planes, seed=seed, outlier_frac=outliers, with_neighbours=False)
-    kept, F, e1, e2, keep, refined = oracle.front_half(sc.src, sc.dst, sc.aff, seed ^ 0xf00d, 4000, 2.6)
+    # r06: under both definitions of the distance to the epipolar geometry (metric 1 — the point-to-epipolar-line distance
+    # cv::findFundamentalMat thresholds — is the class default now; 0 = Sampson, the default until r05)
+    oracle.set_fundamental_metric(metric)
+    engine.set_fundamental_metric(metric)
+    try:
+        kept, F, e1, e2, keep, refined, reason = oracle.front_half(sc.src, sc.dst, sc.aff, seed ^ 0xf00d, 4000, 2.6, with_reasons=True)
+        engine.set_correspondences(sc.src, sc.dst, sc.aff)
+        Fg, e2g, mask, inl = engine.estimate_fundamental(seed ^ 0xf00d, 4000, 2.6)
+    finally:
+        oracle.set_fundamental_metric(0)
+        engine.set_fundamental_metric(0)
     assert 0.6 * n < kept < n, "the front half should drop the gross outliers and keep the rest"
     # the engine's pieces on the same input: same F, same mask, same refined coordinates
-    engine.set_correspondences(sc.src, sc.dst, sc.aff)
-    Fg, e2g, mask, inl = engine.estimate_fundamental(seed ^ 0xf00d, 4000, 2.6)
     assert np.max(np.abs(Fg - F)) <= 1e-9 * np.max(np.abs(F)) and np.max(np.abs(e2g - e2)) <= 1e-9 * np.max(np.abs(e2))
     e1g, e2g2 = engine.epipoles(Fg)
     keep_g, refined_g = engine.refine_correspondences(Fg, e1g, e2g2, mask)
     assert np.array_equal(keep_g, keep), f"{int((keep_g != keep).sum())} correspondences filtered differently"
     assert np.max(np.abs(refined_g - refined)) <= 1e-9 * max(np.max(np.abs(refined)), 1.0)
+    assert np.array_equal(engine.refine_reasons(), reason), "the stage at which a row left (mh_get_refine_reasons)"
+    assert np.array_equal(reason == 0, keep == 1)
     # the oracle's Process() on what is left, with the F it estimated
     pts = refined[keep == 1]
     sub = SimpleNamespace(src=np.ascontiguousarray(pts[:, 0:2]), dst=np.ascontiguousarray(pts[:, 2:4]), n=int(kept))
     rowptr, col = _knn_hits(sub, 16)
     want = oracle.process(sub.src, sub.dst, np.ascontiguousarray(pts[:, 4:8]), F, e2, THR, LOCALITY, LAM, 20, seed, rowptr, col,
                           init_mode=2, hypotheses=4000, max_propose=12)
-    k, labels, H, it, en = _run_process(mh, sc, seed, hypotheses=4000, max_models=12, raw=True)
+    k, labels, H, it, en = _run_process(mh, sc, seed, hypotheses=4000, max_models=12, raw=True, fund_metric=metric)
     assert np.all(labels[kept:] == -7), "labels cover the kept correspondences only"
     _assert_same_result((k, labels[:kept], H, it, en), want)
     assert k >= 2
+    # the stage table of that Process() (MultiH::GetFrontStages) against the oracle's reasons
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    st = (C.c_int * 4)()
+    host.mhh_get_front_stages(st)
+    assert list(st) == [n, int((reason != 1).sum()), int(np.isin(reason, (0, 3)).sum()), int(kept)]
+    if metric == 1:
+        k2, labels2, H2, it2, en2 = _run_process(mh, sc, seed, hypotheses=4000, max_models=12, raw=True)
+        assert k2 == k and np.array_equal(labels2, labels), "the point-to-line distance is the class default"
 
 
 def test_engines_reused_between_multih_objects_carry_nothing_over(mh, engine_lib, synth):

@@ -61,3 +61,42 @@ def test_agreement_with_the_references_labels(mh, engine_lib, route):
     assert min(aris) >= (0.8 if route == "dlt" else 0.5), lines
     assert max(aris) >= (0.9 if route == "dlt" else 0.65), lines
     assert max(clean) >= 0.9, lines                                      # the reference's cleanest plane (128 points) comes out as one label
+
+
+def test_the_harness_route_from_the_raw_input_file(mh, engine_lib):
+    """r06: the reference's CALLER from the raw 2 903-row file, as multih_harness runs it now — the
+    load-time filter of LoadPointsFromFile (M/main.cpp:399-409: F-RANSAC at 2.0 px, rejected rows erased) through the engine's
+    own estimator, then Process() without a given F (RANSAC at 2.6 px, OptimalTriangulation, distanceError <= 1,
+    M/MultiH.cpp:770-848), both thresholds on the point-to-epipolar-line distance cv::findFundamentalMat uses.  The stage
+    table (rows after each stage) is asserted against what was measured over twelve seeds
+    (profiles/r06_barrsmith_agreement.txt: 2 903 -> 1 441-1 571 -> 1 440-1 571 -> the same -> 1 336-1 448, 949-1 022 of the
+    reference's 1 094 among them); the agreement floors are what those runs gave (default route: median ARI on the
+    reference's inliers 0.67, 4-9 planes) — NOT the 0.8 the review asked for: profiles/r06_barrsmith_trace*.txt shows the
+    loop itself, on the reference's own 1 094 rows, moving between 0.27 and 0.92 over eight seeds, and why."""
+    t = _tool()
+    pts, ref_rows, ref_labels = t.kept_correspondences(with_rows=True)
+    aris, planes, lines = [], [], []
+    for seed in (1234, 7, 99):
+        rows, labels, k, st = t.harness_route(pts, "dlt", seed, load_filter=2.0, metric=1)
+        assert st["loaded"] == 2903
+        assert 1300 <= st["after_load_filter"] <= 1700, st            # until r05 (no load filter, Sampson): 2 903 -> 1 782 at 2.6 px
+        assert st["after_load_filter"] - 40 <= st["in_ransac_mask"] <= st["after_load_filter"], st   # the second RANSAC (2.6 px) finds little left to reject
+        assert st["in_ransac_mask"] - 5 <= st["after_optimal_triangulation"] <= st["in_ransac_mask"], st     # the optimum is never at infinity on this pair
+        assert 50 <= st["after_optimal_triangulation"] - st["after_distance_error"] <= 250, st                # the affine-consistency test takes 6-9 %
+        assert st["after_distance_error"] == len(rows) == len(labels)
+        full = np.full(len(pts), -2)
+        full[rows] = labels
+        ours = full[ref_rows]
+        both = ours > -2
+        assert both.sum() >= 900, "at least 900 of the reference's 1 094 kept rows survive our front half"
+        a = t.agreement(ours[both], ref_labels[both])
+        aris.append(a["ari_reference_inliers"])
+        planes.append(k)
+        lines.append(f"seed {seed}: {st['loaded']} -> {st['after_load_filter']} -> {st['in_ransac_mask']} -> {st['after_optimal_triangulation']} -> "
+                     f"{st['after_distance_error']} ({int(both.sum())} of the reference's 1094), {k} planes, ARI on the reference's inliers {a['ari_reference_inliers']:.3f}")
+        assert labels.min() >= -1 and labels.max() == k - 1 and 3 <= k <= 10, lines[-1]
+    print("\n[barrsmith, raw file] " + "\n                      ".join(lines))
+    assert np.median(aris) >= 0.5 and max(aris) >= 0.6, lines
+    # the filter can be switched off and the Sampson distance selected: the harness of r05 (1 782 rows pass its one RANSAC)
+    rows, labels, k, st = t.harness_route(pts, "dlt", 1234, load_filter=0.0, metric=0)
+    assert st["after_load_filter"] == 2903 and 1700 <= st["in_ransac_mask"] <= 1850 and k >= 2, st

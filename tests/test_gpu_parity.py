@@ -1190,8 +1190,20 @@ def test_symmetric_transfer_mode(engine, synth, oracle):
 
 
 # ---- epipolar front half on the GPU -------------------------------------
+@pytest.fixture(params=[0, 1], ids=["sampson", "epipolar_max"])
+def fund_metric(request, engine, oracle):
+    """r06: both definitions of the distance to the epipolar geometry (mh_set_fundamental_metric), set on the engine and on
+    the oracle for the duration of a test: 0 Sampson, 1 the larger squared point-to-epipolar-line distance — what
+    cv::findFundamentalMat thresholds at M/main.cpp:400 and M/MultiH.cpp:775."""
+    engine.set_fundamental_metric(request.param)
+    oracle.set_fundamental_metric(request.param)
+    yield request.param
+    oracle.set_fundamental_metric(0)
+    engine.set_fundamental_metric(0)
+
+
 @pytest.mark.parametrize("n,m,seed", [(8, 16, 1), (500, 256, 2), (5000, 2000, 1234)])
-def test_fundamental_hypotheses_and_sampson_scores(engine, synth, oracle, n, m, seed):
+def test_fundamental_hypotheses_and_sampson_scores(engine, synth, oracle, n, m, seed, fund_metric):
     sc = synth.make_scene(n, 3, seed=seed, outlier_frac=0.2 if n > 8 else 0.0, with_neighbours=False)
     engine.set_correspondences(sc.src, sc.dst)
     engine.propose_fund8(seed, 3, m)
@@ -1206,7 +1218,45 @@ def test_fundamental_hypotheses_and_sampson_scores(engine, synth, oracle, n, m, 
     assert np.array_equal(cnt[ok], oracle.sampson_score(sc.src, sc.dst, F_ref[ok], 4.0))
 
 
-def test_fundamental_refit_and_estimate(engine, synth, oracle):
+def test_epipolar_max_is_the_point_to_line_distance(engine, synth, oracle):
+    """r06: the second definition against plain numpy — max over the two images of (p2' F p1)^2 / |line normal|^2 — and its
+    relation to Sampson's: at least twice it (e^2 / min(A, B) against e^2 / (A + B)), so the same threshold in pixels lets
+    fewer correspondences through."""
+    sc = synth.make_scene(3000, 3, seed=5, outlier_frac=0.3, with_neighbours=False)
+    F = sc.F.reshape(3, 3)
+    p1 = np.concatenate([sc.src, np.ones((sc.n, 1))], 1)
+    p2 = np.concatenate([sc.dst, np.ones((sc.n, 1))], 1)
+    l2, l1 = p1 @ F.T, p2 @ F
+    e = np.einsum("ni,ni->n", p2, l2)
+    want = np.maximum(e * e / (l2[:, 0] ** 2 + l2[:, 1] ** 2), e * e / (l1[:, 0] ** 2 + l1[:, 1] ** 2))
+    oracle.set_fundamental_metric(1)
+    try:
+        d1 = oracle.sampson(sc.src, sc.dst, sc.F)
+    finally:
+        oracle.set_fundamental_metric(0)
+    d0 = oracle.sampson(sc.src, sc.dst, sc.F)
+    assert np.allclose(d1, want, rtol=1e-9, atol=1e-12)
+    ok = d0 > 1e-12
+    assert (d1[ok] >= 2 * d0[ok] * (1 - 1e-12)).all()
+    # the counts of the two definitions at one threshold, engine against oracle, and their order
+    engine.set_correspondences(sc.src, sc.dst)
+    engine.propose_fund8(11, 0, 256)
+    Fh, _ = engine.get_fund_hypotheses()
+    counts = {}
+    for metric in (0, 1):
+        engine.set_fundamental_metric(metric)
+        oracle.set_fundamental_metric(metric)
+        try:
+            counts[metric] = engine.score_sampson(4.0)
+            okh = np.isfinite(Fh).all(axis=1)
+            assert np.array_equal(counts[metric][okh], oracle.sampson_score(sc.src, sc.dst, Fh[okh], 4.0))
+        finally:
+            engine.set_fundamental_metric(0)
+            oracle.set_fundamental_metric(0)
+    assert (counts[1] <= counts[0]).all() and (counts[1] < counts[0]).any()
+
+
+def test_fundamental_refit_and_estimate(engine, synth, oracle, fund_metric):
     sc = synth.make_scene(5000, 3, seed=1234, with_neighbours=False)
     engine.set_correspondences(sc.src, sc.dst, sc.aff)
     engine.propose_fund8(99, 0, 1000)

@@ -79,8 +79,12 @@ def agreement(ours, ref):
     return out
 
 
+def _host():
+    return C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+
+
 def run(route, corr, F, e2, seed=1234, hypotheses=20000, knn=0, approx=None):
-    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    host = _host()
     host.mhh_set_neighbourhood(int(knn), C.c_double(0.0))      # 0 = the class default (16 nearest hits within 1 / locality)
     # approx = (trees, checks): MultiH::SetNeighbourApprox — the reference's radiusMatch as FLANN's default search answers it
     host.mhh_set_neighbourhood_approx(int(approx[0]) if approx else 0, int(approx[1]) if approx else 32, C.c_ulonglong(0x464c414e4e + seed))
@@ -115,27 +119,83 @@ def front_half(pts, seed=1234):
     return idx, np.ascontiguousarray(refined[idx]), F, e2
 
 
-def raw_route(seeds=(1234, 7, 99), knn=0):
-    """From the RAW input file (2 903 rows) as the reference's harness runs it: front half, then Process() on the kept,
-    refined correspondences; compared with the reference's labels on the rows BOTH kept."""
+def harness_route(pts, route, seed, load_filter=2.0, metric=1, hypotheses=20000):
+    """The reference's caller on the RAW rows, stage by stage, as multih_harness runs it since r06 (host/main.cpp):
+    LoadPointsFromFile's filter (M/main.cpp:399-409: F-RANSAC at `load_filter` px, 0 = off) through
+    multih::FilterCorrespondencesByEpipolarGeometry, then Process() WITHOUT a given F (its own RANSAC at 2.6 px,
+    OptimalTriangulation, distanceError <= 1: M/MultiH.cpp:770-848), both with `metric` (1 = the point-to-epipolar-line
+    distance cv::findFundamentalMat thresholds, 0 = Sampson).  Returns (rows of `pts` the loop saw, their labels, planes,
+    the stage table)."""
+    host = _host()
+    dp = C.POINTER(C.c_double)
+    n0 = len(pts)
+    src, dst = (np.ascontiguousarray(pts[:, a:b]) for a, b in ((0, 2), (2, 4)))
+    mask = np.ones(n0, dtype=np.uint8)
+    if load_filter > 0:
+        k0 = host.mhh_filter_correspondences(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), n0, C.c_double(load_filter),
+                                             C.c_ulonglong(seed ^ 0x10adf117e4), 4000, int(metric), 0, mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        assert k0 >= 8, "the load filter failed"
+    rows1 = np.flatnonzero(mask)
+    sub = np.ascontiguousarray(pts[rows1])
+    # Process()'s own front half, decomposed with the engine's pieces to learn WHICH rows it keeps (the class returns labels
+    # for the kept rows in order; tests/test_gpu_alternation.py holds this decomposition equal to what the class does)
+    e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
+    e.set_fundamental_metric(metric)
+    e.set_correspondences(sub[:, 0:2], sub[:, 2:4], sub[:, 4:8])
+    F, e2, m, inl = e.estimate_fundamental(seed ^ 0xf00d, 4000, 2.6)
+    e1, e2b = e.epipoles(F)
+    keep, _ = e.refine_correspondences(F, e1, e2b, m)
+    reason = e.refine_reasons()
+    e.close()
+    rows2 = rows1[np.flatnonzero(keep)]
+    host.mhh_set_neighbourhood(0, C.c_double(0.0))
+    host.mhh_set_neighbourhood_approx(0, 32, C.c_ulonglong(0))
+    host.mhh_set_post_filter(1)
+    host.mhh_set_fundamental_metric(int(metric))
+    s2, d2, a2 = (np.ascontiguousarray(sub[:, a:b]) for a, b in ((0, 2), (2, 4), (4, 8)))
+    labels = np.full(len(sub), -7, dtype=np.int32)
+    Hout = np.zeros((256, 9))
+    it, en = C.c_int(0), C.c_double(0)
+    k = host.mhh_run_process(s2.ctypes.data_as(dp), d2.ctypes.data_as(dp), a2.ctypes.data_as(dp), len(sub), None, None,
+                             C.c_double(2.6), C.c_double(2.2), C.c_double(0.005), C.c_double(0.5), 20, C.c_ulonglong(seed), hypotheses, 32, 0,
+                             None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256, C.byref(it), C.byref(en),
+                             None, 0, -1 if route == "stable_sets" else 4)
+    host.mhh_set_fundamental_metric(-1)
+    st = (C.c_int * 4)()
+    host.mhh_get_front_stages(st)
+    C.CDLL(None).fflush(None)
+    stages = {"loaded": int(n0), "after_load_filter": int(len(rows1)), "in_ransac_mask": int(st[1]), "after_optimal_triangulation": int(st[2]),
+              "after_distance_error": int(st[3])}
+    assert st[3] == len(rows2) and st[1] == int((reason != 1).sum()), "the class and its decomposition keep different rows"
+    return rows2, labels[:len(rows2)].copy(), int(k), stages
+
+
+def raw_route(seeds=(1234, 7, 99), configs=((2.0, 1), (0.0, 0))):
+    """From the RAW input file (2 903 rows) as the reference's harness runs it; compared with the reference's labels on the
+    rows BOTH kept.  configs: (load-filter threshold, metric) — (2.0, 1) is the harness since r06, (0.0, 0) what it did until r05."""
     pts, ref_rows, ref_labels = kept_correspondences(with_rows=True)
     out = {}
-    for route in ("stable_sets", "dlt"):
-        runs = []
-        for seed in seeds:
-            idx, refined, F, e2 = front_half(pts, seed)
-            k, labels, it, en = run(route, refined, F, e2, seed=seed, knn=knn)
-            full = np.full(len(pts), -2, dtype=int)              # -2: dropped by OUR front half
-            full[idx] = labels
-            ours = full[ref_rows]
-            both = ours > -2
-            a = agreement(ours[both], ref_labels[both]) if k > 0 else {"planes": int(k)}
-            a.update(seed=seed, kept_by_us=int(len(idx)), kept_by_both=int(both.sum()), kept_by_reference=int(len(ref_rows)))
-            runs.append(a)
-            print(f"raw input, {route:12s} seed {seed:5d}: we keep {len(idx)} of {len(pts)} (the reference kept {len(ref_rows)}, {int(both.sum())} in common): "
-                  f"{k} planes, ARI on the reference's inliers {a.get('ari_reference_inliers', float('nan')):.3f}, all {a.get('ari_all', float('nan')):.3f}, "
-                  f"histogram {a.get('ours_histogram')}", flush=True)
-        out[route] = runs
+    for load_filter, metric in configs:
+        tag = f"load filter {load_filter:g} px, {'point-to-line' if metric else 'Sampson'} distance"
+        out[tag] = {}
+        for route in ("dlt", "stable_sets"):
+            runs = []
+            for seed in seeds:
+                rows, labels, k, stages = harness_route(pts, route, seed, load_filter, metric)
+                full = np.full(len(pts), -2, dtype=int)              # -2: dropped by OUR front half
+                full[rows] = labels
+                ours = full[ref_rows]
+                both = ours > -2
+                a = agreement(ours[both], ref_labels[both]) if k > 0 else {"planes": int(k)}
+                a.update(seed=seed, stages=stages, kept_by_both=int(both.sum()), kept_by_reference=int(len(ref_rows)))
+                runs.append(a)
+                print(f"raw input [{tag}], {route:12s} seed {seed:5d}: {stages['loaded']} -> {stages['after_load_filter']} -> {stages['in_ransac_mask']} -> "
+                      f"{stages['after_optimal_triangulation']} -> {stages['after_distance_error']} (the reference kept {len(ref_rows)}, {int(both.sum())} in common): "
+                      f"{k} planes, ARI on the reference's inliers {a.get('ari_reference_inliers', float('nan')):.3f}, all {a.get('ari_all', float('nan')):.3f}, "
+                      f"histogram {a.get('ours_histogram')}", flush=True)
+            aris = sorted(r.get("ari_reference_inliers", float("nan")) for r in runs)
+            print(f"   => {route}: planes {[r['planes'] for r in runs]}, median ARI on the reference's inliers {aris[len(aris) // 2]:.3f}, min {aris[0]:.3f}", flush=True)
+            out[tag][route] = runs
     return out
 
 
@@ -179,7 +239,8 @@ def main():
               + ", ".join(f"{r['ari_reference_inliers']:.3f}" for r in runs), flush=True)
     run("dlt", corr, F, e2)                                  # (leaves the default neighbourhood set)
     if os.environ.get("RAW", "1") != "0":
-        rec["from_the_raw_input_file"] = raw_route()
+        seeds = tuple(int(x) for x in os.environ.get("SEEDS", "1234,7,99").split(","))
+        rec["from_the_raw_input_file"] = raw_route(seeds)
     print(json.dumps(rec))
     return rec
 
