@@ -124,17 +124,22 @@ def cpu_baseline(sc, thr2: float, sample: int, seed: int, beside=None):
     return out, H, c1
 
 
-def labeling_extra(mh, eng, a, thr2, lam, legacy=False):
+def labeling_extra(mh, eng, a, thr2, lam, legacy=False, plane_separation=None):
     """Context for the label half of the path (not part of `value`): one LabelingStep on the GPU next
     to the REFERENCE's own alpha-expansion (oracle/_ref: GCoptimization + BK compiled unmodified, its
-    lazy callback data cost restated) on one host core, same inputs, labels compared."""
+    lazy callback data cost restated) on one host core, same inputs, labels compared.
+    Three scenes (r06): the bench's own (planes 13 px apart where they are observed: every move is decided by the dominance
+    reduction, NO max-flow is solved — `moves_solved` 0), an intermediate one (planes 7 px apart: some moves keep an undecided
+    core and go through the solver, GCoptimization.cpp:1212-1274) and the r04 generator's (planes inside each other's
+    truncation threshold: cores of thousands of sites).  Each record says which it is: moves_solved, core_max, barriers."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     # legacy: the r04 generator — planes inside each other's truncation threshold, i.e. ambiguous data terms: the HARD
     # instances of the alpha-expansion (cores of thousands of sites, several cycles), kept as the solver's stress figure
-    sc = mh.synth.make_scene(a.points, a.planes, seed=a.seed, legacy_r04=legacy)
+    kw = {} if plane_separation is None else {"plane_separation": float(plane_separation)}
+    sc = mh.synth.make_scene(a.points, a.planes, seed=a.seed, legacy_r04=legacy, **kw)
     eng.set_correspondences(sc.src, sc.dst, sc.aff)
     eng.set_epipolar(sc.F, sc.e2)
     eng.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
@@ -145,8 +150,17 @@ def labeling_extra(mh, eng, a, thr2, lam, legacy=False):
     t0 = time.perf_counter()
     lab, energy, cycles = eng.labeling_step(False, np.full(sc.n, -1, np.int32))
     gpu_ms = (time.perf_counter() - t0) * 1e3
-    out = {"sites": sc.n, "labels": H.shape[0] + 1, "neighbour_hits": int(sc.hit_col.size),
-           "gpu_labeling_step_ms": gpu_ms, "energy": int(energy), "cycles": int(cycles)}
+    st = eng.expand_stats()
+    out = {"scene": ("the r04 generator (planes inside each other's truncation threshold)" if legacy else
+                     f"planes {plane_separation if plane_separation is not None else 13.0:g} px apart where they are observed"),
+           "sites": sc.n, "labels": H.shape[0] + 1, "neighbour_hits": int(sc.hit_col.size),
+           "gpu_labeling_step_ms": gpu_ms, "energy": int(energy), "cycles": int(cycles),
+           "moves_run": int(st["moves_run"]), "moves_solved": int(st["moves_solved"]), "core_max": int(st["core_max"]),
+           "barriers": int(st["barriers"]), "solver_ms": st["solve_us"] * 1e-3,
+           "what": ("NO max-flow solved: every move of this step was decided by the dominance reduction (k_move_setup + k_reduce only)"
+                    if int(st["moves_solved"]) == 0 else
+                    f"{int(st['moves_solved'])} of {int(st['moves_run'])} moves kept an undecided core (at most {int(st['core_max'])} sites) and went through the "
+                    "push-relabel solver (k_solve)")}
     # B4: per-label HAF re-estimation, GPU kernel vs the oracle's restatement of
     # GetHomographyHAFNonminimal (M/MultiH.cpp:913-989) on one host core, same labels
     eng.set_models(H)
@@ -173,28 +187,36 @@ def labeling_extra(mh, eng, a, thr2, lam, legacy=False):
 
 def full_loop_extra(a):
     """Context (not part of `value`): BASELINE configs[4] on this one GPU — the whole Process() of the host class
-    (100 000 proposals, greedy selection, 20 merge/label/re-estimate iterations) through tools/loop_bench.py in a
-    child process."""
+    (100 000 proposals, greedy selection, then the merge/label/re-estimate loop capped at 20 iterations) through
+    tools/loop_bench.py in a child process; r06: the loop's CPU baseline beside it (the oracle's restatement with the
+    reference's GCO inside, one core, same scene, same initial models) and the reference's own route (INIT_STABLE_SETS)."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(N=str(a.points), K=str(a.planes), HYP=str(a.models), ITERS="20", REPEAT="1")
 
-    def run(iter_hyp: int):
-        e = dict(env, ITER_HYP=str(iter_hyp))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loop_bench.py")], env=e, capture_output=True, text=True, timeout=600)
+    def run(iter_hyp: int, **extra):
+        e = dict(env, ITER_HYP=str(iter_hyp), **extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loop_bench.py")], env=e, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return None, (r.stdout + r.stderr)[-400:]
         return json.loads(line[-1]), None
 
-    rec, err = run(0)
+    def per_iteration(rec):
+        n = max(int(rec.get("labeling_steps") or 0), 1)
+        return rec["loop_s"] / n * 1e3
+
+    rec, err = run(0, CPU_LOOP="1")
     if rec is None:
         return {"error": err}
-    out = {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 100000 proposals, then 20 merge/label/re-estimate iterations",
-           "fixed_iterations": 20, "iterations_reported_by_the_class": rec["iterations"],
-           "iterations_note": "GetIterationNumber() is the reference's iteration_number - 1 (M/MultiH.cpp:311): 19 after 20 LabelingSteps; fewer when the loop "
-                              "converges before the twentieth (the reference's own stop rule, :295, stays in force)",
+    out = {"workload": "BASELINE configs[4] on 1 GPU: Process() of class MultiH, 100000 DLT proposals + greedy selection, then the merge / label / "
+                       "re-estimate loop until the reference's stop rule (M/MultiH.cpp:295) fires, at most 20 iterations",
+           "iteration_cap": 20, "iterations_run": rec.get("labeling_steps"), "iterations_reported_by_the_class": rec["iterations"],
+           "iterations_note": "iterations_run = LabelingSteps the loop ran (MultiH::GetLabelingStepsRun); GetIterationNumber() is the reference's "
+                              "iteration_number - 1 (M/MultiH.cpp:311), one less.  The cap of 20 (SetFixedIterations) is a cap: the reference's own "
+                              "stop rule stays in force and ends this loop earlier",
            "clusters": rec["clusters"], "energy": rec["energy"], "loop_s": rec["loop_s"],
+           "ms_per_iteration": per_iteration(rec),
            "ground_truth": {"what": "agreement of the labels with the generator's ground truth: a plane is recovered when one label holds >= 80 % of "
                                     "its inlier correspondences; ARI over all correspondences (outliers a class of their own)",
                             "planes_recovered": rec.get("planes_recovered"), "planes": rec.get("planes"), "ari": rec.get("ari"),
@@ -202,11 +224,22 @@ def full_loop_extra(a):
            "process_s": rec["total_s"], "process_s_second_call": rec.get("total_s_second_call"),
            "note": "process_s is the first Process() of a fresh process (it also pays for the HIP runtime and the code objects); "
                    "process_s_second_call is the same call repeated in that process, identical result",
-           "ms_per_iteration": rec["loop_s"] / 20 * 1e3, "digest": rec["digest"]}
+           "digest": rec["digest"]}
+    cl = rec.get("cpu_loop")
+    if cl:
+        out["cpu_baseline_loop"] = dict(cl, gpu_loop_s=rec["loop_s"], ratio=cl["value"] / max(rec["loop_s"], 1e-9))
+    # the reference's OWN route: per-point HAF homographies, mean shift, 3-point fits hand hundreds of models to the loop
+    rec3, err3 = run(0, INIT="stable")
+    out["reference_route"] = ({"what": "MultiH::INIT_STABLE_SETS (EstablishStablePointSets, M/MultiH.cpp:604-694) instead of the DLT proposals",
+                               "iterations_run": rec3.get("labeling_steps"), "clusters": rec3["clusters"], "energy": rec3["energy"],
+                               "loop_s": rec3["loop_s"], "ms_per_iteration": per_iteration(rec3), "process_s": rec3["total_s"],
+                               "process_s_second_call": rec3.get("total_s_second_call"), "planes_recovered": rec3.get("planes_recovered"),
+                               "ari": rec3.get("ari"), "digest": rec3["digest"]}
+                              if rec3 is not None else {"error": err3})
     # the same with a fresh batch of proposals in EVERY iteration (PEARL re-proposal on the points left unexplained)
     rec2, err2 = run(a.models)
-    out["with_reproposal"] = ({"iter_hypotheses": a.models, "clusters": rec2["clusters"], "energy": rec2["energy"],
-                               "loop_s": rec2["loop_s"], "process_s": rec2["total_s"], "digest": rec2["digest"],
+    out["with_reproposal"] = ({"iter_hypotheses": a.models, "iterations_run": rec2.get("labeling_steps"), "clusters": rec2["clusters"], "energy": rec2["energy"],
+                               "loop_s": rec2["loop_s"], "ms_per_iteration": per_iteration(rec2), "process_s": rec2["total_s"], "digest": rec2["digest"],
                                "planes_recovered": rec2.get("planes_recovered"), "ari": rec2.get("ari")}
                               if rec2 is not None else {"error": err2})
     return out
@@ -410,6 +443,7 @@ def main():
             eng.adopt_prefetched()
         n_res, ms_res = eng.profile_get(1)       # MH_K_RESIDUAL
         n_dlt, ms_dlt = eng.profile_get(0)       # MH_K_DLT4 (on the second stream, beside the sweep)
+        n_x, ms_x = eng.profile_get(7)           # MH_K_EXCHANGE: all-gather + arg-max on the exchange stream, from the sweep's end
         best, score = last
         import hashlib
         import numpy as np
@@ -421,7 +455,7 @@ def main():
         else:
             ptr, _ = eng.device_buffer(0)
             scores = torch.as_tensor(_DevView(ptr, M, "<i4"), device=dev).cpu().numpy()
-        return {"sizes": sizes, "M": M, "dt": float(tt.item()), "res_ms": ms_res / max(n_res, 1),
+        return {"sizes": sizes, "M": M, "dt": float(tt.item()), "dt_local": dt, "xchg_ms": ms_x / max(n_x, 1), "res_ms": ms_res / max(n_res, 1),
                 "dlt_ms": ms_dlt / max(n_dlt, 1), "best_model": int(best), "best_score": int(score),
                 "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "step_ms_max": per_step[-1],
                 "scores_sha256": hashlib.sha256(np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]}
@@ -462,7 +496,7 @@ def main():
     kernel_pass = None
     if world > 1:
         kernel_pass = run_mode(a.scaling, min(a.steps, 8), 1, pipelined=True, profile=True)
-        pipe["res_ms"], pipe["dlt_ms"] = kernel_pass["res_ms"], kernel_pass["dlt_ms"]
+        pipe["res_ms"], pipe["dlt_ms"], pipe["xchg_ms"] = kernel_pass["res_ms"], kernel_pass["dlt_ms"], kernel_pass["xchg_ms"]
     other = None
     if world > 1 and not a.no_other_mode:
         other = run_mode("weak" if a.scaling == "strong" else "strong", a.steps, a.warmup, pipelined=True, profile=False)
@@ -477,6 +511,23 @@ def main():
     # reported beside the headline (`pipelined_form` / `sequential_form`).
     head, other_form = (seq, pipe) if world == 1 else (pipe, seq)
     M, sizes, dt = head["M"], head["sizes"], head["dt"]
+    # What the transport is, read back from RCCL itself, and each rank's own figures — gathered ONCE, outside every timed
+    # region: a multi-GPU number can then be decomposed into the ranks' sweeps, their waits in the exchange and their steps.
+    transport = {"kind": transport_kind if world > 1 else "none (one GPU: no exchange; the arg-max runs on the engine's exchange stream)",
+                 "rccl_ranks": None, "rccl_rank_of_rank0": None, "rccl_version": None}
+    if native_comm is not None:
+        transport["rccl_ranks"] = int(native_comm[0].mhr_count(native_comm[1]))
+        transport["rccl_rank_of_rank0"] = int(native_comm[0].mhr_rank(native_comm[1]))
+        transport["rccl_version"] = int(native_comm[0].mhr_version())
+        if transport["rccl_ranks"] != world:
+            raise SystemExit(f"bench.py: RCCL reports a communicator of {transport['rccl_ranks']} ranks, the launcher started {world}")
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "hypotheses_per_step": head["M"], "k_residual_ms": head["res_ms"], "exchange_ms": head.get("xchg_ms"),
+                "step_ms": head["dt_local"] / a.steps * 1e3,
+                "rccl_rank": int(native_comm[0].mhr_rank(native_comm[1])) if native_comm is not None else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     head_first = (sharding.shard_range(a.models, world, rank)[0] if a.scaling == "strong" else sharding.batch_first(0, world, rank, M))
     # One GPU only: the per-rank shards a strong split of this batch over 2 / 4 / 8 GPUs would hand a rank, stepped the same
     # way (no timing markers inside, 40 steps) — what the split can reach at best before any exchange between real ranks.
@@ -645,7 +696,11 @@ def main():
                 "step_ms_median": other_form["step_ms_median"], "k_residual_ms": other_form["res_ms"], "k_dlt4_ms": other_form["dlt_ms"],
                 "k_residual_frac_of_hbm_peak": frac("other_form.k_residual_frac_of_hbm_peak", alg_bytes / (other_form["res_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS),
                 "scores_identical": other_form["scores_sha256"] == head["scores_sha256"]},
-            "transport": transport_kind,
+            "transport": transport,
+            "per_rank": per_rank,
+            "per_rank_note": ("k_residual_ms / exchange_ms: HIP events around every launch in a separate pass of 8 steps (exchange_ms: from the end of the batch's "
+                              "sweep to the end of the arg-max behind the all-gather, on the exchange stream = the rank's wait for its peers + the wire time); "
+                              "step_ms: this rank's own wall time over the headline steps (the headline takes the MAX over ranks)") if per_rank else None,
             "strong_split_rehearsal_on_one_gpu": shard_rehearsal,
             "fused_score_hypotheses_per_s_per_gpu": M_res / (pretest_ms * 1e-3),
             "fused_score": {"what": "mh_score on the same batch, no matrix written: FP32 pre-test with a rigorous error bound, FP64 formula only for the "
@@ -699,6 +754,7 @@ def main():
             assert np.array_equal(eng.score(thr2), cs), "GPU/oracle score mismatch"
             try:
                 out["labeling"] = labeling_extra(mh, eng, a, thr2, lam)
+                out["labeling_on_the_intermediate_scene"] = labeling_extra(mh, eng, a, thr2, lam, plane_separation=7.0)
                 out["labeling_on_the_r04_scene"] = labeling_extra(mh, eng, a, thr2, lam, legacy=True)
             except Exception as ex:                      # context only: never lose the headline line
                 out["labeling"] = {"error": repr(ex)}

@@ -339,41 +339,55 @@ enum { MH_K_DLT4 = 0, MH_K_RESIDUAL = 1, MH_K_SCORE = 2, MH_K_DATACOST = 3, MH_K
 MH_API int mh_profile_enable(mh_engine* e, int on);
 MH_API int mh_profile_reset(mh_engine* e);
 MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total_ms);
-/* Tuning and diagnostic knobs for tools/ (defaults are the measured optima).  Keys 2..12 change the SCHEDULE of the
- * alpha-expansion or what is logged, never a result: 2..5 solver schedule (frontier rounds per barrier interval, most
- * push cycles per phase, push phases per global relabel, workgroups of the solver launch), 6 dominance-reduction
- * rounds per launch (0 = off), 7 mean-shift iterations per host round trip, 8 moves logged by mh_get_expand_trace
- * (0 = off), 9 move whose relabels are logged one by one, 10 push cycles per phase as a multiple of the last
- * relabel's depth, 11 flow recycling between the cycles of an expansion (1 on, 0 every move from the zero flow), 12
- * dominance-reduction launches per move (1 or 2), 14 test hook: the first attempts of the next n expansions count as
- * barrier time-outs (exercises the restart with fewer workgroups), 15 the FP32 pre-test of the score kernels (1 on, 0 the
- * FP64 sweep for every pair; the counts are equal by construction), 16 tiling of that pre-test kernel, 17 passes of the
- * dominance cascade inside the solver launch (0 = to its fixed point), 18 test hook: the n-th scoring round of the coming
- * greedy selections fails on this rank (exercises the collective exit of mh_select_greedy), 19 the materialising residual sweep as a resident
- * grid that hands itself the work items (value = workgroup slots left free beyond its own occupancy, default 0; -1 = one
- * hardware-dispatched workgroup per item), 20 the sweep is held until the second stream has reached a pending DLT prefetch's
- * dispatch (1, default) or not (0) — schedule only, 21 moves whose core components are diagnosed (mh_get_core_components; 0 = off), 22 experiment: dummy streams
- * created in front of the engine's second stream (before its first use), 23 the int32 cost matrix as a resident grid (n point slices,
- * default 8; 0 = one hardware-dispatched workgroup per item; -1 = about 37 500 items), 24 the same for the FP32 pre-test score
- * (default 12) — schedule only, 25 the DLT proposer's form (0, default: by context — columns in registers handed round with
- * DPP for mh_propose_dlt4, the LDS-staged form, whose 72 registers fit beside a resident sweep, for mh_prefetch_dlt4; 1: the
- * LDS-staged form everywhere; 2: the register form everywhere; same bits), 26 experiment: the resident residual sweep takes its items slice-major with this
- * many point slices (0, default: model block fastest, ~37 500 items), 27 the same order for the resident cost-matrix kernel,
- * 28 experiment: the cost-matrix kernel evaluates the near pairs of several models together (same matrix; slower) — schedule only,
- * 29 mean shift: once at most this many climbs of a batch are still running they run to their end in one persistent launch
- * (default 12, and never more than are resident at once; 0 = a launch per iteration throughout) — schedule only,
- * 30 NOT schedule-only: mh_select_greedy refits every round's winner to the correspondences of the support set it explains
- * (the loop's per-label HAF least squares, M/MultiH.cpp:913-989, with one label; needs affinities and the epipolar geometry)
- * before it claims them, and the refit takes the hypothesis' place in H_out when it is finite and explains at least as many
- * (0 = off, the default of the engine; class MultiH switches it on: SetProposalRefit), 31 the k-NN table through a grid over
- * the source image (1, default) or by the exhaustive pass (0) — the same table, schedule only, 32 mean shift: a workgroup per
- * climb through a one-coordinate index, one launch per batch (1, default, for 6- and 10-dimensional rows up to 131 072 of them;
- * 0: the launched / persistent schedule of keys 7 and 29) and 33 the members per iteration beyond which such a climb counts as
- * dense and is handed to the persistent kernel once the batch has drained (default 8) — same modes, schedule only, 36 the
- * rounds of mh_select_greedy after the first count their candidates on the points the last claim took out of the support set
- * and subtract (1, default) or count them again on what is left (0) — the same selection, schedule only.  Keys 0 (residual kernel) and 1 (score kernel) select measurement builds of those kernels — one of
- * them (fused multiply-adds) is not bit-exact — and are accepted only by a library compiled with -DMH_TUNING
- * (python multi-h_amd/build.py --tuning); the product library answers MH_ERR_INVALID to any value but 0. */
+/* mh_set_tuning — every key in one table (r06).  Class:
+ *   S  product switch, SCHEDULE ONLY: accepted by the product library, never changes a result (defaults are the measured optima)
+ *   R  product switch that CHANGES RESULTS — key 30 alone
+ *   D  diagnostic: what is logged / read back, never a result
+ *   T  test hook: injects a failure
+ *   X  experiment of a measurement build: accepted only by a library compiled with -DMH_TUNING (python multi-h_amd/build.py
+ *      --tuning); the product library takes the value 0 and answers MH_ERR_INVALID to anything else
+ *
+ *  key class default  what
+ *   0   X     0       residual kernel variant (other tilings, nt stores, compiler division, store-only calibration, fused multiply-adds: one not bit-exact)
+ *   1   X     0       score kernel variant
+ *   2   S     128     alpha-expansion solver: frontier (relax) rounds per barrier interval
+ *   3   S     512     ... most push cycles per phase
+ *   4   S     1       ... push phases per global relabel
+ *   5   S     256     ... workgroups of the solver launch
+ *   6   S     2       dominance-reduction rounds per launch (0 = off)
+ *   7   S     6       mean shift: climb iterations per host round trip (launched schedule)
+ *   8   D     0       moves logged by mh_get_expand_trace (0 = off)
+ *   9   D     -1      the move whose relabels are logged one by one
+ *  10   S     6       push cycles per phase as a multiple of the last relabel's depth
+ *  11   S     1       flow recycling between the cycles of an expansion (0: every move from the zero flow)
+ *  12   S     1       dominance-reduction launches per move (1 or 2)
+ *  13   X     0       row pitch of R in doubles (0 = the product's)
+ *  14   T     0       the first attempts of the next n expansions count as barrier time-outs (restart with fewer workgroups)
+ *  15   S     1       FP32 pre-test of the score kernels (0: the FP64 sweep for every pair; counts equal by construction)
+ *  16   X     0       tiling of that pre-test kernel
+ *  17   S     2       passes of the dominance cascade inside the solver launch (0 = to its fixed point)
+ *  18   T     0       the n-th scoring round of the coming greedy selections fails on this rank (collective exit of mh_select_greedy)
+ *  19   S     0       residual sweep as a resident grid: workgroup slots left free beyond its own occupancy (-1: one hardware-dispatched workgroup per item)
+ *  20   S     1       the sweep is held until the second stream has reached a pending DLT prefetch's dispatch
+ *  21   D     0       moves whose core components are diagnosed (mh_get_core_components)
+ *  22   S     0       dummy streams created in front of the engine's second stream, before its first use (placement experiment kept in the product: no effect on results)
+ *  23   S     8       int32 cost matrix as a resident grid: point slices (0: one workgroup per item; -1: about 37 500 items)
+ *  24   S     12      the same for the FP32 pre-test score
+ *  25   S     0       DLT proposer's form: 0 by context (registers + DPP for mh_propose_dlt4, LDS-staged for mh_prefetch_dlt4), 1 LDS everywhere, 2 registers everywhere — same bits
+ *  26   X     0       resident residual sweep takes its items slice-major with this many point slices
+ *  27   X     0       the same order for the resident cost-matrix kernel
+ *  28   X     0       cost-matrix kernel evaluates the near pairs of several models together (same matrix; slower)
+ *  29   S     12      mean shift: at most this many running climbs of a batch finish in one persistent launch (0 = a launch per iteration)
+ *  30   R     0       mh_select_greedy refits every round's winner to the correspondences of the support set it explains (the loop's
+ *                     per-label HAF least squares, M/MultiH.cpp:913-989, one label; needs affinities and the epipolar geometry) before it
+ *                     claims them; the refit takes the hypothesis' place when it is finite and explains at least as many.  Sticky per engine;
+ *                     class MultiH sets it on every call (SetProposalRefit, default on).  The ranks of a sharded batch must agree on it
+ *                     (their records carry it; r06).
+ *  31   S     1       k-NN table through a grid over the source image (0: the exhaustive pass) — the same table
+ *  32   S     1       mean shift: a workgroup per climb through a one-coordinate index, one launch per batch (0: keys 7 / 29's schedule)
+ *  33   S     8       ... members per iteration beyond which an indexed climb counts as dense and is handed to the persistent kernel
+ *  36   S     1       greedy selection: rounds after the first count on the points the last claim took out and subtract (0: count again on what is left)
+ * (34 and 35 are not assigned.) */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);
 
 #ifdef __cplusplus

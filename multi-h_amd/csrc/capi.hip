@@ -595,10 +595,13 @@ static int build_knn_graph(mh_engine* e, int k, double radius)
         HIPCHK(e->knn_start.reserve((size_t)G * G + 1));
         HIPCHK(e->knn_P.reserve((size_t)4 * n));
         HIPCHK(e->knn_orig.reserve((size_t)n));
-        HIPCHK(launch_knn_grid(pp, k, e->knn_tmp.p, e->knn_cell.p, e->knn_count.p, e->knn_start.p, e->knn_P.p, e->knn_orig.p, e->stream));
-        const float r2g = radius > 0.0 ? (float)radius * (float)radius : INFINITY;
-        HIPCHK(launch_hits_filter(pp, k, r2g, e->knn_tmp.p, e->gb_info.p + 2, e->stream));
-        return device_sym_graph(e, nullptr, k, e->knn_tmp.p);
+        const hipError_t hg = launch_knn_grid(pp, k, e->knn_tmp.p, e->knn_cell.p, e->knn_count.p, e->knn_start.p, e->knn_P.p, e->knn_orig.p, e->stream);
+        if (hg == hipSuccess) {
+            const float r2g = radius > 0.0 ? (float)radius * (float)radius : INFINITY;
+            HIPCHK(launch_hits_filter(pp, k, r2g, e->knn_tmp.p, e->gb_info.p + 2, e->stream));
+            return device_sym_graph(e, nullptr, k, e->knn_tmp.p);
+        }
+        if (hg != hipErrorInvalidValue) HIPCHK(hg);      // InvalidValue: no usable grid (all source points coincide, or a cell size beyond float32) — the exhaustive pass below
     }
     // enough slices of the candidate range to give every SIMD a few waves (one thread per query and slice)
     const int blocks = (n + 255) / 256;
@@ -756,12 +759,14 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key >= 2 && key <= 5 && value >= 1) { e->tune_expand[key - 2] = value; return MH_OK; }
     if (key == 6 && value >= 0) { e->tune_reduce = value; return MH_OK; }
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
-    if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }
+    if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }       // mean shift: persistent tail below this many climbs (0 = off)
     if (key == 32 && (value == 0 || value == 1)) { e->tune_ms_indexed = value; return MH_OK; }     // mean shift: indexed climbs (1, default) or the launched / persistent schedule (0): same modes
     if (key == 36 && (value == 0 || value == 1)) { e->tune_select_decrement = value; return MH_OK; }     // greedy selection: decremental rounds (1, default) — schedule only
     if (key == 33 && value >= 0 && value <= (1 << 20)) { e->tune_ms_dense = value; return MH_OK; }     // ... and the member count beyond which an indexed climb is handed on
+    // key 30 CHANGES RESULTS (the one such key the product library accepts): every winner of mh_select_greedy is refitted to its
+    // inliers before it claims them.  Sticky per engine; class MultiH sets it on every ProposeModels call (SetProposalRefit).
     if (key == 30 && (value == 0 || value == 1)) { e->tune_select_refine = value; return MH_OK; }
-    if (key == 31 && (value == 0 || value == 1)) { e->tune_knn_grid = value; return MH_OK; }        // k-NN through the grid (1, default) or exhaustively (0): same table     // NOT schedule-only: changes what mh_select_greedy selects       // mean shift: persistent tail below this many climbs (0 = off)
+    if (key == 31 && (value == 0 || value == 1)) { e->tune_knn_grid = value; return MH_OK; }        // k-NN through the grid (1, default) or exhaustively (0): same table
     if (key == 8 && value >= 0 && value <= (1 << 20)) { e->trace_moves = value; return MH_OK; }
     if (key == 9 && value >= -1) { e->detail_move = value; return MH_OK; }
     if (key == 10 && value >= 1 && value <= 64) { e->tune_push_mult = value; return MH_OK; }

@@ -227,6 +227,11 @@ int mh_local_homographies(mh_engine* e, double locality, double* H_out, double* 
     });
 }
 
+// iterations one indexed / persistent launch may run a climb for before it hands it back still running (r06, advisor: 1 << 20 let
+// a climb that neither converges nor dies spin for seconds inside one kernel; 120 000 = the launched schedule's own cap of 20 000
+// rounds x 6 iterations, after which the host's "did not converge" path fires)
+static constexpr int MS_MAX_ITERS_PER_LAUNCH = 120000;
+
 int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_width,
                   unsigned long long seed, double* modes, int max_modes, int* assign, int* n_modes)
 {
@@ -275,7 +280,9 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
     // r05: the index of this call's rows (k_ms_indexed).  The coordinate with the widest spread of its ordinary values (rows
     // parked at 1e300 and non-finite ones aside) is binned in cells of bandWidth^2 (1 + 2^-20) — wider if that would take
     // more cells than the index holds.  The choice affects speed only: any coordinate, any lo, any w >= that bound is exact.
-    const bool indexed = e->tune_ms_indexed != 0 && ms_indexed_supported(n, d);
+    // r06 (advisor): only for an ordinary positive bandWidth^2 — the index's exactness rests on cells at least that wide; a huge or
+    // non-finite band runs the launched / persistent schedule, which has no such precondition
+    const bool indexed = e->tune_ms_indexed != 0 && ms_indexed_supported(n, d) && band_sq > 0.0 && band_sq < 1e299;
     MeanShiftIndex ix{};
     if (indexed) {
         double lo[16], hi[16];
@@ -291,7 +298,6 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
         double spread = -1.0;
         for (int j = 0; j < d; ++j) { const double sp = hi[j] >= lo[j] ? hi[j] - lo[j] : 0.0; if (sp > spread) { spread = sp; coord = j; } }
         double width = band_sq * (1.0 + 0x1p-20);
-        if (!(width > 0.0) || !(width < 1e299)) width = 1.0;                  // (a degenerate band: one cell does)
         const int max_cells = ms_index_max_cells();
         if (!(spread >= 0.0) || !(spread < 1e299)) spread = 0.0;
         if (spread / width > (double)(max_cells - 2)) width = spread / (double)(max_cells - 2);
@@ -393,11 +399,11 @@ int mh_mean_shift(mh_engine* e, const double* data, int n, int d, double band_wi
                     const int room = std::max(0, per_cu) * e->cu_count * 7 / 8;
                     keep = std::min(e->tune_ms_persist, room / std::min(64, (n + 255) / 256));
                 }
-                HIPCHK(launch_ms_indexed(w, active, n_active, starts_dev, ix, band_sq, stop_thresh, 1 << 20, e->tune_ms_dense,
+                HIPCHK(launch_ms_indexed(w, active, n_active, starts_dev, ix, band_sq, stop_thresh, MS_MAX_ITERS_PER_LAUNCH, e->tune_ms_dense,
                                          keep, e->ms_ctl.p, e->h_ms_dev, e->stream, ms_stats ? e->ms_ticks.p + 5 : nullptr));
                 ++e->ms_indexed_launches;
             } else if (G > 0) {
-                HIPCHK(launch_ms_persist(w, active, n_active, band_sq, stop_thresh, 1 << 20, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
+                HIPCHK(launch_ms_persist(w, active, n_active, band_sq, stop_thresh, MS_MAX_ITERS_PER_LAUNCH, e->ms_ctl.p, e->ms_partial2.p, e->ms_pcnt2.p,
                                          e->h_ms_dev, e->stream, ms_stats ? e->ms_ticks.p : nullptr));
                 ++e->ms_persist_launches;
                 st_G += G;

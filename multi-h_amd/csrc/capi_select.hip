@@ -91,9 +91,14 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
     const int symmetric = e->residual_mode == MH_RESIDUAL_SYMMETRIC ? 1 : 0;
     // r05, key 30: each round's winner is refitted to its inliers before it claims them (select.hip, launch_sel_refit).  Needs the
     // affinities and the epipolar geometry (the per-label HAF least squares of the loop); a setting, like thr2, that the ranks share.
+    // r06 (advisor): affinities / epipolar geometry missing is the state of THIS rank's engine — it goes through local_failure like
+    // every other rank-local error (returning here would leave the peers waiting in the all-gather), and the setting itself
+    // travels in the records' mode word (bit 1) beside the residual mode (bit 0): ranks that disagree about it would claim with
+    // different models, so k_sel_claim raises error 3 on any mismatch of the word.
     const bool refine = e->tune_select_refine != 0;
-    if (refine && (!e->have_aff || !e->have_epi))
-        return fail(MH_ERR_NOT_SET, "mh_select_greedy with refitted winners (mh_set_tuning key 30) needs affinities and the epipolar geometry");
+    const bool refine_usable = refine && e->have_aff && e->have_epi;
+    if (refine && !refine_usable)
+        local_failure(MH_ERR_NOT_SET, "mh_select_greedy with refitted winners (mh_set_tuning key 30) needs affinities and the epipolar geometry");
     if (refine) {
         HIPCHK(e->labels_pts.reserve((size_t)n));
         HIPCHK(e->sel_refit.reserve(10));
@@ -201,7 +206,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         const int local_err = local_rc != MH_OK ? 1 : 0;
         const bool gather_scores = sharded && first && longest > 0;      // north_star's exchange, once per batch
         HIPCHK(launch_sel_argmax(e->sel_counts.p, orig, Mc, my_off, key_local, gather_scores ? e->sel_scores.p : nullptr, s));
-        HIPCHK(launch_sel_record(e->sel_counts.p, orig, Hs, Mc, my_off, key_local, local_err, symmetric, my_record, s));
+        HIPCHK(launch_sel_record(e->sel_counts.p, orig, Hs, Mc, my_off, key_local, local_err, symmetric | (refine ? 2 : 0), my_record, s));
         if (sharded) {
             if (gather_scores) {
                 rc = exchange(e, e->sel_scores.p, e->sel_gathered.p, sizeof(int) * (size_t)longest, s);
@@ -214,7 +219,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         HIPCHK(launch_sel_compact(e->sel_counts.p, orig, Hs, Mc, need, records, world, my_off, e->sel_orig[cur ^ 1].p,
                                   e->sel_cand_H[cur ^ 1].p, e->sel_rec.p, decrement ? e->sel_carried[cur ^ 1].p : nullptr, s));
         const double* refit = nullptr;
-        if (refine) {
+        if (refine_usable) {
             // every rank holds all the points and the same records: the refit is computed redundantly, identically
             Affines aff{ e->a11.p, e->a12.p, e->a21.p, e->a22.p };
             HIPCHK(launch_sel_refit(e->pts(), aff, e->epi, records, world, thr2, need, e->mask.p, e->labels_pts.p, e->sel_refit.p,
@@ -231,7 +236,7 @@ int mh_select_greedy(mh_engine* e, double thr2, int need, int max_models, unsign
         if (e->h_sel[4] != 0)                            // every rank sees the same word, so every rank leaves here
             return fail(e->h_sel[4] == 3 ? MH_ERR_INVALID : MH_ERR_HIP,
                         e->h_sel[4] == 2 ? "greedy selection: the gathered score vector and the ranks' records disagree about the winner"
-                        : e->h_sel[4] == 3 ? "greedy selection: the ranks are not in the same residual mode (mh_set_residual_mode)"
+                        : e->h_sel[4] == 3 ? "greedy selection: the ranks are not in the same residual mode (mh_set_residual_mode) or do not agree on refitted winners (mh_set_tuning key 30)"
                                            : "greedy selection: a rank reported an error");
         const int best = e->h_sel[0];
         if (best < need) break;

@@ -240,7 +240,10 @@ k_knn_grid(int N, int k, KnnGrid g, const int* __restrict__ start, const float4*
             if (xlo <= 0 && ylo <= 0 && xhi >= G - 1 && yhi >= G - 1) break;        // the whole grid has been seen
             if (r >= 1) {
                 const float reach = ((float)r - 0.01f) * g.c;               // no unexamined point is closer than this
-                if (kd < reach * reach * (1.0f - 1e-5f)) break;
+                // r06 (advisor): the walk ends on the k-th entry — the last one that is output — not on the K-th of the list
+                // (K = 8 / 16 / 32 >= k: for k = 9 .. 15 or 17 .. 31 it ran several rings longer than the table needs)
+                const float kdk = __shfl(bd, k - 1, 64);
+                if (kdk < reach * reach * (1.0f - 1e-5f)) break;
             }
         }
         if (lane < k) out[(size_t)q * k + lane] = bi;
@@ -277,11 +280,16 @@ hipError_t launch_knn_grid(const Points& p, int k, int* nbr_out, int* cell_of, i
     if (p.n <= 0) return hipSuccess;
     const int G = knn_grid_cells(p.n);
     const double range = std::fmax(p.xmax - p.xmin, p.ymax - p.ymin);
-    if (!(range >= 0.0) || !std::isfinite(range) || !std::isfinite(p.xmin) || !std::isfinite(p.ymin)) return hipErrorInvalidValue;
+    // r06 (advisor): no grid when all source points coincide (every point in cell 0, every query still walking up to G empty
+    // rings) or when the cell size does not fit float32 (c = inf, inv_c = 0: the same); hipErrorInvalidValue sends the caller
+    // to the exhaustive pass
+    if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(p.xmin) || !std::isfinite(p.ymin) ||
+        !std::isfinite((float)(range / G)) || !((float)(G / range) > 0.0f) || !std::isfinite((float)(G / range)))
+        return hipErrorInvalidValue;
     KnnGrid g;
     g.G = G;
-    g.c = (float)(range > 0.0 ? range / G : 1.0);
-    g.inv_c = (float)(range > 0.0 ? G / range : 0.0);
+    g.c = (float)(range / G);
+    g.inv_c = (float)(G / range);
     g.x0 = (float)p.xmin;
     g.y0 = (float)p.ymin;
     float4* P = reinterpret_cast<float4*>(P4);

@@ -246,7 +246,7 @@ hipError_t launch_argmin_labels(const int* cost, int L, int n, int* label, long 
 hipError_t launch_sel_pack_points(const Points& p, const unsigned char* mask, double* cx1, double* cy1, double* cx2, double* cy2,
                                   int* count, hipStream_t s);
 // one rank's offer in a round of the greedy selection: 88 bytes, the unit of the sharded exchange
-struct SelRecord { unsigned long long key; double H[9]; int err; int mode; };      // mode: the rank's residual mode (must agree)
+struct SelRecord { unsigned long long key; double H[9]; int err; int mode; };      // mode: bit 0 the rank's residual mode, bit 1 refitted winners (key 30); the ranks' words must agree
 static_assert(sizeof(SelRecord) == 88, "the exchanged record is 88 bytes");
 hipError_t launch_sel_argmax(const int* counts, const int* orig, int Mc, unsigned int my_off, unsigned long long* key,
                              int* scores_full, hipStream_t s);

@@ -160,7 +160,7 @@ k_sel_claim(const double* __restrict__ x1, const double* __restrict__ y1, const 
         int err = 0;
         for (int r = 0; r < world; ++r) if (records[r].err) err = records[r].err;
         if (key_check && *key_check != kg) err = 2;
-        for (int r = 1; r < world; ++r) if (records[r].mode != records[0].mode) err = 3;      // forward on one rank, symmetric on another
+        for (int r = 1; r < world; ++r) if (records[r].mode != records[0].mode) err = 3;      // forward on one rank, symmetric on another; or winners refitted on one only
         if (err) rec[4] = err;
     }
     if (!kg || best < need) return;

@@ -36,44 +36,58 @@ struct Rng {
 
 struct Node { int dim; double val; int lo, hi, point; };      // leaf: dim = -1, point = the row
 
-int build(const double* pv, std::vector<int>& idx, int first, int count, Rng& rng, std::vector<Node>& nodes)
+// r06 (advisor): built with an explicit stack.  A tree split at the mean can be as deep as it has points (one gross outlier peeled
+// off per level), and the recursive form needed a host stack frame per level.  Same tree, node for node: a node is numbered and
+// draws its cut dimension when it is taken off the stack, and the left child is taken before anything of the right one
+// (pre-order — the order of the recursion, and of the Python twin in tools/neighbourhood_sweep.py).
+int build(const double* pv, std::vector<int>& idx, int first0, int count0, Rng& rng, std::vector<Node>& nodes)
 {
-    const int me = (int)nodes.size();
-    nodes.push_back(Node{ -1, 0.0, -1, -1, -1 });
-    if (count == 1) { nodes[me].point = idx[first]; return me; }
-    const int ns = std::min(count, 100);
-    double mean[4], var[4];
-    for (int d = 0; d < 4; ++d) {
-        double s = 0.0;
-        for (int k = 0; k < ns; ++k) s = s + pv[4 * (size_t)idx[first + k] + d];
-        mean[d] = s / (double)ns;
-        double v = 0.0;
-        for (int k = 0; k < ns; ++k) { const double x = pv[4 * (size_t)idx[first + k] + d] - mean[d]; v = v + x * x; }
-        var[d] = v / (double)ns;
-    }
-    int order[4] = { 0, 1, 2, 3 };
-    std::stable_sort(order, order + 4, [&](int a, int b) { return var[a] > var[b]; });      // largest variance first
-    const int dim = order[rng.below(4)];                  // "among the five of largest variance": all four here
-    const double val = mean[dim];
+    struct Todo { int first, count, parent; bool is_hi; };
+    std::vector<Todo> todo;
+    todo.push_back(Todo{ first0, count0, -1, false });
+    const int root = (int)nodes.size();
     std::vector<int> left, right;
-    for (int k = 0; k < count; ++k) {
-        const int p = idx[first + k];
-        (pv[4 * (size_t)p + dim] < val ? left : right).push_back(p);
+    while (!todo.empty()) {
+        const Todo t = todo.back();
+        todo.pop_back();
+        const int first = t.first, count = t.count;
+        const int me = (int)nodes.size();
+        nodes.push_back(Node{ -1, 0.0, -1, -1, -1 });
+        if (t.parent >= 0) (t.is_hi ? nodes[t.parent].hi : nodes[t.parent].lo) = me;
+        if (count == 1) { nodes[me].point = idx[first]; continue; }
+        const int ns = std::min(count, 100);
+        double mean[4], var[4];
+        for (int d = 0; d < 4; ++d) {
+            double s = 0.0;
+            for (int k = 0; k < ns; ++k) s = s + pv[4 * (size_t)idx[first + k] + d];
+            mean[d] = s / (double)ns;
+            double v = 0.0;
+            for (int k = 0; k < ns; ++k) { const double x = pv[4 * (size_t)idx[first + k] + d] - mean[d]; v = v + x * x; }
+            var[d] = v / (double)ns;
+        }
+        int order[4] = { 0, 1, 2, 3 };
+        std::stable_sort(order, order + 4, [&](int a, int b) { return var[a] > var[b]; });      // largest variance first
+        const int dim = order[rng.below(4)];                  // "among the five of largest variance": all four here
+        const double val = mean[dim];
+        left.clear();
+        right.clear();
+        for (int k = 0; k < count; ++k) {
+            const int p = idx[first + k];
+            (pv[4 * (size_t)p + dim] < val ? left : right).push_back(p);
+        }
+        if (left.empty() || right.empty()) {                  // every point equal in that dimension: halve
+            left.assign(idx.begin() + first, idx.begin() + first + count / 2);
+            right.assign(idx.begin() + first + count / 2, idx.begin() + first + count);
+        }
+        std::copy(left.begin(), left.end(), idx.begin() + first);
+        std::copy(right.begin(), right.end(), idx.begin() + first + (int)left.size());
+        nodes[me].dim = dim;
+        nodes[me].val = val;
+        const int nl = (int)left.size();
+        todo.push_back(Todo{ first + nl, count - nl, me, true });      // taken after the whole left subtree
+        todo.push_back(Todo{ first, nl, me, false });
     }
-    if (left.empty() || right.empty()) {                  // every point equal in that dimension: halve
-        left.assign(idx.begin() + first, idx.begin() + first + count / 2);
-        right.assign(idx.begin() + first + count / 2, idx.begin() + first + count);
-    }
-    std::copy(left.begin(), left.end(), idx.begin() + first);
-    std::copy(right.begin(), right.end(), idx.begin() + first + (int)left.size());
-    nodes[me].dim = dim;
-    nodes[me].val = val;
-    const int nl = (int)left.size();
-    const int lo = build(pv, idx, first, nl, rng, nodes);
-    const int hi = build(pv, idx, first + nl, count - nl, rng, nodes);
-    nodes[me].lo = lo;
-    nodes[me].hi = hi;
-    return me;
+    return root;
 }
 
 } // namespace
@@ -96,6 +110,9 @@ void ApproxNeighbourHits(const double* pv, int n, int trees, int checks, double 
         roots[t] = build(pv, perm, 0, n, rng, forest[t]);
     }
     const double r2 = radius * radius;
+    // r06 (advisor): a far branch whose lower bound already exceeds the radius cannot hold a hit and is not queued (FLANN prunes
+    // against its worst distance).  The hit lists do not change: such branches sat behind every branch that can hold one and
+    // only used up what was left of the `checks` budget on points that are no hits.
     struct Branch { double mind; long long order; int tree, node; };
     auto later = [](const Branch& a, const Branch& b) { return a.mind > b.mind || (a.mind == b.mind && a.order > b.order); };
     std::vector<int> stamp((size_t)n, -1);
@@ -110,7 +127,7 @@ void ApproxNeighbourHits(const double* pv, int n, int trees, int checks, double 
             while (nd[node].dim >= 0) {
                 const double diff = v[nd[node].dim] - nd[node].val;
                 const int near = diff < 0 ? nd[node].lo : nd[node].hi, far = diff < 0 ? nd[node].hi : nd[node].lo;
-                heap.push(Branch{ mind + diff * diff, pushed++, t, far });
+                if (mind + diff * diff <= r2) heap.push(Branch{ mind + diff * diff, pushed++, t, far });
                 node = near;
             }
             const int p = nd[node].point;

@@ -48,6 +48,19 @@ attempt("wrong_shard", lambda: eng.propose_dlt4(77, first, mine - 1) if rank == 
 # rank 0 is in symmetric mode
 attempt("symmetric", lambda: eng.set_residual_mode(True) if rank == 0 else None)
 eng.set_residual_mode(False)
+# r06 (advisor): refitted winners (key 30).  (a) both ranks have the setting on, but rank 1's engine has no epipolar geometry
+# (rank-local state): it must go through the collective with its error word set, not return before it.  (b) rank 1 alone has
+# the setting on: the records' mode words differ and every rank fails with the same words.  (c) both on and complete: a clean
+# refitted selection, the same on both ranks.
+eng.set_tuning(30, 1)
+if rank == 0:
+    eng.set_epipolar(sc.F, sc.e2)
+attempt("refit_without_geometry_on_rank_1", lambda: None)
+eng.set_epipolar(sc.F, sc.e2)
+attempt("refit_on_one_rank", lambda: eng.set_tuning(30, 0) if rank == 0 else None)
+eng.set_tuning(30, 1)
+attempt("refit_clean", lambda: None)
+eng.set_tuning(30, 0)
 attempt("clean_again", lambda: None)
 for r in range(world):                                  # one rank at a time: the launcher merges the ranks' stdout
     if r == rank:

@@ -41,6 +41,14 @@ def test_a_rank_local_failure_ends_the_selection_on_every_rank():
     # every rank fails with the same words when one of them is in the other mode
     for r in (r0, r1):
         assert not r["symmetric"]["ok"] and "same residual mode" in r["symmetric"]["msg"] and r["symmetric"]["code"] == -2, r["symmetric"]
+    # r06 (advisor, medium): refitted winners.  The setting travels in the records' mode word; a rank whose engine lacks the
+    # geometry the refit needs fails THROUGH the collective
+    for r in (r0, r1):
+        assert not r["refit_on_one_rank"]["ok"] and "refitted winners" in r["refit_on_one_rank"]["msg"] and r["refit_on_one_rank"]["code"] == -2, r["refit_on_one_rank"]
+    assert not r1["refit_without_geometry_on_rank_1"]["ok"] and r1["refit_without_geometry_on_rank_1"]["code"] == -4
+    assert "epipolar" in r1["refit_without_geometry_on_rank_1"]["msg"]
+    assert not r0["refit_without_geometry_on_rank_1"]["ok"] and "a rank reported an error" in r0["refit_without_geometry_on_rank_1"]["msg"]
+    assert r0["refit_clean"]["ok"] and r0["refit_clean"] == r1["refit_clean"] and len(r0["refit_clean"]["counters"]) >= 3
     assert r0["clean_again"] == r0["clean"] and r1["clean_again"] == r1["clean"]
 
 

@@ -142,6 +142,10 @@ def test_native_rccl_transport_on_a_one_rank_communicator(mh, engine, synth, ora
     comm = C.c_void_p()
     assert rl.mhr_init(C.byref(comm), 0, 1, uid, 0) == 0, rl.mhr_last_error()
     try:
+        # r06: what RCCL itself says about the communicator — the read-back every bench line and harness log carries
+        assert rl.mhr_count(comm) == 1 and rl.mhr_rank(comm) == 0, rl.mhr_last_error()
+        assert rl.mhr_version() >= 20000, "ncclGetVersion: major * 10000 + minor * 100 + patch"
+        assert rl.mhr_count(None) == -1 and b"communicator" in rl.mhr_last_error()
         sc = synth.make_scene(4000, 4, seed=31, with_neighbours=False)
         _load(engine, sc)
         engine.propose_dlt4(77, 0, 3001)
@@ -157,8 +161,13 @@ def test_native_rccl_transport_on_a_one_rank_communicator(mh, engine, synth, ora
         # the bench step's exchange: score all-gather + arg-max over the gathered vector (mh_select_best)
         engine.residual_matrix(THR2, fetch_R=False, fetch_counts=False)
         before = rl.mhr_calls(comm)
+        engine.profile_reset()
+        engine.profile_enable(True)
         best_via = engine.select_best(3001)
+        engine.profile_enable(False)
         assert rl.mhr_calls(comm) - before == 1
+        n_x, ms_x = engine.profile_get(7)                  # MH_K_EXCHANGE: the all-gather + the arg-max behind it, timed on the exchange stream
+        assert n_x == 1 and 0.0 < ms_x < 50.0
         engine.set_transport(0, 1)
         assert engine.select_best() == best_via
         cnt_all = engine.score(THR2)

@@ -11,7 +11,10 @@ the int32 scores per greedy round); labeling and re-estimation r
 deterministic.  Every rank must end with the same labels — checked here — and the result must not
 depend on G.  Env: N K ITERS HYP ITER_HYP; LOOP_BACKEND=gloo LOOP_DEVICE=0 put several ranks on one
 GPU (the parity test's setup).  INIT=stable: the reference's own initialisation (per-point homographies, mean shift,
-3-point fits) instead of the DLT batch."""
+3-point fits) instead of the DLT batch.  CPU_LOOP=1 (one GPU, DLT route): the same loop — ClusterMergingAndLabeling,
+M/MultiH.cpp:263-311 — once more through the ORACLE on one host core (oracle/mh_oracle.cpp section 11, every
+alpha-expansion by the reference's own GCoptimization of oracle/_ref), from the models the GPU's selection handed to the
+loop and on the neighbourhood the engine built: the CPU baseline beside `loop_s` (checker code, reported only)."""
 import ctypes as C, hashlib, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,6 +64,7 @@ k = host.mhh_run_process(src.ctypes.data_as(dp), dst.ctypes.data_as(dp), aff.cty
                          None, 0, labels.ctypes.data_as(C.POINTER(C.c_int)), Hout.ctypes.data_as(dp), 256,
                          C.byref(it), C.byref(en), C.byref(secs), ITER_HYP, -1 if os.environ.get("INIT") == "stable" else 4)
 wall = time.time() - t0
+labeling_steps = int(host.mhh_get_labeling_steps())
 digest = hashlib.sha256(labels.tobytes() + Hout[:max(k, 0)].tobytes()).hexdigest()[:16]
 # REPEAT=1: the same call once more in this process — the first call of a process also pays for the HIP runtime and the code
 # objects; the second is what a caller that processes image pair after image pair sees
@@ -94,7 +98,38 @@ if rank == 0:
     print(f"N={N} planes={K} hypotheses={HYP} gpus={world}: clusters={k} iterations={it.value} energy={en.value:.0f} "
           f"loop={secs.value:.2f}s total={wall:.2f}s  planes recovered {quality['planes_recovered']}/{K}  ARI {quality['ari']:.3f}  "
           f"outliers labelled {quality['outliers_labelled']} (generated {quality['outliers_generated']})")
+    cpu_loop = None
+    if os.environ.get("CPU_LOOP") and world == 1 and os.environ.get("INIT") != "stable":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        e = mh.Engine(device, 2.6, 2.2, 0.005, 0.5, 20)
+        e.set_correspondences(sc.src, sc.dst, sc.aff)
+        e.set_epipolar(sc.F, sc.e2)
+        e.propose_dlt4(1234, 0, HYP)                                   # MultiH::ProposeModels: the same batch, the same selection
+        e.set_tuning(30, 1)
+        H0, _, _, _ = e.select_greedy(2.2 * 2.2, 20, 32, mask=np.ones(N, np.uint8))
+        e.build_neighbors_knn(16, radius=1.0 / 0.005)
+        rp, col, w = e.get_sym_graph()
+        e.close()
+        rows = np.repeat(np.arange(N), np.diff(rp))
+        keepw = (w == 2) | ((w == 1) & (rows < col))                   # a pair of weight 2 was found from both sides (SURVEY A-2)
+        hr, hc = rows[keepw], col[keepw]
+        order = np.lexsort((hc, hr))
+        hit_col = hc[order].astype(np.int32)
+        hit_rowptr = np.concatenate([[0], np.cumsum(np.bincount(hr, minlength=N))]).astype(np.int32)
+        O.lib().mho_set_fixed_iterations(ITERS)
+        t0 = time.time()
+        lab_o, H_o, it_o, en_o, used_ref = O.cluster_merging_and_labeling(sc.src, sc.dst, sc.aff, H0, sc.F, sc.e2, 0.5, 2.2, hit_rowptr, hit_col, 1234)
+        cpu_s = time.time() - t0
+        O.lib().mho_set_fixed_iterations(0)
+        cpu_loop = {"value": cpu_s, "unit": "s", "cores": 1, "kind": "port",
+                    "sample": f"the whole loop on the same scene from the same {H0.shape[0]} initial models: oracle restatement of ClusterMergingAndLabeling "
+                              f"(M/MultiH.cpp:263-311), every alpha-expansion by the reference's GCoptimization compiled unmodified (oracle/_ref): {bool(used_ref)}",
+                    "iterations": int(it_o), "energy": float(en_o), "models": int(H_o.shape[0]),
+                    "same_iterations_and_energy_as_the_gpu_loop": bool(it_o == it.value and en_o == en.value)}
+        print(f"CPU loop (oracle, one core): {cpu_s:.2f} s, iterations {it_o}, energy {en_o:.0f}, {H_o.shape[0]} models")
     print(json.dumps({"workload": "full_loop", "points": N, "planes": K, "hypotheses": HYP, "iterations": it.value,
+                      "labeling_steps": labeling_steps, "cpu_loop": cpu_loop,
                       "iter_hypotheses": ITER_HYP, "n_gpus": world, "clusters": k, "energy": en.value,
                       "loop_s": secs.value, "total_s": wall, "total_s_second_call": wall_warm, "digest": digest, "ranks_identical": same,
                       "exchanges": hook.stats["calls"] if hook else 0, **quality}))
