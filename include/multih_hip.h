@@ -306,6 +306,11 @@ MH_API int mh_expand(mh_engine* e, const int* init_labels, int* labels_out, int*
  * repeated once with the same grid before the grid is halved, word 22 = restarts of all expansions of this engine so far; only
  * the last attempt waits 3 s)}. */
 MH_API int mh_get_expand_stats(mh_engine* e, long long stats[24]);
+/* r06: the concurrent alpha-moves of the last expansion (csrc/expand.hip, k_commit): [0] batches launched, [1] moves kept out of a
+ * batch (solved beside others on the same labeling and validated), [2] batches that ended at a move whose test failed (it heads the
+ * next batch), [3] moves the host never launched because they were provably idempotent, [4] moves run alone, [5] reserved (0),
+ * [6] moves per batch (mh_set_tuning key 37), [7] label count from which the first cycle is batched too (key 38). */
+MH_API int mh_get_expand_batch_stats(mh_engine* e, long long stats[8]);
 /* Per-move log of the last alpha-expansion's solver launches (diagnostic; enabled with mh_set_tuning key 8 = number of
  * moves to log): 8 ints per move {undecided core sites, workgroups, global relabels, relabel intervals, push phases, grid
  * barriers, 100 MHz ticks inside the launch, of which inside barriers}; all zero for moves that were skipped or had an empty core. */
@@ -387,6 +392,10 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  *  32   S     1       mean shift: a workgroup per climb through a one-coordinate index, one launch per batch (0: keys 7 / 29's schedule)
  *  33   S     8       ... members per iteration beyond which an indexed climb counts as dense and is handed to the persistent kernel
  *  36   S     1       greedy selection: rounds after the first count on the points the last claim took out and subtract (0: count again on what is left)
+ *  37   S     16      alpha-expansion: this many consecutive moves are solved together on the same labeling and committed in order, each
+ *                     validated against what its predecessors changed (1: one move after the other, the form until r05) — same labels,
+ *                     energies and cycle counts
+ *  38   S     16      ... from the first cycle on for label sets of at least this many labels (smaller sets from the second cycle)
  * (34 and 35 are not assigned.) */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
     "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_get_score_stats", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_compat_trial_stats", "mh_inlier_moments", "mh_data_cost", "mh_expand",
-    "mh_get_expand_stats", "mh_get_expand_trace", "mh_get_core_components", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
+    "mh_get_expand_stats", "mh_get_expand_batch_stats", "mh_get_expand_trace", "mh_get_core_components", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
 
@@ -403,6 +403,12 @@ class Engine:
                          "core_sites", "core_max", "barriers", "relabels", "solve_us", "barrier_us", "relax_us", "push_us", "tail_us",
                          "barrier_timeout_retries", "solver_workgroups", "xcd_local_moves", "longest_barrier_wait_us"),
                         list(st)))
+
+    def expand_batch_stats(self):
+        st = (C.c_longlong * 8)()
+        self._check(self.lib.mh_get_expand_batch_stats(self._h, st))
+        return dict(zip(("batches", "batch_committed", "batch_invalid", "host_skipped", "solo_moves", "reserved", "moves_per_batch",
+                         "batch_min_labels"), list(st)))
 
     def expand_trace(self, moves: int):
         out = np.zeros((int(moves), 8), dtype=np.int32)

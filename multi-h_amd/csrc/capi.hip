@@ -402,6 +402,9 @@ void mh_destroy(mh_engine* e)
     e->ew_sink.release(); e->ew_height.release(); e->ew_decided.release(); e->ew_flags.release(); e->ew_acc.release();
     e->ew_comp.release(); e->ew_comp_out.release();
     e->ew_took.release(); e->ew_core.release(); e->ew_sent.release(); e->ew_trace.release(); e->ew_saved.release(); e->d_order.release(); e->d_wsum.release();
+    for (int k = 0; k < EXPAND_MAX_CTX - 1; ++k) { e->ewx_arcs[k].release(); e->ewx_sites[k].release(); e->ewx_core[k].release(); e->ewx_flags[k].release(); e->ewx_acc[k].release(); e->ewx_took[k].release(); }
+    e->ew_bctl.release(); e->ew_took_list.release();
+    if (e->h_batch) (void)hipHostFree(e->h_batch);
     e->knn_tmp.release(); e->knn_part_i.release(); e->knn_part_d.release();
     e->knn_cell.release(); e->knn_count.release(); e->knn_start.release(); e->knn_P.release(); e->knn_orig.release();
     for (int c = 0; c < 4; ++c) e->sel_pts[c].release();
@@ -761,6 +764,8 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 7 && value >= 1 && value <= 64) { e->tune_ms_batch = value; return MH_OK; }
     if (key == 29 && value >= 0 && value <= 64) { e->tune_ms_persist = value; return MH_OK; }       // mean shift: persistent tail below this many climbs (0 = off)
     if (key == 32 && (value == 0 || value == 1)) { e->tune_ms_indexed = value; return MH_OK; }     // mean shift: indexed climbs (1, default) or the launched / persistent schedule (0): same modes
+    if (key == 37 && value >= 1 && value <= EXPAND_MAX_CTX) { e->tune_expand_ctx = value; return MH_OK; }     // alpha-moves solved together (1: one after the other) — schedule only
+    if (key == 38 && value >= 0 && value <= (1 << 20)) { e->tune_batch_min_labels = value; return MH_OK; }    // ... from the first cycle on for label sets of at least this many labels
     if (key == 36 && (value == 0 || value == 1)) { e->tune_select_decrement = value; return MH_OK; }     // greedy selection: decremental rounds (1, default) — schedule only
     if (key == 33 && value >= 0 && value <= (1 << 20)) { e->tune_ms_dense = value; return MH_OK; }     // ... and the member count beyond which an indexed climb is handed on
     // key 30 CHANGES RESULTS (the one such key the product library accepts): every winner of mh_select_greedy is refitted to its

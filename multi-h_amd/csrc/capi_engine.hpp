@@ -186,6 +186,16 @@ struct mh_engine {
     int trace_moves = 0;                     // > 0: k_solve logs 8 ints per move (mh_set_tuning key 8)
     int detail_move = -1;                    // move whose relabels are logged one by one (key 9)
     DevBuf<unsigned char> ew_took;
+    // r06: the contexts of the concurrent alpha-moves beyond context 0 (expand.hip): per context cap + sent (2 nnz ints), excess /
+    // sink_cap / height / decided (4 n), core (8 n), control words and accumulators; took (n bytes); and the batch's own scratch
+    DevBuf<int> ewx_arcs[EXPAND_MAX_CTX - 1], ewx_sites[EXPAND_MAX_CTX - 1], ewx_core[EXPAND_MAX_CTX - 1], ewx_flags[EXPAND_MAX_CTX - 1];
+    DevBuf<long long> ewx_acc[EXPAND_MAX_CTX - 1];
+    DevBuf<unsigned char> ewx_took[EXPAND_MAX_CTX - 1];
+    DevBuf<int> ew_bctl, ew_took_list;
+    int* h_batch = nullptr;                  // mapped pinned: k_commit's publication
+    int* h_batch_dev = nullptr;
+    int tune_expand_ctx = 16;                // key 37: alpha-moves solved together (1 = one after the other, the form until r05)
+    int tune_batch_min_labels = 16;          // key 38: label sets of at least this many labels are batched from the first cycle on (smaller ones from the second)
     int cu_count = 256;
     DevBuf<int> sweep_ctl;                   // work counter + exit counter of the resident sweep (cleared by the launch itself)
     int sweep_wg_per_cu = -1;                // workgroups of the materialising sweep a compute unit holds (-1 = not queried yet)

@@ -26,6 +26,32 @@ int ensure_expand_work(mh_engine* e)
         HIPCHK(hipHostMalloc((void**)&e->h_acc, sizeof(long long) * 16, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&e->h_acc_dev, e->h_acc, 0));
     }
+    // r06: the contexts of the concurrent moves (key 37).  Fresh memory is cleared once: a context's capacities and flow counters
+    // are read for arcs the current move has not written only together with verdicts that make them irrelevant (expand.hip), but
+    // the control words' rings and tickets must start at zero (k_ctl_init) and nothing is gained by leaving the rest to chance.
+    const int extra = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX)) - 1;
+    for (int k = 0; k < extra; ++k) {
+        const size_t cap_a = e->ewx_arcs[k].cap, cap_s = e->ewx_sites[k].cap, cap_c = e->ewx_core[k].cap, cap_t = e->ewx_took[k].cap;
+        HIPCHK(e->ewx_arcs[k].reserve(2 * (size_t)nnz + 2));
+        HIPCHK(e->ewx_sites[k].reserve(5 * (size_t)n + 5));
+        HIPCHK(e->ewx_core[k].reserve((size_t)EXPAND_CORE_SHARDS * n));
+        HIPCHK(e->ewx_flags[k].reserve(EXPAND_FLAG_WORDS));
+        HIPCHK(e->ewx_acc[k].reserve(EXPAND_ACC_WORDS));
+        HIPCHK(e->ewx_took[k].reserve((size_t)n + 2));
+        if (e->ewx_arcs[k].cap != cap_a) HIPCHK(hipMemsetAsync(e->ewx_arcs[k].p, 0, sizeof(int) * e->ewx_arcs[k].cap, e->stream));
+        if (e->ewx_sites[k].cap != cap_s) HIPCHK(hipMemsetAsync(e->ewx_sites[k].p, 0, sizeof(int) * e->ewx_sites[k].cap, e->stream));
+        if (e->ewx_core[k].cap != cap_c) HIPCHK(hipMemsetAsync(e->ewx_core[k].p, 0, sizeof(int) * e->ewx_core[k].cap, e->stream));
+        if (e->ewx_took[k].cap != cap_t) HIPCHK(hipMemsetAsync(e->ewx_took[k].p, 0, e->ewx_took[k].cap, e->stream));
+    }
+    if (extra > 0) {
+        HIPCHK(e->ew_bctl.reserve(8 + EXPAND_MAX_CTX));
+        HIPCHK(e->ew_took_list.reserve((size_t)n + 2));
+        if (!e->h_batch) {
+            HIPCHK(hipHostMalloc((void**)&e->h_batch, sizeof(int) * 8, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer((void**)&e->h_batch_dev, e->h_batch, 0));
+            for (int i = 0; i < 8; ++i) e->h_batch[i] = 0;
+        }
+    }
     return MH_OK;
 }
 
@@ -75,6 +101,21 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
                   e->h_flags, e->h_acc, e->h_flags_dev, e->h_acc_dev,
                   e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], solve_grid, e->tune_push_mult, e->tune_reduce, e->tune_reduce_launches,
                   e->tune_cascade_iters, nullptr, 0, -1, nullptr, nullptr };
+    // r06: contexts for concurrent moves (expand.hip, k_commit)
+    w.n_ctx = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX));
+    for (int k = 0; k + 1 < w.n_ctx; ++k) {
+        ExpandWork::Ctx& x = w.ctx[k];
+        x.cap = e->ewx_arcs[k].p; x.sent = e->ewx_arcs[k].p + ((size_t)g.nnz + 1);
+        x.excess = e->ewx_sites[k].p; x.sink_cap = x.excess + ((size_t)g.n + 1); x.height = x.sink_cap + ((size_t)g.n + 1); x.decided = x.height + ((size_t)g.n + 1);
+        x.took = e->ewx_took[k].p; x.core = e->ewx_core[k].p; x.flags = e->ewx_flags[k].p; x.acc = e->ewx_acc[k].p;
+        x.took_list = x.decided + ((size_t)g.n + 1);
+    }
+    if (w.n_ctx > 1) {
+        w.bctl = e->ew_bctl.p;
+        w.h_batch = e->h_batch; w.h_batch_dev = e->h_batch_dev;
+        w.took_list0 = e->ew_took_list.p;
+        w.batch_min_labels = e->tune_batch_min_labels;
+    }
     // flow recycling (expand.hip, k_solve): L x (nnz + n) ints, cleared per expansion; left out (every move starts from
     // the zero flow) beyond 8 GiB.  Flows are not kept from one call to the next: measured in the alternation, the
     // re-estimated models move the problems far enough for a kept flow to cost more rounds than the zero flow.
@@ -267,6 +308,23 @@ int mh_get_expand_stats(mh_engine* e, long long stats[24])
     stats[21] = e->last_solve_grid;
     stats[22] = e->expand_retries_total;
     stats[23] = (long long)(e->last_expand.max_barrier_wait_ms * 1e3);
+    return MH_OK;
+    });
+}
+
+int mh_get_expand_batch_stats(mh_engine* e, long long stats[8])
+{
+    return guarded([&]() -> int {
+    if (!e || !stats) return fail(MH_ERR_INVALID, "null argument");
+    const ExpandStats& x = e->last_expand;
+    stats[0] = x.batches;
+    stats[1] = x.batch_committed;
+    stats[2] = x.batch_invalid;
+    stats[3] = x.host_skipped;
+    stats[4] = x.solo_moves;
+    stats[5] = 0;
+    stats[6] = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX));
+    stats[7] = e->tune_batch_min_labels;
     return MH_OK;
     });
 }

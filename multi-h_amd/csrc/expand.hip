@@ -72,6 +72,7 @@ enum { C_TLAST = 0,        // index of the last accepted move, -1 before the fir
        C_FLOW_MOVES = 7,
        C_CORE = 8,         // 8 shard counters of the core list
        C_MOVES_SOLVED = 16, C_CORE_MAX = 17, C_MOVES_RUN = 18, C_XCD_USED = 19,
+       C_TOOK_N = 20,      // sites in the context's took list (k_delta appends, k_commit walks; cleared by the move's first reduction launch)
        // grid barrier of k_solve, one 128-B line per XCD and one for the top level:
        //   line + 0 census (workgroups on this XCD), + 2 .. 9 four 64-bit {arrivals, changed, active} words, + 10 .. 13 four hmax words
        C_XCD = 64, C_LINE = 32, C_TOP = C_XCD + 8 * C_LINE,
@@ -91,6 +92,25 @@ enum { A_DELTA = 0, A_ENERGY = 1, A_EXCESS_SUM = 2, A_CORE_SUM = 3, A_OUTER = 4,
        A_BARRIERS = 7, A_TICKS = 8, A_T_BAR = 9, A_T_RELAX = 10, A_T_PUSH = 11, A_T_TAIL = 12, A_TAIL_ROUNDS = 13, A_MAX_WAIT = 14, A_COUNT = 16 /* mirrored to the host */ };
 enum { ERR_OVERFLOW = 1, ERR_BARRIER_TIMEOUT = 2, ERR_NO_CONVERGENCE = 3 };
 
+// r06: the per-move state of ONE move in flight (a "context"), and a batch of them: every kernel of a move takes a MoveBatch
+// and serves the context blockIdx.y selects, so K consecutive moves that are solved on the same labeling (see k_commit) cost
+// the launches of one.  A move alone is a batch of one on context 0.
+struct MoveCtx {
+    int* cap; int* sent; int* excess; int* sink_cap; int* height; int* decided; unsigned char* took; int* core;
+    int* took_list;        // the sites with took[] set, in any order (null: not kept — a move alone applies its labels lazily from took[])
+    int* flags; long long* acc;
+    int* saved_flow; int* saved_sink; int* trace; int* detail;
+    int alpha, t, warm;
+};
+struct MoveBatch { MoveCtx c[EXPAND_MAX_CTX]; int count; };
+// batch control words (device) and what k_commit publishes to the host
+enum { B_TLAST0 = 0,       // index of the last accepted move when the batch began (what its moves' skip tests saw)
+       B_SEQ = 1,
+       B_BAD = 8,          // EXPAND_MAX_CTX words: bit k of word j = move k of the batch fails its test against what move j changes
+       B_WORDS = 8 + EXPAND_MAX_CTX };
+static_assert(EXPAND_MAX_CTX <= 32, "one bit per move of a batch");
+enum { HB_FIRST_INVALID = 0, HB_TLAST = 1, HB_ERROR = 2, HB_ACCEPTED_HERE = 3, HB_DIRTY = 4, HB_SEQ = 5, HB_WORDS = 8 };
+
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
@@ -100,8 +120,10 @@ __device__ __forceinline__ bool move_is_skipped(const int* flags, int t, int L)
     return flags[C_ERROR] != 0 || (t >= L && flags[C_TLAST] <= t - L);
 }
 
-__global__ void k_ctl_init(int* __restrict__ flags, long long* __restrict__ acc)
+__global__ void k_ctl_init(MoveBatch b)                 // one workgroup per context
 {
+    int* flags = b.c[blockIdx.x].flags;
+    long long* acc = b.c[blockIdx.x].acc;
     for (int t = threadIdx.x; t < C_COUNT; t += blockDim.x) flags[t] = (t == C_TLAST || t == C_PEND) ? -1 : 0;
     for (int t = threadIdx.x; t < A_TOTAL; t += blockDim.x) acc[t] = 0;
 }
@@ -236,11 +258,18 @@ constexpr int SITES_PER_WBLOCK = 4 * SPW;      // per 256-thread workgroup
 // `label` is read (neighbours) and written (own site, pending move) in the same launch: a neighbour
 // j with took[j] reads as `pa` whether or not its row has already stored the new label.
 __global__ void __launch_bounds__(256)
-k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int t, int reduce_on,
-             int* label, int* __restrict__ cur_cost, const unsigned char* __restrict__ took,
-             int* __restrict__ cap, int* __restrict__ excess, int* __restrict__ sink_cap,
-             int* __restrict__ decided, int* __restrict__ flags, long long* __restrict__ acc)
+k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int reduce_on,
+             int* label, int* __restrict__ cur_cost, MoveBatch b)
 {
+    const MoveCtx& c = b.c[blockIdx.y];
+    const int alpha = c.alpha, t = c.t;
+    const unsigned char* __restrict__ took = c.took;
+    int* __restrict__ cap = c.cap;
+    int* __restrict__ excess = c.excess;
+    int* __restrict__ sink_cap = c.sink_cap;
+    int* __restrict__ decided = c.decided;
+    int* __restrict__ flags = c.flags;
+    long long* __restrict__ acc = c.acc;
     const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
     const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW;
@@ -322,9 +351,17 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int alpha,
 // COMPACT: sites still undecided when their row finishes are appended to the core list.
 template <bool COMPACT>
 __global__ void __launch_bounds__(256)
-k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decided,
-         int* __restrict__ flags, long long* __restrict__ acc, int* __restrict__ core, int ROUNDS, int housekeep)
+k_reduce(Graph g, int L, MoveBatch b, int ROUNDS, int housekeep)
 {
+    const MoveCtx& c = b.c[blockIdx.y];
+    const int t = c.t;
+    int* cap = c.cap;
+    int* excess = c.excess;
+    int* sink_cap = c.sink_cap;
+    int* decided = c.decided;
+    int* __restrict__ flags = c.flags;
+    long long* __restrict__ acc = c.acc;
+    int* __restrict__ core = c.core;
     // COMPACT walks the sites in a fixed pseudo-random order (g.order).  The solver gives 64 consecutive core sites to
     // one workgroup, and the sites that are busy in a move are neighbours in the image: were they also neighbours in
     // the list (input sorted along a scan line, a Z-curve ...) a few CUs would issue all the uncoalesced requests of
@@ -344,6 +381,7 @@ k_reduce(Graph g, int L, int t, int* cap, int* excess, int* sink_cap, int* decid
         // the core counters and the solver's barrier words are cleared by k_delta, behind the solver launch that used them)
         flags[C_PEND] = -1;                              // k_move_setup has applied it
         flags[C_TICKET] = 0;
+        flags[C_TOOK_N] = 0;
         for (int s = 0; s < SUBTICKETS; ++s) flags[C_SUBTICKET + s * C_LINE] = 0;
         long long ex = 0;
         for (int s = 0; s < STRIPES; ++s) { ex += acc[A_EXCESS_S + s * STRIPE_LL]; acc[A_EXCESS_S + s * STRIPE_LL] = 0; acc[A_DELTA_S + s * STRIPE_LL] = 0; }
@@ -1138,10 +1176,23 @@ k_core_components(Graph g, int L, int t, const int* __restrict__ decided, const 
 }
 
 __global__ void __launch_bounds__(SOLVE_THREADS)
-k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, int* height, int* decided,
-        const int* __restrict__ core, int* flags, long long* acc, int* __restrict__ trace, int* __restrict__ detail,
-        int* __restrict__ saved_flow, int* __restrict__ saved_sink, int warm, int mslots, SolveParams sp)
+k_solve(Graph g, int L, MoveBatch b, int mslots, SolveParams sp)
 {
+    const MoveCtx& c = b.c[blockIdx.y];
+    const int t = c.t, warm = c.warm;
+    int* cap = c.cap;
+    int* sent = c.sent;
+    int* excess = c.excess;
+    int* sink_cap = c.sink_cap;
+    int* height = c.height;
+    int* decided = c.decided;
+    const int* __restrict__ core = c.core;
+    int* flags = c.flags;
+    long long* acc = c.acc;
+    int* __restrict__ trace = c.trace;
+    int* __restrict__ detail = c.detail;
+    int* __restrict__ saved_flow = c.saved_flow;
+    int* __restrict__ saved_sink = c.saved_sink;
     extern __shared__ int s_priv[];                  // F_FIELDS x mslots x SOLVE_ROWS
     __shared__ int s_red[8];
     __shared__ int s_skip;
@@ -1167,11 +1218,15 @@ k_solve(Graph g, int L, int t, int* cap, int* sent, int* excess, int* sink_cap, 
 // Energy difference of the candidate labeling (sites with decided == 1 take alpha) and, by the last
 // workgroup to finish, the verdict of the move: accept iff the energy strictly decreases (:1259).
 __global__ void __launch_bounds__(256)
-k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int t,
-        const int* __restrict__ label, const int* __restrict__ cur_cost,
-        const int* __restrict__ decided, unsigned char* __restrict__ took,
-        int* __restrict__ flags, long long* acc)
+k_delta(Graph g, const int* __restrict__ cost, int L, int potts,
+        const int* __restrict__ label, const int* __restrict__ cur_cost, MoveBatch b)
 {
+    const MoveCtx& c = b.c[blockIdx.y];
+    const int alpha = c.alpha, t = c.t;
+    const int* __restrict__ decided = c.decided;
+    unsigned char* __restrict__ took = c.took;
+    int* __restrict__ flags = c.flags;
+    long long* acc = c.acc;
     __shared__ long long s[256];
     __shared__ int s_last;
     if (threadIdx.x == 0) s_last = move_is_skipped(flags, t, L) ? 1 : 0;
@@ -1192,6 +1247,15 @@ k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int 
         ti = decided[i] == 1;
         took[i] = ti ? 1 : 0;
         if (ti) mine += (long long)cost[(size_t)i * L + alpha] - cur_cost[i];
+    }
+    if (c.took_list) {                                   // (wave-uniform) the moving sites as a list, for k_commit
+        const unsigned long long tb = __ballot(ti);
+        if (tb) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&flags[C_TOOK_N], (int)__popcll(tb));
+            base = __shfl(base, 0);
+            if (ti) c.took_list[base + (int)__popcll(tb & ((1ull << lane) - 1ull))] = i;
+        }
     }
     for_flagged(__ballot(ti), [&](int m) {
         const int oi_m = __shfl(oi, m < 0 ? 0 : m);
@@ -1250,7 +1314,7 @@ k_delta(Graph g, const int* __restrict__ cost, int L, int potts, int alpha, int 
 __global__ void __launch_bounds__(256)
 k_apply_pending(int n, const int* __restrict__ cost, int L, int* __restrict__ label,
                 int* __restrict__ cur_cost, const unsigned char* __restrict__ took,
-                const int* __restrict__ flags)
+                const int* __restrict__ flags, int /* in_front_of_a_batch */)
 {
     const int pa = flags[C_PEND];
     if (pa < 0) return;
@@ -1258,6 +1322,175 @@ k_apply_pending(int n, const int* __restrict__ cost, int L, int* __restrict__ la
     if (i < n && took[i]) {                                      // applyNewLabeling, :423-441
         label[i] = pa;
         cur_cost[i] = cost[(size_t)i * L + pa];
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// r06: CONCURRENT ALPHA-MOVES.  oneExpansionIteration (GCoptimization.cpp:1278-1289) runs the expansions on alpha = 0, 1, ...
+// one after the other, each on the labeling its predecessor left.  Here K consecutive moves are solved TOGETHER on the same
+// labeling f (one launch of each move kernel, context = blockIdx.y), and k_batch_commit then walks them in the reference's order
+// and keeps a move's result only when it is provably what the sequential order would have given:
+//
+//   Let the accepted predecessors of move beta in this batch have changed the sites S (f -> f').  Write W_p = potts * sum_q w_pq
+//   and call p UNARY-KEPT for beta under a labeling g when  D_beta(p) - D_{g_p}(p) > W_p  (or g_p = beta: p is not a variable
+//   of the move at all): switching p to beta costs more in its data term than all its n-links together can return, so p keeps
+//   its label in EVERY minimum cut.  If every p in S u N(S) is unary-kept for beta under f AND under f', then in both problems
+//   — beta on f, beta on f' — those sites stay, the sites outside S u N(S) see the same unary terms, the same n-links among
+//   themselves and the same (unchanged) labels on the N(S) side of their other n-links: the two problems have the same set of
+//   minimum cuts, hence the same canonical one (the read-out is BK's minimal sink side, SURVEY A-1), the same sites take beta,
+//   and — every term that changes touches only sites whose labels agree in f and f' — the same energy gain, so the same verdict.
+//   A move that fails the test is not kept: it becomes the first move of the next batch, solved on the labeling as it then stands.
+//   The test for (j, k) reads the labeling the batch started from, j's list of moving sites and the two labels — not which other
+//   moves are accepted — so k_batch_check evaluates all pairs in parallel and k_batch_commit only walks a K x K bit table.
+//
+// A move that was skipped as idempotent when the batch began (move_is_skipped: nothing accepted since its label's last
+// expansion) stays skipped only while no predecessor in its batch is accepted; otherwise it is re-run too.  Labels, energies and
+// cycle counts are therefore the sequential ones (every parity test, golden file and stress tool runs through this path).
+// ---------------------------------------------------------------------------
+
+// In front of a batch: the contexts beyond 0 see the control words context 0 — the global ones — holds now.
+__global__ void k_batch_prep(MoveBatch b, int* __restrict__ bctl)
+{
+    int* G = b.c[0].flags;
+    const int k = threadIdx.x;
+    if (k == 0) { bctl[B_TLAST0] = G[C_TLAST]; G[C_PEND] = -1; }      // (whatever was pending has been applied: k_apply_pending, or k_batch_commit)
+    if (k < EXPAND_MAX_CTX) bctl[B_BAD + k] = 0;
+    if (k >= 1 && k < b.count) {
+        int* f = b.c[k].flags;
+        f[C_TLAST] = G[C_TLAST];
+        f[C_PEND] = -1;
+        f[C_ERROR] = G[C_ERROR];
+    }
+}
+
+__device__ __forceinline__ bool batch_move_skipped(const MoveCtx& c, int tlast0, int L)
+{
+    return c.flags[C_ERROR] != 0 || (c.t >= L && tlast0 <= c.t - L);           // what every launch of this move evaluated
+}
+
+// Behind a batch's k_delta, in parallel over everything: for every move j of the batch that would be accepted and every LATER move
+// k, does k pass the test above against what j changes?  The test looks only at the labeling the batch started from, at j's took
+// list and at the two labels — nothing in it depends on which other moves end up accepted — so all pairs are checked at once:
+// bit k of bctl[B_BAD + j] = "move k must not be kept if move j is".  Context blockIdx.y = j; 16 lanes per site of j's list walk
+// the site and its neighbours.  (The labels of the batch are consecutive, so a site's costs for all later moves are contiguous.)
+__global__ void __launch_bounds__(256)
+k_batch_check(Graph g, const int* __restrict__ cost, int L, int potts, const int* __restrict__ label, const int* __restrict__ cur_cost,
+              MoveBatch b, int* __restrict__ bctl)
+{
+    const int j = blockIdx.y;
+    if (j + 1 >= b.count) return;                        // nothing comes behind the last move
+    const MoveCtx& cj = b.c[j];
+    const int tlast0 = bctl[B_TLAST0];
+    if (batch_move_skipped(cj, tlast0, L) || cj.flags[C_PEND] < 0) return;       // skipped or rejected: it changes nothing
+    const int nt = cj.flags[C_TOOK_N];
+    const int sub = threadIdx.x % LPN;
+    const int alpha_j = cj.alpha, later = b.count - 1 - j;
+    unsigned bad = 0;
+    for (int idx = blockIdx.x * SITES_PER_BLOCK + (int)threadIdx.x / LPN; idx < nt; idx += gridDim.x * SITES_PER_BLOCK) {
+        const int p = cj.took_list[idx];
+        const int k0 = g.rowptr[p], k1 = g.rowptr[p + 1];
+        // lane `sub` serves the neighbours k0 + sub, k0 + sub + 16, ...; lane 0 also the site itself (slot -1)
+        for (int a = k0 + sub - (sub == 0 ? 1 : 0); a < k1; a = (a < k0 ? k0 : a + LPN)) {
+            const int s_ = a < k0 ? p : g.col[a];
+            const long long W = (long long)potts * g.wsum[s_];
+            const int lb = label[s_];
+            const long long Dl = cur_cost[s_];
+            const int* row = cost + (size_t)s_ * L + (alpha_j + 1);
+            const long long Dj = a < k0 ? (long long)cost[(size_t)s_ * L + alpha_j] : 0;
+            for (int q = 0; q < later; ++q) {
+                const long long Db = row[q];
+                bool ok = lb == alpha_j + 1 + q || Db - Dl > W;                    // under the labeling the batch started from
+                if (ok && a < k0) ok = Db - Dj > W;                               // the changed site itself: also under its new label
+                if (!ok) bad |= 1u << (j + 1 + q);
+            }
+        }
+    }
+    // (moves skipped when the batch began have no verdict to keep: k_batch_commit handles them)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) bad |= (unsigned)__shfl_xor((int)bad, m, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicOr((unsigned*)&bctl[B_BAD + j], bad);
+}
+
+// ... then the commit, in the reference's order (see above): every workgroup derives the same decisions from the same words —
+// none of which this launch writes — and applies its share of the accepted moves' took lists (applyNewLabeling, :423-441);
+// workgroup 0 records them in the global control words and publishes to the host.
+__global__ void __launch_bounds__(256)
+k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int* __restrict__ cur_cost, MoveBatch b,
+               int* __restrict__ bctl, int* __restrict__ h_batch)
+{
+    __shared__ int s_first, s_err, s_last_t, s_n_acc;
+    __shared__ unsigned s_acc;
+    if (threadIdx.x == 0) {
+        const int tlast0 = bctl[B_TLAST0];
+        unsigned accepted = 0;
+        int first_invalid = b.count, err = 0, last_t = -1, n_acc = 0;
+        for (int k = 0; k < b.count; ++k) {
+            const MoveCtx& c = b.c[k];
+            const int ek = c.flags[C_ERROR];
+            if (ek) err = ek;
+            const bool skipped = ek != 0 || (c.t >= L && tlast0 <= c.t - L);
+            bool valid = true;
+            if (accepted) {
+                if (skipped) valid = false;                  // no longer idempotent: something in front of it changed the labeling
+                else
+                    for (int j = 0; j < k; ++j)
+                        if ((accepted >> j & 1u) && ((unsigned)bctl[B_BAD + j] >> k & 1u)) valid = false;
+            }
+            if (!valid) { first_invalid = k; break; }
+            if (!skipped && c.flags[C_PEND] >= 0) { accepted |= 1u << k; last_t = c.t; ++n_acc; }
+        }
+        s_first = first_invalid; s_err = err; s_acc = accepted; s_last_t = last_t; s_n_acc = n_acc;
+    }
+    __syncthreads();
+    const unsigned accepted = s_acc;
+    for (int k = 0; k < b.count; ++k) {
+        if (!(accepted >> k & 1u)) continue;
+        const MoveCtx& c = b.c[k];
+        const int nt = c.flags[C_TOOK_N], a = c.alpha;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gridDim.x * 256) {
+            const int p = c.took_list[i];
+            label[p] = a;
+            cur_cost[p] = cost[(size_t)p * L + a];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int* G = b.c[0].flags;
+        if (s_err && !G[C_ERROR]) G[C_ERROR] = s_err;
+        // (context 0's k_delta wrote the global words for its own move itself: count the others)
+        if (s_last_t > G[C_TLAST]) G[C_TLAST] = s_last_t;
+        G[C_ACCEPTED] += s_n_acc - (int)(accepted & 1u);
+        const int seq = bctl[B_SEQ] + 1;
+        bctl[B_SEQ] = seq;
+        h_batch[HB_FIRST_INVALID] = s_first;
+        h_batch[HB_TLAST] = G[C_TLAST];
+        h_batch[HB_ERROR] = G[C_ERROR];
+        h_batch[HB_ACCEPTED_HERE] = s_n_acc;
+        h_batch[HB_DIRTY] = 0;
+        h_batch[HB_SEQ] = seq;
+    }
+}
+
+// The solver's statistics of the contexts beyond 0 into context 0's words (which k_publish mirrors to the host).
+__global__ void k_stats_merge(MoveBatch b)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int* G = b.c[0].flags;
+    long long* A = b.c[0].acc;
+    for (int k = 1; k < b.count; ++k) {
+        int* f = b.c[k].flags;
+        long long* a = b.c[k].acc;
+        G[C_FLOW_MOVES] += f[C_FLOW_MOVES]; f[C_FLOW_MOVES] = 0;
+        G[C_MOVES_SOLVED] += f[C_MOVES_SOLVED]; f[C_MOVES_SOLVED] = 0;
+        G[C_MOVES_RUN] += f[C_MOVES_RUN]; f[C_MOVES_RUN] = 0;
+        if (f[C_CORE_MAX] > G[C_CORE_MAX]) G[C_CORE_MAX] = f[C_CORE_MAX];
+        if (f[C_XCD_USED] > G[C_XCD_USED]) G[C_XCD_USED] = f[C_XCD_USED];
+        f[C_CORE_MAX] = 0; f[C_XCD_USED] = 0;
+        for (int w = A_CORE_SUM; w < A_COUNT; ++w) {
+            if (w == A_MAX_WAIT) { if (a[w] > A[w]) A[w] = a[w]; }
+            else A[w] += a[w];
+            a[w] = 0;
+        }
     }
 }
 
@@ -1341,11 +1574,27 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 {
     const dim3 grid1((g.n + 255) / 256), blk(256);                          // one thread per site
     const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site, 256 threads
-    const dim3 grid_w((g.n + SITES_PER_WBLOCK - 1) / SITES_PER_WBLOCK);    // one lane per site first, then LPN lanes for the sites that need them
+    const unsigned wblocks = (unsigned)((g.n + SITES_PER_WBLOCK - 1) / SITES_PER_WBLOCK);    // one lane per site first, then LPN lanes for the sites that need them
     ExpandStats stats = {};
-    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, s, w.flags, w.acc);
+    // the contexts: 0 = the work area's own buffers (and the global control words), k = w.ctx[k - 1]
+    const int n_ctx = std::max(1, std::min(w.n_ctx, EXPAND_MAX_CTX));
+    MoveBatch all{};
+    all.count = n_ctx;
+    for (int k = 0; k < n_ctx; ++k) {
+        MoveCtx& c = all.c[k];
+        if (k == 0) { c.cap = w.cap; c.sent = w.sent; c.excess = w.excess; c.sink_cap = w.sink_cap; c.height = w.height; c.decided = w.decided;
+                      c.took = w.took; c.core = w.core; c.flags = w.flags; c.acc = w.acc; c.took_list = w.took_list0; }
+        else { const ExpandWork::Ctx& x = w.ctx[k - 1];
+               c.cap = x.cap; c.sent = x.sent; c.excess = x.excess; c.sink_cap = x.sink_cap; c.height = x.height; c.decided = x.decided;
+               c.took = x.took; c.core = x.core; c.flags = x.flags; c.acc = x.acc; c.took_list = x.took_list; }
+    }
+    hipLaunchKernelGGL(k_ctl_init, dim3(n_ctx), dim3(64), 0, s, all);
     RET_IF(hipGetLastError());
     ++stats.launches;
+    auto finish_cycle = [&]() -> hipError_t {             // the contexts' solver statistics, then the control words to the host
+        if (n_ctx > 1) { hipLaunchKernelGGL(k_stats_merge, dim3(1), dim3(64), 0, s, all); ++stats.launches; }
+        return fetch(w, stats, s);
+    };
 
     if (g.nnz == 0) {                                  // solveSpecialCases, :470-491
         RET_IF(launch_argmin_labels(cost, L, g.n, w.label, w.acc, s));
@@ -1371,44 +1620,114 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     if (solve_lds > 128 * 1024) return hipErrorOutOfMemory;     // > 1.3 M sites at 256 workgroups
     if (solve_lds > 48 * 1024)
         RET_IF(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+
+    // The launches of `count` consecutive moves (labels alpha0 ..., move indices t0 ...) solved on the same labeling, contexts
+    // 0 .. count - 1.  count == 1: a move alone, the sequential form.
+    auto enqueue_moves = [&](int alpha0, int t0, int count, int cycle) -> hipError_t {
+        MoveBatch b = all;
+        b.count = count;
+        for (int k = 0; k < count; ++k) {
+            MoveCtx& c = b.c[k];
+            c.alpha = alpha0 + k;
+            c.t = t0 + k;
+            c.trace = (w.trace && c.t < w.trace_moves) ? w.trace : nullptr;
+            c.detail = (w.trace && c.t == w.detail_move) ? w.trace + 8 * (size_t)w.trace_moves : nullptr;
+            c.saved_flow = w.saved_flow ? w.saved_flow + (size_t)c.alpha * g.nnz : nullptr;
+            c.saved_sink = w.saved_flow ? w.saved_sink + (size_t)c.alpha * g.n : nullptr;
+            c.warm = (w.saved_flow && cycle > 1) ? 1 : 0;
+            if (count == 1) c.took_list = nullptr;             // a move alone: nobody walks the list
+        }
+        const dim3 grid_w(wblocks, (unsigned)count);
+        if (count > 1) { hipLaunchKernelGGL(k_batch_prep, dim3(1), dim3(64), 0, s, b, w.bctl); ++stats.launches; }
+        hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, w.reduce_rounds > 0 ? 1 : 0, w.label, w.cur_cost, b);
+        if (w.reduce_launches > 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, 1);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, w.reduce_launches > 1 ? 0 : 1);
+        if (count == 1 && w.comp_out && t0 < w.comp_moves)             // diagnostic: components of the core the reduction left
+            hipLaunchKernelGGL(k_core_components, dim3(1), dim3(1024), 0, s, g, L, t0, w.decided, w.flags, w.comp_scratch,
+                               w.comp_scratch + g.n, w.comp_out + 16 * (size_t)t0);
+        hipLaunchKernelGGL(k_solve, dim3((unsigned)solve_grid, (unsigned)count), dim3(SOLVE_THREADS), solve_lds, s, g, L, b, mslots, sp);
+        hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b);
+        if (count > 1) {
+            hipLaunchKernelGGL(k_batch_check, dim3(32, (unsigned)count), blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b, w.bctl);
+            hipLaunchKernelGGL(k_batch_commit, dim3(32), blk, 0, s, cost, L, w.label, w.cur_cost, b, w.bctl, w.h_batch_dev);
+            stats.launches += 2;
+        }
+        stats.launches += w.reduce_launches > 1 ? 5 : 4;
+        if (w.reduce_rounds > 0) stats.reduce_launches += w.reduce_launches > 1 ? 2 : 1;
+        return hipGetLastError();
+    };
+
+    // Batches: only with contexts to run them in, a label set worth it, and none of the per-move diagnostics that look at
+    // context 0's state between the launches of a move.
+    const bool can_batch = n_ctx > 1 && w.bctl && w.h_batch && L >= 2 && !w.comp_out;
+    bool batching = can_batch && L >= w.batch_min_labels;       // ... from the first cycle on; smaller label sets from the second (see below)
+    if (can_batch) RET_IF(hipMemsetAsync(w.bctl, 0, sizeof(int) * B_WORDS, s));
+    // What the host knows of C_TLAST (the index of the last accepted move): exact right behind a commit or a cycle's end,
+    // unknown once a move has been enqueued on its own since.  A move t >= L with TLAST <= t - L is idempotent — the device
+    // would return from each of its launches at once (move_is_skipped) — and is not launched at all when the host can tell.
+    int host_tlast = -1;
+    bool host_fresh = true;
+    int bsize = n_ctx;                                  // moves of the next batch: halved when a batch keeps little, doubled when one is kept whole
     int t = 0;
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         old_energy = energy;
-        for (int alpha = 0; alpha < L; ++alpha, ++t) {
-            ++stats.moves;
-            hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.reduce_rounds > 0 ? 1 : 0,
-                               w.label, w.cur_cost, w.took, w.cap, w.excess, w.sink_cap, w.decided, w.flags, w.acc);
-            if (w.reduce_launches > 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
-                                   w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds, 1);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, t, w.cap, w.excess,
-                               w.sink_cap, w.decided, w.flags, w.acc, w.core, w.reduce_rounds, w.reduce_launches > 1 ? 0 : 1);
-            if (w.comp_out && t < w.comp_moves)             // diagnostic: components of the core the reduction left
-                hipLaunchKernelGGL(k_core_components, dim3(1), dim3(1024), 0, s, g, L, t, w.decided, w.flags, w.comp_scratch,
-                                   w.comp_scratch + g.n, w.comp_out + 16 * (size_t)t);
-            hipLaunchKernelGGL(k_solve, dim3(solve_grid), dim3(SOLVE_THREADS), solve_lds, s, g, L, t, w.cap, w.sent, w.excess,
-                               w.sink_cap, w.height, w.decided, w.core, w.flags, w.acc,
-                               (w.trace && t < w.trace_moves) ? w.trace : nullptr,
-                               (w.trace && t == w.detail_move) ? w.trace + 8 * (size_t)w.trace_moves : nullptr,
-                               w.saved_flow ? w.saved_flow + (size_t)alpha * g.nnz : nullptr,
-                               w.saved_flow ? w.saved_sink + (size_t)alpha * g.n : nullptr,
-                               (w.saved_flow && cycle > 1) ? 1 : 0, mslots, sp);
-            hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, alpha, t, w.label, w.cur_cost,
-                               w.decided, w.took, w.flags, w.acc);
-            RET_IF(hipGetLastError());
-            stats.launches += w.reduce_launches > 1 ? 5 : 4;
-            if (w.reduce_rounds > 0) stats.reduce_launches += w.reduce_launches > 1 ? 2 : 1;
+        int alpha = 0;
+        // A first cycle from a cold start rewrites the labeling wholesale: with a handful of labels every accepted move
+        // touches its successor's sites and nothing validates; from the second cycle on most moves change little or nothing.
+        if (can_batch && cycle >= 2) batching = true;
+        while (alpha < L) {
+            if (host_fresh && t >= L && host_tlast <= t - L) {      // idempotent from here to the end of the cycle (nothing can be accepted in between)
+                const int rest = L - alpha;
+                stats.moves += rest; stats.host_skipped += rest;
+                alpha += rest; t += rest;
+                break;
+            }
+            int B = std::min(bsize, L - alpha);
+            if (host_fresh && t + B > host_tlast + L && host_tlast + L > t && t >= L) B = host_tlast + L - t;   // stop in front of the first idempotent move
+            if (!batching || B < 2) {
+                RET_IF(enqueue_moves(alpha, t, 1, cycle));
+                ++stats.moves; ++stats.solo_moves;
+                ++alpha; ++t;
+                host_fresh = false;
+                continue;
+            }
+            if (!host_fresh) {
+                // a move enqueued on its own may have left its labels pending (they are written lazily): the batch's moves all
+                // read the labeling, so it is brought up to date first
+                hipLaunchKernelGGL(k_apply_pending, grid1, blk, 0, s, g.n, cost, L, w.label, w.cur_cost, w.took, w.flags, 1);
+                ++stats.launches;
+            }
+            RET_IF(enqueue_moves(alpha, t, B, cycle));
+            ++stats.batches;
+            ++stats.host_syncs;
+            RET_IF(hipStreamSynchronize(s));
+            if (w.h_batch[HB_ERROR]) break;                           // the cycle's end reports it
+            const int j = w.h_batch[HB_FIRST_INVALID];
+            host_tlast = w.h_batch[HB_TLAST];
+            host_fresh = true;
+            stats.moves += j; stats.batch_committed += j;
+            alpha += j; t += j;
+            if (j < B) {
+                // Move alpha failed its test: it heads the next batch — a batch's first move has no predecessor to be tested
+                // against, so every batch keeps at least one move and no move is ever run twice in a row.  What came behind it
+                // in this batch is solved again there.  A batch that kept little was mostly wasted work: the next is smaller.
+                ++stats.batch_invalid;
+                if (2 * j < B) bsize = std::max(2, bsize / 2);
+            } else if (B == bsize) bsize = std::min(n_ctx, 2 * bsize);
         }
-        hipLaunchKernelGGL(k_apply_pending, grid1, blk, 0, s, g.n, cost, L, w.label, w.cur_cost, w.took, w.flags);
+        hipLaunchKernelGGL(k_apply_pending, grid1, blk, 0, s, g.n, cost, L, w.label, w.cur_cost, w.took, w.flags, 0);
         hipLaunchKernelGGL(k_energy, grid, blk, 0, s, g, potts, w.label, w.cur_cost, w.flags, w.acc);
         stats.launches += 2;
-        RET_IF(fetch(w, stats, s));
+        RET_IF(finish_cycle());
         stats.cycles = cycle;
         if (w.h_flags[C_ERROR]) {
             stats.energy = -(long long)w.h_flags[C_ERROR];
             if (st) *st = stats;
             return w.h_flags[C_ERROR] == ERR_OVERFLOW ? hipErrorInvalidValue : hipErrorLaunchTimeOut;
         }
+        host_tlast = w.h_flags[C_TLAST];
+        host_fresh = true;
         energy = w.h_acc[A_ENERGY];
         if (energy == old_energy) break;               // :1045
     }

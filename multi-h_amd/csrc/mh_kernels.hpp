@@ -207,7 +207,20 @@ struct ExpandWork {         // scratch owned by the engine
     int* comp_out = nullptr;
     int* comp_scratch = nullptr;
     int comp_moves = 0;
+    // r06: concurrent alpha-moves (expand.hip, "batches").  n_ctx >= 2: that many consecutive moves are solved together on
+    // the SAME labeling, each in a context of its own (the fields above are context 0; ctx[k - 1] holds context k), and
+    // committed in order by k_batch_commit, which keeps a move only if it passes a test against what its predecessors in the batch changed.
+    int n_ctx = 1;
+    struct Ctx { int* cap; int* sent; int* excess; int* sink_cap; int* height; int* decided; unsigned char* took; int* core; int* flags; long long* acc; int* took_list; };
+    int* took_list0 = nullptr;    // n   context 0's list of the sites its move takes (the other contexts': Ctx::took_list)
+    Ctx ctx[15] = {};     // EXPAND_MAX_CTX - 1
+    int* bctl = nullptr;          // 8 + EXPAND_MAX_CTX   batch control words (device)
+    int* h_batch = nullptr;       // 8   k_batch_commit's publication, pinned + device-mapped (host address) ...
+    int* h_batch_dev = nullptr;   //     ... and its device address
+    int batch_min_labels = 0;     // batches only when the label set has at least this many labels
 };
+constexpr int EXPAND_MAX_CTX = 16;
+static_assert(sizeof(ExpandWork::ctx) / sizeof(ExpandWork::Ctx) == EXPAND_MAX_CTX - 1, "one context is the work area itself");
 constexpr int EXPAND_FLAG_WORDS = 896;     // device control block (expand.hip)
 constexpr int EXPAND_HOST_WORDS = 32;      // its head, mirrored to the host
 constexpr int EXPAND_ACC_WORDS = 64 + 3 * 64 * 16;   // 16 scalars (mirrored to the host) + three striped sums
@@ -230,6 +243,10 @@ struct ExpandStats {
     double tail_ms;                           // of which: relabel/push rounds that began with fewer than 64 rows still holding excess
     long long tail_rounds;
     double max_barrier_wait_ms;               // longest single wait of the leader workgroup at a grid barrier
+    // r06, concurrent moves: batches launched; moves committed out of a batch (solved beside others, results kept); moves whose
+    // validation against their predecessors' changes failed (re-run alone); moves the HOST did not launch at all because they
+    // were provably idempotent; moves run alone (no batch)
+    long long batches, batch_committed, batch_invalid, host_skipped, solo_moves;
 };
 
 // resident workgroups of the solver launch per CU, as the occupancy query sees k_solve
