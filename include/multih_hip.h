@@ -212,6 +212,11 @@ MH_API int mh_inliers_of_homography(mh_engine* e, const double* H, double thr2, 
  * on the host.  Independent of the resident correspondences. */
 MH_API int mh_compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
                                  const double* H, const unsigned char* ok, int trials, double* stats_out);
+/* r06: the same with the trials' 3-point homographies fitted ON THE DEVICE (GetHomography3PT without refinement, M/MultiH.cpp:154,
+ * :995-1050) from F — until r05 the host fitted the 501 x clusters of them.  Bit-identical to the host's fits
+ * (host/merge_step.cpp, Homography3PTLinear).  H_out (clusters x trials x 9) / ok_out (clusters x trials): nullable, the fits. */
+MH_API int mh_compat_trial_stats_fit(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                              const double F[9], int trials, double* stats_out, double* H_out, unsigned char* ok_out);
 /* ---- multi-GPU transport (one process per GPU, hypotheses sharded, correspondences replicated) ------
  * The reference is a single process; the one exchange north_star adds is an all-gather of per-model inlier scores.
  * The engine calls the transport with DEVICE pointers: send `bytes_per_rank` bytes, receive world * bytes_per_rank in

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mh_get_fund_hypotheses", "mh_score_sampson", "mh_refit_fundamental", "mh_estimate_fundamental", "mh_epipoles", "mh_refine_correspondences", "mh_get_refine_reasons",
     "mh_local_homographies", "mh_mean_shift", "mh_propose_dlt4",
     "mh_set_models", "mh_get_models", "mh_get_model_count", "mh_get_samples", "mh_set_residual_mode", "mh_score",
-    "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_get_score_stats", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_compat_trial_stats", "mh_inlier_moments", "mh_data_cost", "mh_expand",
+    "mh_residual_matrix", "mh_cost_matrix", "mh_get_residual_rows", "mh_set_transport", "mh_select_greedy", "mh_get_score_stats", "mh_prefetch_dlt4", "mh_adopt_prefetched", "mh_select_best", "mh_get_copy_stats", "mh_inliers_of_model", "mh_inliers_of_homography", "mh_compat_trial_stats", "mh_compat_trial_stats_fit", "mh_inlier_moments", "mh_data_cost", "mh_expand",
     "mh_get_expand_stats", "mh_get_expand_batch_stats", "mh_get_expand_trace", "mh_get_core_components", "mh_reestimate", "mh_labeling_step", "mh_device_buffer", "mh_profile_enable", "mh_profile_reset",
     "mh_profile_get", "mh_set_tuning",
 ]
@@ -394,6 +394,21 @@ class Engine:
         self._check(self.lib.mh_compat_trial_stats(self._h, _p(pts, C.c_double), _p(begin, C.c_int), clusters, _p(tri, C.c_int),
                                                    _p(H, C.c_double), _p(ok, C.c_ubyte), trials, _p(out, C.c_double)))
         return out
+
+    def compat_trial_stats_fit(self, pts_xyxy, cluster_begin, tri, F):
+        """mh_compat_trial_stats_fit: the trials' 3-point homographies fitted on the device.  Returns (stats [clusters, trials, 8],
+        H [clusters, trials, 9], ok [clusters, trials])."""
+        pts = _f64(pts_xyxy).reshape(-1, 4)
+        begin = np.ascontiguousarray(cluster_begin, dtype=np.int32)
+        tri = np.ascontiguousarray(tri, dtype=np.int32)
+        clusters, trials = tri.shape[0], tri.shape[1]
+        F = _f64(F).reshape(9)
+        out = np.empty((clusters, trials, 8), dtype=np.float64)
+        H = np.empty((clusters, trials, 9), dtype=np.float64)
+        ok = np.empty((clusters, trials), dtype=np.uint8)
+        self._check(self.lib.mh_compat_trial_stats_fit(self._h, _p(pts, C.c_double), _p(begin, C.c_int), clusters, _p(tri, C.c_int),
+                                                       _p(F, C.c_double), trials, _p(out, C.c_double), _p(H, C.c_double), _p(ok, C.c_ubyte)))
+        return out, H, ok
 
     def expand_stats(self):
         st = (C.c_longlong * 24)()

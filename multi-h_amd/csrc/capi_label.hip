@@ -204,14 +204,15 @@ __global__ void k_shift_labels(int n, const int* in, int delta, int* out)
 
 extern "C" {
 
-int mh_compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
-                          const double* H, const unsigned char* ok, int trials, double* stats_out)
+// H / ok given: the caller fitted the trials' homographies (the form until r05); F given instead: the engine fits them itself
+static int compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                              const double* H, const unsigned char* ok, const double* F, int trials, double* stats_out, double* H_out,
+                              unsigned char* ok_out)
 {
-    return guarded([&]() -> int {
     if (!e) return fail(MH_ERR_INVALID, "null engine");
     if (clusters < 0 || trials < 0) return fail(MH_ERR_INVALID, "negative cluster or trial count");
     if (clusters == 0 || trials == 0) return MH_OK;
-    if (!pts_xyxy || !cluster_begin || !tri || !H || !ok || !stats_out) return fail(MH_ERR_INVALID, "null argument");
+    if (!pts_xyxy || !cluster_begin || !tri || !stats_out || (!F && (!H || !ok))) return fail(MH_ERR_INVALID, "null argument");
     if (cluster_begin[0] != 0) return fail(MH_ERR_INVALID, "cluster_begin[0] must be 0");
     for (int c = 0; c < clusters; ++c)
         if (cluster_begin[c + 1] - cluster_begin[c] < 19)
@@ -229,12 +230,35 @@ int mh_compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* clust
     HIPCHK(hipMemcpyAsync(e->cp_pts.p, pts_xyxy, sizeof(double) * 4 * total, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->cp_begin.p, cluster_begin, sizeof(int) * (clusters + 1), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->cp_tri.p, tri, sizeof(int) * 3 * ct, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->cp_H.p, H, sizeof(double) * 9 * ct, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->cp_ok.p, ok, ct, hipMemcpyHostToDevice, e->stream));
+    if (F) {
+        HIPCHK(launch_compat_fit(e->cp_pts.p, e->cp_begin.p, clusters, e->cp_tri.p, F, trials, e->cp_H.p, e->cp_ok.p, e->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(e->cp_H.p, H, sizeof(double) * 9 * ct, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->cp_ok.p, ok, ct, hipMemcpyHostToDevice, e->stream));
+    }
     HIPCHK(launch_compat_select(e->cp_pts.p, e->cp_begin.p, clusters, e->cp_tri.p, e->cp_H.p, e->cp_ok.p, trials, e->cp_out.p, e->stream));
     HIPCHK(hipMemcpyAsync(stats_out, e->cp_out.p, sizeof(double) * 8 * ct, hipMemcpyDeviceToHost, e->stream));
+    if (H_out) HIPCHK(hipMemcpyAsync(H_out, e->cp_H.p, sizeof(double) * 9 * ct, hipMemcpyDeviceToHost, e->stream));
+    if (ok_out) HIPCHK(hipMemcpyAsync(ok_out, e->cp_ok.p, ct, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return MH_OK;
+}
+
+int mh_compat_trial_stats(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                          const double* H, const unsigned char* ok, int trials, double* stats_out)
+{
+    return guarded([&]() -> int {
+    if (!H || !ok) return fail(MH_ERR_INVALID, "null argument");
+    return compat_trial_stats(e, pts_xyxy, cluster_begin, clusters, tri, H, ok, nullptr, trials, stats_out, nullptr, nullptr);
+    });
+}
+
+int mh_compat_trial_stats_fit(mh_engine* e, const double* pts_xyxy, const int* cluster_begin, int clusters, const int* tri,
+                              const double F[9], int trials, double* stats_out, double* H_out, unsigned char* ok_out)
+{
+    return guarded([&]() -> int {
+    if (!F) return fail(MH_ERR_INVALID, "null argument");
+    return compat_trial_stats(e, pts_xyxy, cluster_begin, clusters, tri, nullptr, nullptr, F, trials, stats_out, H_out, ok_out);
     });
 }
 

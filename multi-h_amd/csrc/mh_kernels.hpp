@@ -63,6 +63,9 @@ hipError_t launch_moments(const Points& p, const double* H, int M, double thr2, 
 hipError_t launch_compat_select(const double* pts /* total x 4 */, const int* begin /* clusters + 1 */, int clusters,
                                 const int* tri /* clusters x trials x 3 */, const double* H /* clusters x trials x 9 */,
                                 const unsigned char* ok, int trials, double* out /* clusters x trials x 8 */, hipStream_t s);
+// the trials' 3-point homographies (GetHomography3PT without refinement, M/MultiH.cpp:154) — H: 9 doubles per (cluster, trial), ok: 1 where finite
+hipError_t launch_compat_fit(const double* pts, const int* begin, int clusters, const int* tri, const double F[9], int trials,
+                             double* H, unsigned char* ok, hipStream_t s);
 
 // --- dlt4.hip ---------------------------------------------------------------
 hipError_t launch_dlt4(const Points& p, unsigned long long seed, long long first, int M,

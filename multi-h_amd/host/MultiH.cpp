@@ -380,19 +380,21 @@ void MultiH::HomographyCompatibilityCheck()
         const double* p = reinterpret_cast<const double*>(cluster_homographies[i].data);
         for (int k = 0; k < 9; ++k) H[9 * (size_t)i + k] = p[k];
     }
-    // the trials' order statistics come from the engine (csrc/compat.hip); the fits, the replay of the draws and the
-    // reference's stale-buffer bookkeeping are host work (merge_step.cpp)
+    // the trials' 3-point fits (r06) and their order statistics come from the engine (csrc/compat.hip); the replay of the draws
+    // and the reference's stale-buffer bookkeeping are host work (merge_step.cpp)
     multih::CompatStatsFn on_engine;
     if (engine)
         on_engine = [this](const double* pts, const int* begin, int clusters, const int* tri, const double* Ht,
                            const unsigned char* ok, int trials, double* out) {
+            if (!Ht) return Check(mh_compat_trial_stats_fit(engine, pts, begin, clusters, tri, fundamental_matrix, trials, out, nullptr, nullptr),
+                                  "mh_compat_trial_stats_fit");
             return Check(mh_compat_trial_stats(engine, pts, begin, clusters, tri, Ht, ok, trials, out), "mh_compat_trial_stats");
         };
     bool failed = false;
     const int kept = multih::CompatibilityCheck(s.data(), d.data(), N, labeling.data(), H.data(), nh,
                                                 fundamental_matrix, sqr_threshold_homography,
                                                 minimum_inlier_number, proposal_seed ^ 0xc0117a7ull, nullptr,
-                                                engine ? &on_engine : nullptr, &failed);
+                                                engine ? &on_engine : nullptr, &failed, engine != nullptr);
     if (failed) { post_filter_failed = true; return; }
     cluster_homographies.clear();
     for (int i = 0; i < kept; ++i) cluster_homographies.push_back(MatFrom9(&H[9 * (size_t)i]));
@@ -909,17 +911,22 @@ int mhh_filter_correspondences(const double* src_xy, const double* dst_xy, int n
 
 // multih::CompatibilityCheck with the trials' order statistics from an engine (mh_compat_trial_stats), as Process() runs
 // it, returning the per-cluster median-of-medians too; -1 if the engine fails.  For the GPU tests.
+static int g_compat_fits_on_engine = 1;           // mhh_compatibility_medians_on_engine: 1 = the fits on the device too (as Process() runs it since r06), 0 = on the host
+extern "C" __attribute__((visibility("default")))
+void mhh_set_compat_fits_on_engine(int on) { g_compat_fits_on_engine = on; }
 extern "C" __attribute__((visibility("default")))
 int mhh_compatibility_medians_on_engine(mh_engine* engine, const double* src_xy, const double* dst_xy, int n, int* labels, double* H,
                                         int nh, const double* F, double sqr_thr, int min_inliers, unsigned long long seed,
                                         double* medians)
 {
-    multih::CompatStatsFn fn = [engine](const double* pts, const int* begin, int clusters, const int* tri, const double* Ht,
-                                        const unsigned char* ok, int trials, double* out) {
+    multih::CompatStatsFn fn = [engine, F](const double* pts, const int* begin, int clusters, const int* tri, const double* Ht,
+                                           const unsigned char* ok, int trials, double* out) {
+        if (!Ht) return mh_compat_trial_stats_fit(engine, pts, begin, clusters, tri, F, trials, out, nullptr, nullptr) == MH_OK;
         return mh_compat_trial_stats(engine, pts, begin, clusters, tri, Ht, ok, trials, out) == MH_OK;
     };
     bool failed = false;
-    const int kept = multih::CompatibilityCheck(src_xy, dst_xy, n, labels, H, nh, F, sqr_thr, min_inliers, seed, medians, &fn, &failed);
+    const int kept = multih::CompatibilityCheck(src_xy, dst_xy, n, labels, H, nh, F, sqr_thr, min_inliers, seed, medians, &fn, &failed,
+                                                g_compat_fits_on_engine != 0);
     return failed ? -1 : kept;
 }
 
@@ -934,10 +941,14 @@ int mhh_run_process(const double* src_xy, const double* dst_xy, const double* af
 {
     std::vector<cv::Point2d> s(n), d(n);
     std::vector<cv::Mat> a(n);
+    // r06: the affinities as NON-owning 2 x 2 headers over one copy of the caller's array (cv::Mat(rows, cols, type, data): the
+    // same with the real library) — 50 000 matrices that each own a 32-byte allocation cost 5 ms to build and to copy, a third
+    // of what this hook reported as "Process()" at configs[4].  The copy outlives the call below.
+    std::vector<double> aff_copy(aff, aff + 4 * (size_t)n);
     for (int i = 0; i < n; ++i) {
         s[i] = cv::Point2d(src_xy[2 * i], src_xy[2 * i + 1]);
         d[i] = cv::Point2d(dst_xy[2 * i], dst_xy[2 * i + 1]);
-        a[i] = OwnedMat(2, 2, aff + 4 * (size_t)i);
+        a[i] = cv::Mat(2, 2, CV_64F, aff_copy.data() + 4 * (size_t)i);
     }
     MultiH mh(thr_F, thr_H, locality, lambda, min_inliers);
     if (F && e2) mh.SetEpipolarGeometry(F, e2);

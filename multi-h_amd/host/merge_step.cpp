@@ -577,7 +577,7 @@ static_assert(sizeof(TrialStats) == 8 * sizeof(double), "the statistics travel a
 
 int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
                        const double F[9], double sqr_thr, int min_inliers, uint64_t seed, double* medians,
-                       const CompatStatsFn* stats_fn, bool* failed)
+                       const CompatStatsFn* stats_fn, bool* failed, bool stats_fn_fits)
 {
     const int trials = 501;                                               // MAX(501, MIN(501, ...)), :128
     if (failed) *failed = false;
@@ -613,21 +613,23 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
         if (stats_fn && *stats_fn) {
             std::vector<int> begin(nb + 1, 0);
             for (int b = 0; b < nb; ++b) begin[b + 1] = begin[b] + (int)(src[big[b]].size() / 2);
-            std::vector<double> pts(4 * (size_t)begin[nb]), Ht(9 * (size_t)nb * trials);
+            std::vector<double> pts(4 * (size_t)begin[nb]), Ht(stats_fn_fits ? 0 : 9 * (size_t)nb * trials);
             std::vector<int> tr(3 * (size_t)nb * trials);
-            std::vector<unsigned char> ok((size_t)nb * trials);
+            std::vector<unsigned char> ok(stats_fn_fits ? 0 : (size_t)nb * trials);
             for (int b = 0; b < nb; ++b) {
                 const std::vector<double>&sx = src[big[b]], &dx = dst[big[b]];
                 double* q = &pts[4 * (size_t)begin[b]];
                 for (size_t i = 0; i < sx.size() / 2; ++i) { q[4 * i] = sx[2 * i]; q[4 * i + 1] = sx[2 * i + 1]; q[4 * i + 2] = dx[2 * i]; q[4 * i + 3] = dx[2 * i + 1]; }
                 std::copy(tri[big[b]].begin(), tri[big[b]].end(), tr.begin() + 3 * (size_t)b * trials);
             }
-            ParallelFor(nb * trials, (size_t)nb * trials * 400, [&](int i) {
-                const int b = i / trials, t = i % trials;
-                ok[i] = TrialHomography(src[big[b]], dst[big[b]], &tri[big[b]][3 * (size_t)t], F, &Ht[9 * (size_t)i]) ? 1 : 0;
-                if (!ok[i]) for (int k = 0; k < 9; ++k) Ht[9 * (size_t)i + k] = 0.0;
-            });
-            if (!(*stats_fn)(pts.data(), begin.data(), nb, tr.data(), Ht.data(), ok.data(), trials, reinterpret_cast<double*>(st.data()))) {
+            if (!stats_fn_fits)
+                ParallelFor(nb * trials, (size_t)nb * trials * 400, [&](int i) {
+                    const int b = i / trials, t = i % trials;
+                    ok[i] = TrialHomography(src[big[b]], dst[big[b]], &tri[big[b]][3 * (size_t)t], F, &Ht[9 * (size_t)i]) ? 1 : 0;
+                    if (!ok[i]) for (int k = 0; k < 9; ++k) Ht[9 * (size_t)i + k] = 0.0;
+                });
+            if (!(*stats_fn)(pts.data(), begin.data(), nb, tr.data(), stats_fn_fits ? nullptr : Ht.data(), stats_fn_fits ? nullptr : ok.data(), trials,
+                             reinterpret_cast<double*>(st.data()))) {
                 if (failed) *failed = true;
                 return nh;
             }

@@ -71,7 +71,10 @@ using CompatStatsFn = std::function<bool(const double* pts_xyxy, const int* clus
 int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* labels, double* H, int nh,
                        const double F[9], double sqr_thr, int min_inliers, uint64_t seed,
                        double* medians = nullptr /* nh, optional: per-cluster median-of-medians */,
-                       const CompatStatsFn* stats_fn = nullptr, bool* failed = nullptr);
+                       const CompatStatsFn* stats_fn = nullptr, bool* failed = nullptr,
+                       // r06: stats_fn fits the trials' 3-point homographies itself (the engine's mh_compat_trial_stats_fit): it is
+                       // called with H = ok = nullptr and the host fits none
+                       bool stats_fn_fits = false);
 
 // The reference's neighbourhood as FLANN's default search answers it (approx_neighbours.cpp): `trees` randomised KD-trees,
 // best-bin-first with `checks` examined points per query, the hits among them within `radius`; pv = n x 4 float32-rounded

@@ -115,6 +115,12 @@ int mh_compat_trial_stats(mh_engine*, const double*, const int*, int clusters, c
     for (long long i = 0; i < 8ll * clusters * trials; ++i) out[i] = 0.0;      // every cluster looks compatible
     return MH_OK;
 }
+int mh_compat_trial_stats_fit(mh_engine*, const double*, const int*, int clusters, const int*, const double*, int trials, double* out, double*,
+                              unsigned char*)
+{
+    for (long long i = 0; i < 8ll * clusters * trials; ++i) out[i] = 0.0;
+    return MH_OK;
+}
 int mh_inlier_moments(mh_engine* e, double, double* mom, double* mineig)
 {
     for (int j = 0; j < e->m; ++j) { for (int q = 0; q < 6; ++q) mom[6 * j + q] = 20.0; mineig[j] = 1.0; }

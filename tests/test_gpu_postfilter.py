@@ -117,3 +117,55 @@ def test_check_with_the_engines_statistics_equals_the_hosts_and_the_oracles(mh, 
     t = ~np.isnan(med_o)
     assert np.array_equal(np.isnan(med_e), ~t) and np.max(np.abs(med_e[t] - med_o[t]) / med_o[t]) <= 1e-6
     assert k_e < planes
+
+
+def test_the_trials_three_point_fits_on_the_device_are_the_hosts_bit_for_bit(mh, engine, synth):
+    """r06: mh_compat_trial_stats_fit fits the trials' homographies on the device (csrc/compat.hip k_compat_fit: GetHomography3PT
+    without refinement, M/MultiH.cpp:154, :995-1050) — until r05 the host did (3.2 of the post-filter's 3.6 ms at configs[4]).
+    Every fit against the host's Homography3PTLinear on the same three correspondences, bit for bit, including degenerate draws
+    (a point drawn twice; three collinear points; coincident points: non-finite fits -> ok = 0, H = 0), and the statistics
+    against the r05 form fed with those fits."""
+    host = C.CDLL(os.path.join(os.path.dirname(mh.LIB_PATH), "libmultih_host.so"))
+    sizes, trials = (40, 700, 2333), 60
+    total = int(sum(sizes))
+    sc = synth.make_scene(4000, 3, seed=23, noise=0.5, outlier_frac=0.2, with_neighbours=False)
+    pts = np.concatenate([sc.src, sc.dst], axis=1)[:total].copy()
+    begin = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rng = np.random.default_rng(8)
+    tri = np.stack([np.stack([rng.choice(sizes[c], 3, replace=False) for _ in range(trials)]) for c in range(len(sizes))]).astype(np.int32)
+    tri[0, 0] = [5, 5, 9]                                        # a point drawn twice
+    tri[1, 1] = [7, 7, 7]                                        # ... three times: no homography
+    pts[begin[2] + 1] = pts[begin[2] + 0]; pts[begin[2] + 2] = pts[begin[2] + 0]; tri[2, 2] = [0, 1, 2]      # three coincident correspondences
+    line = np.linspace(100.0, 300.0, 3)
+    pts[begin[1] + 10:begin[1] + 13, 0] = line; pts[begin[1] + 10:begin[1] + 13, 1] = 2.0 * line + 5.0; tri[1, 3] = [10, 11, 12]   # collinear sources
+    F = np.ascontiguousarray(sc.F)
+    stats, H_dev, ok_dev = engine.compat_trial_stats_fit(pts, begin, tri, F)
+    H_host = np.zeros_like(H_dev)
+    ok_host = np.zeros_like(ok_dev)
+    for c in range(len(sizes)):
+        for t in range(trials):
+            p = pts[begin[c] + tri[c, t]]
+            p1, p2 = np.ascontiguousarray(p[:, :2]), np.ascontiguousarray(p[:, 2:])
+            h = np.zeros(9)
+            with np.errstate(all="ignore"):
+                ok_host[c, t] = host.mhh_homography_3pt(p1.ctypes.data_as(_dp), p2.ctypes.data_as(_dp), 3, F.ctypes.data_as(_dp), h.ctypes.data_as(_dp))
+            H_host[c, t] = h if ok_host[c, t] else 0.0
+    assert np.array_equal(ok_dev, ok_host), f"{int((ok_dev != ok_host).sum())} fits succeed on one side only"
+    assert np.array_equal(H_dev.view(np.uint64), H_host.view(np.uint64)), "a 3-point fit differs in some bit"
+    assert ok_dev.sum() >= ok_dev.size - 6 and (ok_dev == 0).any()
+    want = engine.compat_trial_stats(pts, begin, tri, H_host, ok_host)
+    assert np.array_equal(stats.view(np.uint64), want.view(np.uint64))
+    # the host-fit form of the whole check stays available and equal (mhh_set_compat_fits_on_engine)
+    labels = np.full(sc.n, -1, dtype=np.int32)
+    for c in range(3):
+        labels[np.flatnonzero(sc.gt_label == c)[:600]] = c
+    src, dst = np.ascontiguousarray(sc.src), np.ascontiguousarray(sc.dst)
+    res = []
+    for on in (1, 0):
+        host.mhh_set_compat_fits_on_engine(on)
+        H = sc.H_true.copy(); lab = labels.copy(); med = np.zeros(3)
+        k = host.mhh_compatibility_medians_on_engine(engine._h, src.ctypes.data_as(_dp), dst.ctypes.data_as(_dp), sc.n, lab.ctypes.data_as(C.POINTER(C.c_int)),
+                                                     H.ctypes.data_as(_dp), 3, F.ctypes.data_as(_dp), C.c_double(2.2 ** 2), 20, C.c_ulonglong(77), med.ctypes.data_as(_dp))
+        res.append((k, lab.tobytes(), H.tobytes(), med.tobytes()))
+    host.mhh_set_compat_fits_on_engine(1)
+    assert res[0] == res[1] and res[0][0] == 3
