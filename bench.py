@@ -12,7 +12,7 @@ Two forms of the same step are timed in every run, EXACTLY K steps each, nothing
   sequential  propose, sweep, arg-max one after the other on one stream — the headline at ONE GPU;
   pipelined   the DLT solve of batch i+2 on the engine's second, high-priority stream beside the residual sweep of
               batch i (mh_prefetch_dlt4 / mh_adopt_prefetched) — the headline at SEVERAL GPUs, where a rank's step is 1 ms.
-The residual kernel runs at the board's power cap — its time is its energy (profiles/r03_energy.json) — so a DLT beside
+The residual kernel runs at the board's power cap — its time is its energy (profiles/archive/r03_energy.json) — so a DLT beside
 it is not free: it shows as a longer sweep, and at one GPU the two forms step within 0.1 % of each other.  The
 roofline's launch time is the kernel's in the headline form; the other form is reported as `pipelined_form` /
 `sequential_form`.
@@ -47,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-HBM_WRITE_CEILING_GBPS = 6240.0  # best pure streaming-store kernel on this chip (profiles/r01_store_bw.txt)
+HBM_WRITE_CEILING_GBPS = 6240.0  # best pure streaming-store kernel on this chip (profiles/archive/r01_store_bw.txt)
 
 
 def parse():
@@ -129,9 +129,11 @@ def labeling_extra(mh, eng, a, thr2, lam, legacy=False, plane_separation=None):
     to the REFERENCE's own alpha-expansion (oracle/_ref: GCoptimization + BK compiled unmodified, its
     lazy callback data cost restated) on one host core, same inputs, labels compared.
     Three scenes (r06): the bench's own (planes 13 px apart where they are observed: every move is decided by the dominance
-    reduction, NO max-flow is solved — `moves_solved` 0), an intermediate one (planes 7 px apart: some moves keep an undecided
-    core and go through the solver, GCoptimization.cpp:1212-1274) and the r04 generator's (planes inside each other's
-    truncation threshold: cores of thousands of sites).  Each record says which it is: moves_solved, core_max, barriers."""
+    reduction, NO max-flow is solved — `moves_solved` 0), an intermediate one (planes 2 px apart, inside the truncation
+    threshold of 4.95 px: a quarter of the moves keep an undecided core of a few hundred sites and go through the solver,
+    GCoptimization.cpp:1212-1274; at 4 px and more none does) and the r04 generator's (planes drawn independently: cores of
+    thousands of sites).  Each record says which it is — moves_solved, core_max, barriers — and how the concurrent moves
+    fared (csrc/expand.hip k_batch_commit): batches, moves kept out of them, batches cut short by a failed test."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -151,12 +153,17 @@ def labeling_extra(mh, eng, a, thr2, lam, legacy=False, plane_separation=None):
     lab, energy, cycles = eng.labeling_step(False, np.full(sc.n, -1, np.int32))
     gpu_ms = (time.perf_counter() - t0) * 1e3
     st = eng.expand_stats()
+    bs = eng.expand_batch_stats()
     out = {"scene": ("the r04 generator (planes inside each other's truncation threshold)" if legacy else
                      f"planes {plane_separation if plane_separation is not None else 13.0:g} px apart where they are observed"),
            "sites": sc.n, "labels": H.shape[0] + 1, "neighbour_hits": int(sc.hit_col.size),
            "gpu_labeling_step_ms": gpu_ms, "energy": int(energy), "cycles": int(cycles),
            "moves_run": int(st["moves_run"]), "moves_solved": int(st["moves_solved"]), "core_max": int(st["core_max"]),
-           "barriers": int(st["barriers"]), "solver_ms": st["solve_us"] * 1e-3,
+           "barriers": int(st["barriers"]), "solver_ms": st["solve_us"] * 1e-3, "launches": int(st["launches"]),
+           "concurrent_moves": {"moves_per_batch": int(bs["moves_per_batch"]), "moves": int(st["moves"]), "batches": int(bs["batches"]),
+                                "kept_out_of_batches": int(bs["batch_committed"]), "batches_cut_short_by_a_failed_test": int(bs["batch_invalid"]),
+                                "run_alone": int(bs["solo_moves"]), "never_launched_as_idempotent": int(bs["host_skipped"]),
+                                "validation_hit_rate": (bs["batch_committed"] / max(bs["batch_committed"] + bs["batch_invalid"], 1))},
            "what": ("NO max-flow solved: every move of this step was decided by the dominance reduction (k_move_setup + k_reduce only)"
                     if int(st["moves_solved"]) == 0 else
                     f"{int(st['moves_solved'])} of {int(st['moves_run'])} moves kept an undecided core (at most {int(st['core_max'])} sites) and went through the "
@@ -754,7 +761,7 @@ def main():
             assert np.array_equal(eng.score(thr2), cs), "GPU/oracle score mismatch"
             try:
                 out["labeling"] = labeling_extra(mh, eng, a, thr2, lam)
-                out["labeling_on_the_intermediate_scene"] = labeling_extra(mh, eng, a, thr2, lam, plane_separation=7.0)
+                out["labeling_on_the_intermediate_scene"] = labeling_extra(mh, eng, a, thr2, lam, plane_separation=2.0)
                 out["labeling_on_the_r04_scene"] = labeling_extra(mh, eng, a, thr2, lam, legacy=True)
             except Exception as ex:                      # context only: never lose the headline line
                 out["labeling"] = {"error": repr(ex)}

@@ -58,6 +58,8 @@
 #include "mh_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 
 namespace mh {
 
@@ -1467,30 +1469,38 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
         h_batch[HB_ERROR] = G[C_ERROR];
         h_batch[HB_ACCEPTED_HERE] = s_n_acc;
         h_batch[HB_DIRTY] = 0;
-        h_batch[HB_SEQ] = seq;
+        // the host POLLS the sequence word (run_expansion): everything above is visible to it before the word changes
+        __threadfence_system();
+        __hip_atomic_store(&h_batch[HB_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// The solver's statistics of the contexts beyond 0 into context 0's words (which k_publish mirrors to the host).
+// The solver's statistics of the contexts beyond 0 into context 0's words (which k_publish mirrors to the host).  One thread
+// per word, the contexts in sequence.
 __global__ void k_stats_merge(MoveBatch b)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = threadIdx.x;
     int* G = b.c[0].flags;
     long long* A = b.c[0].acc;
-    for (int k = 1; k < b.count; ++k) {
-        int* f = b.c[k].flags;
-        long long* a = b.c[k].acc;
-        G[C_FLOW_MOVES] += f[C_FLOW_MOVES]; f[C_FLOW_MOVES] = 0;
-        G[C_MOVES_SOLVED] += f[C_MOVES_SOLVED]; f[C_MOVES_SOLVED] = 0;
-        G[C_MOVES_RUN] += f[C_MOVES_RUN]; f[C_MOVES_RUN] = 0;
-        if (f[C_CORE_MAX] > G[C_CORE_MAX]) G[C_CORE_MAX] = f[C_CORE_MAX];
-        if (f[C_XCD_USED] > G[C_XCD_USED]) G[C_XCD_USED] = f[C_XCD_USED];
-        f[C_CORE_MAX] = 0; f[C_XCD_USED] = 0;
-        for (int w = A_CORE_SUM; w < A_COUNT; ++w) {
-            if (w == A_MAX_WAIT) { if (a[w] > A[w]) A[w] = a[w]; }
-            else A[w] += a[w];
+    const int fw[5] = { C_FLOW_MOVES, C_MOVES_SOLVED, C_MOVES_RUN, C_CORE_MAX, C_XCD_USED };
+    if (t < 5) {
+        const int w = fw[t];
+        int v = G[w];
+        for (int k = 1; k < b.count; ++k) {
+            int* f = b.c[k].flags;
+            if (t < 3) v += f[w]; else if (f[w] > v) v = f[w];
+            f[w] = 0;
+        }
+        G[w] = v;
+    } else if (t >= 8 && t - 8 + A_CORE_SUM < A_COUNT) {
+        const int w = t - 8 + A_CORE_SUM;
+        long long v = A[w];
+        for (int k = 1; k < b.count; ++k) {
+            long long* a = b.c[k].acc;
+            if (w == A_MAX_WAIT) { if (a[w] > v) v = a[w]; } else v += a[w];
             a[w] = 0;
         }
+        A[w] = v;
     }
 }
 
@@ -1662,13 +1672,17 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
     // context 0's state between the launches of a move.
     const bool can_batch = n_ctx > 1 && w.bctl && w.h_batch && L >= 2 && !w.comp_out;
     bool batching = can_batch && L >= w.batch_min_labels;       // ... from the first cycle on; smaller label sets from the second (see below)
-    if (can_batch) RET_IF(hipMemsetAsync(w.bctl, 0, sizeof(int) * B_WORDS, s));
+    if (can_batch) {
+        RET_IF(hipMemsetAsync(w.bctl, 0, sizeof(int) * B_WORDS, s));
+        w.h_batch[HB_SEQ] = 0;                          // (no commit of an earlier expansion is in flight: each one ends behind a stream wait)
+    }
     // What the host knows of C_TLAST (the index of the last accepted move): exact right behind a commit or a cycle's end,
     // unknown once a move has been enqueued on its own since.  A move t >= L with TLAST <= t - L is idempotent — the device
     // would return from each of its launches at once (move_is_skipped) — and is not launched at all when the host can tell.
     int host_tlast = -1;
     bool host_fresh = true;
     int bsize = n_ctx;                                  // moves of the next batch: halved when a batch keeps little, doubled when one is kept whole
+    int batch_seq = 0;                                  // batches enqueued = the sequence number the next commit publishes (bctl[B_SEQ] starts at 0)
     int t = 0;
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         old_energy = energy;
@@ -1701,7 +1715,23 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             RET_IF(enqueue_moves(alpha, t, B, cycle));
             ++stats.batches;
             ++stats.host_syncs;
-            RET_IF(hipStreamSynchronize(s));
+            ++batch_seq;
+            // The host needs four words of the commit before it can enqueue the next batch.  Waiting for the stream costs 15-20 us
+            // a time (a thousand times per Process() on the reference's route); the commit writes its words to mapped host memory
+            // and the sequence number last, behind a system-scope fence, so the host polls that word instead — for at most 2 ms
+            // (a batch with large cores), then it waits for the stream as before.  Launches stay ordered by the stream either way.
+            {
+                volatile int* seq_word = w.h_batch + HB_SEQ;
+                const auto t_poll = std::chrono::steady_clock::now();
+                bool seen = false;
+                for (int spin = 0;; ++spin) {
+                    if (*seq_word == batch_seq) { seen = true; break; }
+                    if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(2)) break;
+                }
+                if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+                else RET_IF(hipStreamSynchronize(s));
+                if (w.h_batch[HB_SEQ] != batch_seq) return hipErrorUnknown;           // (cannot happen: the commit always publishes)
+            }
             if (w.h_batch[HB_ERROR]) break;                           // the cycle's end reports it
             const int j = w.h_batch[HB_FIRST_INVALID];
             host_tlast = w.h_batch[HB_TLAST];

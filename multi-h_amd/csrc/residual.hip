@@ -428,7 +428,7 @@ hipError_t launch_residual(const Points& p, const double* H, int M, double thr2,
     // PPL 4, MC 64 (r05; 16 before: same-box A/B 7.21 / 7.11 / 7.06 ms for 16 / 32 / 64 models per work item — the per-tile work is
     // shared by more models), the lean sweep wherever a tile and a model allow it, non-temporal 16-B stores (r03: the kernel runs at
     // the board's power cap, its time is its energy; nt stores — nothing of R is ever re-read — cost 2.7 % less energy
-    // per launch than plain ones, profiles/r03_energy.json)
+    // per launch than plain ones, profiles/archive/r03_energy.json)
     // ... and the nine coefficients of the current model through the scalar unit (s_load from H, uniform address) instead
     // of LDS broadcasts into VGPRs: the twelve linear-form operations then read one operand from SGPRs; 2.5 % less energy.
     if (variant == 0) return launch_rs<4, 64, true, false, true, true, false, true, false, false, true>(p, H, M, thr2, R, ldr, counts, nullptr, s, slices, 0, counts_zeroed, resident_grid, resident_ctl, slice_major);

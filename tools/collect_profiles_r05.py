@@ -49,7 +49,7 @@ if os.path.exists(os.path.join(E, "small_scenes.txt")):
     with open(os.path.join(P, "r05_small_scenes.txt"), "w") as f:
         f.writelines(l[l.index("== N="):] for l in open(os.path.join(E, "small_scenes.txt"), errors="replace") if "== N=" in l)
         f.write(f"source: HEAD {sha}\n")
-COST32_READING = "Reading (VERDICT r04 item 7):\n * The stores are clean: WRITE_SIZE = 1.0002 x the algorithmic 20 GB and 99.99 % of the write requests to the fabric are full 64-B\n   requests — there are no partial-line writes to repair.\n * The resident grid keeps 4 096 waves = 4 per SIMD on the chip.  A wave issues VALU instructions in 22.6 % of its cycles, so a SIMD's VALU\n   pipe is busy 4 x 22.6 % = 0.90 of the time: the kernel is bound by FP32 VALU ISSUE — 23.4 lane-instructions per pair (the cheap\n   test of score32.hip: eight fused multiply-adds, two |.| maxima, two compares, one multiply per pair, plus the cost write-out), 0.57\n   scalar instructions per vector one, 2.3 LDS instructions per pair (the per-model constants, broadcast reads that take no VALU slot).\n   SQ_WAIT_INST_ANY (a wave ready to issue but the pipe taken: 19.9 %) is the same fact seen from the waiting wave.\n * Packing does not help on this chip: v_pk_fma_f32 issues in 4.2 cycles against 2.4 for v_fma_f32 (profiles/r03_valu_cost.txt) — the\n   same flops per cycle.  What would: fewer instructions per pair (none found that keeps the bound rigorous).\n * Launch time 3.7-4.4 ms depending on the box's clock under load (3.73 ms = 0.67 of the HBM peak in profiles/r05_bench.json, 4.35 ms =\n   0.57 on the box of the first r05 session): a VALU-bound kernel follows the shader clock, a store-bound one would not.\nClosed: no further work on k_cost32's stores.\n"
+COST32_READING = "Reading (VERDICT r04 item 7):\n * The stores are clean: WRITE_SIZE = 1.0002 x the algorithmic 20 GB and 99.99 % of the write requests to the fabric are full 64-B\n   requests — there are no partial-line writes to repair.\n * The resident grid keeps 4 096 waves = 4 per SIMD on the chip.  A wave issues VALU instructions in 22.6 % of its cycles, so a SIMD's VALU\n   pipe is busy 4 x 22.6 % = 0.90 of the time: the kernel is bound by FP32 VALU ISSUE — 23.4 lane-instructions per pair (the cheap\n   test of score32.hip: eight fused multiply-adds, two |.| maxima, two compares, one multiply per pair, plus the cost write-out), 0.57\n   scalar instructions per vector one, 2.3 LDS instructions per pair (the per-model constants, broadcast reads that take no VALU slot).\n   SQ_WAIT_INST_ANY (a wave ready to issue but the pipe taken: 19.9 %) is the same fact seen from the waiting wave.\n * Packing does not help on this chip: v_pk_fma_f32 issues in 4.2 cycles against 2.4 for v_fma_f32 (profiles/archive/r03_valu_cost.txt) — the\n   same flops per cycle.  What would: fewer instructions per pair (none found that keeps the bound rigorous).\n * Launch time 3.7-4.4 ms depending on the box's clock under load (3.73 ms = 0.67 of the HBM peak in profiles/r05_bench.json, 4.35 ms =\n   0.57 on the box of the first r05 session): a VALU-bound kernel follows the shader clock, a store-bound one would not.\nClosed: no further work on k_cost32's stores.\n"
 RCCL_HEADER = "The score exchange beside the resident sweep (VERDICT r04 item 4b): rocprofv3 --kernel-trace --memory-copy-trace of tools/shard_proxy.py,\n12 500 hypotheses x 50 000 points per step, the NATIVE transport (libmultih_rccl.so) on a ONE-RANK communicator; three steps of the last phase.\nq2 = the engine's main stream (sweeps), q3 = its second stream (the DLT of the batch after next), q4 = the exchange's stream.\nWhat it shows: with one rank ncclAllGather is a device-to-device COPY kernel (__amd_rocclr_copyBuffer, 5-7 us), not a collective kernel\n(RCCL needs two GPUs for one; no multi-GPU node was available).  It is enqueued behind an event of sweep i, starts 17 us after the sweep\nENDS — not while it runs: what is dispatched while a resident sweep is on the chip waits for its end (DESIGN.md 3.3) — and k_best_fused\nfollows at once; both are over 8 us before sweep i+1 starts, inside the 40 us that separate two sweeps on the main stream anyway.  The\nexchange costs the step nothing; whether a real 8-rank all-gather kernel (50 KB over xGMI) fits the same gap is what no run has shown yet.\n\n"
 with open(os.path.join(P, "r05_cost32_pmc.txt"), "a") as f:
     f.write("\n" + COST32_READING)

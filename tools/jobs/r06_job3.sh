@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python3 -m pytest tests/test_gpu_postfilter.py -x -q -m gpu 2>&1 | grep -v "^\[Multi-H\]" | tail -12
-for i in 1 2; do N=50000 K=10 REPEAT=1 MULTIH_TIMING=1 timeout 600 python3 tools/loop_bench.py 2>&1 | grep -E "done|^N=|Compat|total_s_second" | cut -c1-300 | tail -14; done
+for n in 20000 50000; do
+for k in 4 8 12 16; do
+echo "== N=$n ctx=$k"
+N=$n K=$( [ $n = 20000 ] && echo 6 || echo 10 ) INIT=stable REPEAT=1 TUNE=37=$k timeout 600 python3 tools/loop_bench.py 2>&1 | grep -E "^\{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('loop_s','total_s_second_call')})"
+done; done

@@ -9,7 +9,9 @@ mh = importlib.import_module("multi-h_amd")
 import oracle_lib as O
 N, K = int(os.environ.get("N", 50000)), int(os.environ.get("K", 10))
 # LEGACY=1: the r04 generator (planes inside each other's truncation threshold: the HARD instances of the max-flows)
-t0 = time.time(); sc = mh.synth.make_scene(N, K, seed=1234, legacy_r04=bool(os.environ.get("LEGACY"))); print(f"scene {time.time()-t0:.1f}s ({'r04 generator' if os.environ.get('LEGACY') else 'current generator'}), hits {sc.hit_col.size}")
+# SEPARATION=<px>: planes that far apart where they are observed (default 13; 2: inside the truncation threshold — some moves keep a core)
+kw = {"plane_separation": float(os.environ["SEPARATION"])} if "SEPARATION" in os.environ else {}
+t0 = time.time(); sc = mh.synth.make_scene(N, K, seed=1234, legacy_r04=bool(os.environ.get("LEGACY")), **kw); print(f"scene {time.time()-t0:.1f}s ({'r04 generator' if os.environ.get('LEGACY') else 'current generator'}{', planes ' + os.environ['SEPARATION'] + ' px apart' if kw else ''}), hits {sc.hit_col.size}")
 e = mh.Engine(0, 2.6, 2.2, 0.005, 0.5, 20)
 e.set_correspondences(sc.src, sc.dst, sc.aff); e.set_epipolar(sc.F, sc.e2)
 t0 = time.time(); e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col); print(f"graph upload {time.time()-t0:.2f}s")
@@ -18,9 +20,10 @@ lab = np.full(N, -1, np.int32)
 e.set_models(H)
 if "RECYCLE" in os.environ: e.set_tuning(11, int(os.environ["RECYCLE"]))    # flow recycling off (A/B)
 if "REDUCE" in os.environ: e.set_tuning(6, int(os.environ["REDUCE"]))     # 0 = no dominance reduction (A/B)
+if "CTX" in os.environ: e.set_tuning(37, int(os.environ["CTX"]))         # alpha-moves per batch (1 = one after the other, the form until r05)
 for it in range(int(os.environ.get('STEPS', 3))):
     t0 = time.time(); lab_g, en, cyc = e.labeling_step(it > 0, lab); tg = time.time() - t0
-    print(f"GPU labeling step {it}: {tg*1e3:.1f} ms, energy {int(en)}, cycles {cyc}, stats {e.expand_stats()}")
+    print(f"GPU labeling step {it}: {tg*1e3:.1f} ms, energy {int(en)}, cycles {cyc}, stats {e.expand_stats()}, concurrent moves {e.expand_batch_stats()}")
     if it == 0: lab0, en0 = lab_g.copy(), en
     lab = lab_g
 if os.environ.get("CPU", "1") == "1":
