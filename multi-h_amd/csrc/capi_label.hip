@@ -3,6 +3,17 @@
 
 namespace {
 
+// Contexts of the concurrent alpha-moves (key 37), bounded by what they cost: a context is 2 nnz + 13 n ints, and the complete
+// radius neighbourhood of the reference's rule can hold hundreds of millions of arcs — beyond 8 GiB of contexts fewer moves run
+// together (results never depend on the number).
+int expand_contexts(const mh_engine* e)
+{
+    const int want = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX));
+    const double per_ctx = 4.0 * (2.0 * (double)e->g_nnz + 13.0 * (double)e->n + 2048.0);
+    const int fit = 1 + (int)std::min(64.0, 8.0 * 1024.0 * 1024.0 * 1024.0 / std::max(per_ctx, 1.0));
+    return std::max(1, std::min(want, fit));
+}
+
 int ensure_expand_work(mh_engine* e)
 {
     const int n = e->n, nnz = e->g_nnz;
@@ -29,7 +40,7 @@ int ensure_expand_work(mh_engine* e)
     // r06: the contexts of the concurrent moves (key 37).  Fresh memory is cleared once: a context's capacities and flow counters
     // are read for arcs the current move has not written only together with verdicts that make them irrelevant (expand.hip), but
     // the control words' rings and tickets must start at zero (k_ctl_init) and nothing is gained by leaving the rest to chance.
-    const int extra = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX)) - 1;
+    const int extra = expand_contexts(e) - 1;
     for (int k = 0; k < extra; ++k) {
         const size_t cap_a = e->ewx_arcs[k].cap, cap_s = e->ewx_sites[k].cap, cap_c = e->ewx_core[k].cap, cap_t = e->ewx_took[k].cap;
         HIPCHK(e->ewx_arcs[k].reserve(2 * (size_t)nnz + 2));
@@ -102,7 +113,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
                   e->tune_expand[0], e->tune_expand[1], e->tune_expand[2], solve_grid, e->tune_push_mult, e->tune_reduce, e->tune_reduce_launches,
                   e->tune_cascade_iters, nullptr, 0, -1, nullptr, nullptr };
     // r06: contexts for concurrent moves (expand.hip, k_commit)
-    w.n_ctx = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX));
+    w.n_ctx = expand_contexts(e);
     for (int k = 0; k + 1 < w.n_ctx; ++k) {
         ExpandWork::Ctx& x = w.ctx[k];
         x.cap = e->ewx_arcs[k].p; x.sent = e->ewx_arcs[k].p + ((size_t)g.nnz + 1);
@@ -347,7 +358,7 @@ int mh_get_expand_batch_stats(mh_engine* e, long long stats[8])
     stats[3] = x.host_skipped;
     stats[4] = x.solo_moves;
     stats[5] = 0;
-    stats[6] = std::max(1, std::min(e->tune_expand_ctx, EXPAND_MAX_CTX));
+    stats[6] = expand_contexts(e);
     stats[7] = e->tune_batch_min_labels;
     return MH_OK;
     });

@@ -1,6 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for n in 20000 50000; do
-for k in 4 8 12 16; do
-echo "== N=$n ctx=$k"
-N=$n K=$( [ $n = 20000 ] && echo 6 || echo 10 ) INIT=stable REPEAT=1 TUNE=37=$k timeout 600 python3 tools/loop_bench.py 2>&1 | grep -E "^\{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('loop_s','total_s_second_call')})"
-done; done
+for m in 0 16; do echo "== MINL=$m"; MINL=$m CTX=16 CASES=separated,r04 REPS=5 timeout 600 python3 tools/batch_probe.py 2>&1 | grep -v "^\[Multi-H\]" | tail -5; done
