@@ -51,35 +51,105 @@ void MeanShiftCluster(const double* data, int num_pts, int num_dim, double band_
     uint64_t counter = 0;
     const double band_sq = band_width * band_width;             // MeanShiftClustering.h:31
     const double stop_thresh = 1e-3 * band_width;               // :48
-    std::vector<int> init(num_pts), visited(num_pts, 0);
-    for (int i = 0; i < num_pts; ++i) init[i] = i;
+    // `init` of the reference (:125-130) is the ascending list of the unvisited rows, rebuilt after every climb; a Fenwick tree over
+    // the unvisited flags answers "the k-th unvisited row" without the list (r06; the engine's mh_mean_shift does the same)
+    std::vector<int> visited(num_pts, 0), fen(num_pts + 1, 0);
+    for (int i = 1; i <= num_pts; ++i) { fen[i] += 1; const int j = i + (i & -i); if (j <= num_pts) fen[j] += fen[i]; }
+    int top = 1;
+    while (top * 2 <= num_pts) top *= 2;
+    int unvisited = num_pts;
+    auto kth_unvisited = [&](int k) {                               // 0-based k -> 0-based row
+        int pos = 0, rem = k + 1;
+        for (int step = top; step > 0; step >>= 1)
+            if (pos + step <= num_pts && fen[pos + step] < rem) { pos += step; rem -= fen[pos]; }
+        return pos;
+    };
+    auto mark_visited = [&](int row) {
+        if (visited[row]) return;
+        visited[row] = 1;
+        --unvisited;
+        for (int i = row + 1; i <= num_pts; i += i & -i) fen[i] -= 1;
+    };
     std::vector<std::vector<double>> cent;
-    std::vector<std::vector<int>> votes;
+    // per mode the rows that voted for it and how often (r06: sparse — a mode's climbs touch a handful of the rows); `slot` is the
+    // scratch that finds a row's entry when a later climb is merged into the mode
+    std::vector<std::vector<std::pair<int, int>>> votes;
+    std::vector<int> slot(num_pts, -1);
 
-    while (!init.empty()) {
+    // r06: an index on ONE coordinate.  A climb iteration tests every row against the window sum_j sqrt(r_j^2) < band_sq (:78-85); a
+    // member's every |r_j| is bounded by that sum, so only rows whose coordinate c lies within band_sq (1 + 2^-20) of the mean's can be
+    // members (the slack covers the rounding of r*r and of its root: the computed term is >= |r_c| (1 - 2^-51)).  The rows are sorted on
+    // the coordinate with the widest spread once; an iteration takes the rows of its window, puts them back into ASCENDING ROW ORDER —
+    // the order in which the full scan adds its members up — and applies the reference's own test to them: the same members, the same
+    // sums in the same order, the same bits, without touching the other rows.  (The first MergingStep of the reference's route at
+    // configs[4] shifts 1 564 models: 31 -> 3 ms.)  Non-finite coordinates and windows holding most of the rows fall back to the full scan.
+    int cdim = 0;
+    std::vector<int> perm;                                      // rows in ascending order of coordinate cdim
+    std::vector<double> key;                                    // ... and their coordinate
+    bool indexed = num_pts >= 64 && band_sq > 0.0 && band_sq < 1e299;
+    if (indexed) {
+        double best = -1.0;
+        for (int j = 0; j < num_dim && indexed; ++j) {
+            double lo = data[j], hi = data[j];
+            for (int i = 0; i < num_pts; ++i) {
+                const double x = data[(size_t)i * num_dim + j];
+                if (!(std::fabs(x) < 1e299)) { indexed = false; break; }
+                lo = std::min(lo, x); hi = std::max(hi, x);
+            }
+            if (hi - lo > best) { best = hi - lo; cdim = j; }
+        }
+    }
+    if (indexed) {
+        perm.resize(num_pts);
+        for (int i = 0; i < num_pts; ++i) perm[i] = i;
+        std::sort(perm.begin(), perm.end(), [&](int a, int b) {
+            const double xa = data[(size_t)a * num_dim + cdim], xb = data[(size_t)b * num_dim + cdim];
+            return xa < xb || (xa == xb && a < b);
+        });
+        key.resize(num_pts);
+        for (int i = 0; i < num_pts; ++i) key[i] = data[(size_t)perm[i] * num_dim + cdim];
+    }
+    const double reach = band_sq * (1.0 + 0x1p-20);
+    std::vector<int> cand, touched;                             // rows of the window in row order; rows this climb has voted for
+    std::vector<int> my_votes(num_pts, 0);
+
+    while (unvisited > 0) {
         const double rnd = (double)(splitmix64(seed + counter++) >> 11) * (1.0 / 9007199254740992.0);
-        const int temp = (int)std::round(rnd * (double)(init.size() - 1));   // :55
-        const int st = init[temp];
+        const int temp = (int)std::round(rnd * (double)(unvisited - 1));     // :55
+        const int st = kth_unvisited(temp);
         std::vector<double> mean(data + (size_t)st * num_dim, data + (size_t)(st + 1) * num_dim);
-        std::vector<int> my_votes(num_pts, 0);
+        for (int i : touched) my_votes[i] = 0;
+        touched.clear();
         for (int guard = 0; guard < 100000; ++guard) {
             const std::vector<double> old = mean;
             std::vector<double> acc(num_dim, 0.0);
             int in = 0;
-            for (int i = 0; i < num_pts; ++i) {
+            auto visit = [&](int i) {
                 double dist = 0.0;
                 for (int j = 0; j < num_dim; ++j) {                 // :78-83 (L1 norm via sqrt of square)
                     const double r = old[j] - data[(size_t)i * num_dim + j];
                     dist += std::sqrt(r * r);
                 }
                 if (dist < band_sq) {                                // :85
-                    ++my_votes[i];
+                    if (my_votes[i]++ == 0) touched.push_back(i);
                     ++in;
                     for (int j = 0; j < num_dim; ++j) acc[j] = acc[j] + data[(size_t)i * num_dim + j];
-                    visited[i] = 1;
+                    mark_visited(i);
+                }
+            };
+            bool scanned = false;
+            if (indexed && std::fabs(old[cdim]) < 1e299) {
+                const int lo = (int)(std::lower_bound(key.begin(), key.end(), old[cdim] - reach) - key.begin());
+                const int hi = (int)(std::upper_bound(key.begin(), key.end(), old[cdim] + reach) - key.begin());
+                if (2 * (hi - lo) < num_pts) {
+                    cand.assign(perm.begin() + lo, perm.begin() + hi);
+                    std::sort(cand.begin(), cand.end());
+                    for (int i : cand) visit(i);
+                    scanned = true;
                 }
             }
-            if (in == 0) { mean = old; visited[st] = 1; break; }    // reference: NaN mean, endless loop
+            if (!scanned) for (int i = 0; i < num_pts; ++i) visit(i);
+            if (in == 0) { mean = old; mark_visited(st); break; }   // reference: NaN mean, endless loop
             const double inv = 1.0 / (double)in;                    // cv::Mat / scalar scales by 1/s (:96)
             for (int j = 0; j < num_dim; ++j) mean[j] = acc[j] * inv;
             if (l2(mean, old) < stop_thresh) {                      // :98
@@ -88,22 +158,28 @@ void MeanShiftCluster(const double* data, int num_pts, int num_dim, double band_
                     if (l2(mean, cent[cn]) < band_width / 2) { merge_with = (int)cn; break; }   // :101-109
                 if (merge_with > -1) {
                     for (int j = 0; j < num_dim; ++j) cent[merge_with][j] = 0.5 * (cent[merge_with][j] + mean[j]);
-                    for (int i = 0; i < num_pts; ++i) votes[merge_with][i] += my_votes[i];
+                    std::vector<std::pair<int, int>>& v = votes[merge_with];
+                    for (size_t q = 0; q < v.size(); ++q) slot[v[q].first] = (int)q;
+                    for (int i : touched) {
+                        if (slot[i] >= 0) v[slot[i]].second += my_votes[i];
+                        else v.emplace_back(i, my_votes[i]);
+                    }
+                    for (const auto& e : v) slot[e.first] = -1;
                 } else {
                     cent.push_back(mean);
-                    votes.push_back(my_votes);
+                    votes.emplace_back();
+                    for (int i : touched) votes.back().emplace_back(i, my_votes[i]);
                 }
                 break;
             }
         }
-        init.clear();                                               // :125-130
-        for (int i = 0; i < num_pts; ++i) if (!visited[i]) init.push_back(i);
     }
 
-    std::vector<int> best_votes(num_pts, 0), best_idx(num_pts, -1);  // :133-146
+    // :133-146: a row belongs to the mode that voted for it most often, the FIRST such mode on ties (strict <, modes in order)
+    std::vector<int> best_votes(num_pts, 0), best_idx(num_pts, -1);
     for (size_t r = 0; r < votes.size(); ++r)
-        for (int i = 0; i < num_pts; ++i)
-            if (best_votes[i] < votes[r][i]) { best_votes[i] = votes[r][i]; best_idx[i] = (int)r; }
+        for (const auto& e : votes[r])
+            if (best_votes[e.first] < e.second) { best_votes[e.first] = e.second; best_idx[e.first] = (int)r; }
     out.members.assign(cent.size(), {});
     for (int i = 0; i < num_pts; ++i) if (best_idx[i] >= 0) out.members[best_idx[i]].push_back(i);
     for (auto& c : cent) out.modes.insert(out.modes.end(), c.begin(), c.end());

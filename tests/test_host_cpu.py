@@ -94,6 +94,31 @@ def test_mean_shift_matches_numpy_restatement(host, seed):
         assert len(set(assign[12 * j: 12 * (j + 1)])) == 1
 
 
+@pytest.mark.parametrize("seed,n_clusters,per,strays", [(4, 9, 30, 40), (5, 3, 120, 10), (6, 40, 8, 30)])
+def test_mean_shift_through_its_index_matches_the_full_scan(host, seed, n_clusters, per, strays):
+    """r06: from 64 rows on the host's mean shift takes the rows of a window on one coordinate (sorted once), puts them back
+    into row order and applies the reference's own test to them, picks its seeds through a Fenwick tree over the unvisited
+    rows and keeps the votes sparse.  Same modes, same assignment (ties included: duplicated rows), same number of draws as
+    the plain restatement above, which scans every row in every iteration."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-80, 80, size=(n_clusters, 6))
+    data = np.concatenate([c + rng.normal(0, 0.2, size=(per, 6)) for c in centres] + [rng.uniform(-80, 80, size=(strays, 6))])
+    data[5] = data[4]; data[per + 1] = data[per]                     # duplicated rows: equal votes, the first mode wins
+    data = np.ascontiguousarray(data[rng.permutation(len(data))])
+    n = data.shape[0]
+    assert n >= 64
+    modes = np.zeros((n, 6))
+    assign = np.zeros(n, dtype=np.int32)
+    draws = C.c_ulonglong(0)
+    k = host.mhh_mean_shift(data.ctypes.data_as(_dp), n, 6, C.c_double(2.2), C.c_ulonglong(seed),
+                            modes.ctypes.data_as(_dp), n, assign.ctypes.data_as(C.POINTER(C.c_int)), C.byref(draws))
+    cent, best_i, c = np_mean_shift(data, 2.2, seed)
+    assert k == len(cent) and draws.value == c
+    assert np.allclose(modes[:k], cent, rtol=0, atol=1e-12)
+    assert np.array_equal(assign, best_i)
+    assert k < n - strays, "the clusters should merge into modes"
+
+
 def test_homography_features(host):
     rng = np.random.default_rng(0)
     H = rng.normal(size=(5, 9))

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for m in 0 16; do echo "== MINL=$m"; MINL=$m CTX=16 CASES=separated,r04 REPS=5 timeout 600 python3 tools/batch_probe.py 2>&1 | grep -v "^\[Multi-H\]" | tail -5; done
+for n in 20000 50000; do
+N=$n K=$( [ $n = 20000 ] && echo 6 || echo 10 ) INIT=stable REPEAT=1 timeout 600 python3 tools/loop_bench.py 2>&1 | grep -E "^\{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print($n, {k:d[k] for k in ('loop_s','total_s_second_call','digest')})"
+done
