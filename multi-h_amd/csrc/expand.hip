@@ -108,6 +108,7 @@ struct MoveBatch { MoveCtx c[EXPAND_MAX_CTX]; int count; };
 // batch control words (device) and what k_commit publishes to the host
 enum { B_TLAST0 = 0,       // index of the last accepted move when the batch began (what its moves' skip tests saw)
        B_SEQ = 1,
+       B_TICKET = 2,       // workgroups of the running k_batch_commit that have finished
        B_BAD = 8,          // EXPAND_MAX_CTX words: bit k of word j = move k of the batch fails its test against what move j changes
        B_WORDS = 8 + EXPAND_MAX_CTX };
 static_assert(EXPAND_MAX_CTX <= 32, "one bit per move of a batch");
@@ -1417,9 +1418,10 @@ k_batch_check(Graph g, const int* __restrict__ cost, int L, int potts, const int
 // ... then the commit, in the reference's order (see above): every workgroup derives the same decisions from the same words —
 // none of which this launch writes — and applies its share of the accepted moves' took lists (applyNewLabeling, :423-441);
 // workgroup 0 records them in the global control words and publishes to the host.
+struct CtxFlags { int* p[EXPAND_MAX_CTX]; };       // the control words of ALL contexts of the engine (a batch may use fewer)
 __global__ void __launch_bounds__(256)
 k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int* __restrict__ cur_cost, MoveBatch b,
-               int* __restrict__ bctl, int* __restrict__ h_batch)
+               int* __restrict__ bctl, int* __restrict__ h_batch, CtxFlags all_flags, int n_ctx_all)
 {
     __shared__ int s_first, s_err, s_last_t, s_n_acc;
     __shared__ unsigned s_acc;
@@ -1456,7 +1458,17 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
             cur_cost[p] = cost[(size_t)p * L + a];
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // The global control words, the publication and the next batch's preparation are the LAST workgroup's to write: every workgroup
+    // has derived its decisions from those words and must have finished reading them.
+    __shared__ int s_is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_is_last = atomicAdd(&bctl[B_TICKET], 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_is_last && threadIdx.x == 0) {
+        bctl[B_TICKET] = 0;
         int* G = b.c[0].flags;
         if (s_err && !G[C_ERROR]) G[C_ERROR] = s_err;
         // (context 0's k_delta wrote the global words for its own move itself: count the others)
@@ -1469,9 +1481,21 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
         h_batch[HB_ERROR] = G[C_ERROR];
         h_batch[HB_ACCEPTED_HERE] = s_n_acc;
         h_batch[HB_DIRTY] = 0;
-        // the host POLLS the sequence word (run_expansion): everything above is visible to it before the word changes
+        // the host POLLS the sequence word (run_expansion): everything above — and every label the other workgroups wrote, which
+        // their fences ordered before their tickets — is visible to it before the word changes
         __threadfence_system();
         __hip_atomic_store(&h_batch[HB_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... and what k_batch_prep would do in front of the NEXT batch, whatever that batch will hold (every context, not just the
+        // ones it uses): a batch that follows a commit directly needs no launch of its own for it
+        bctl[B_TLAST0] = G[C_TLAST];
+        G[C_PEND] = -1;
+        for (int k = 0; k < EXPAND_MAX_CTX; ++k) bctl[B_BAD + k] = 0;
+        for (int k = 1; k < n_ctx_all; ++k) {
+            int* f = all_flags.p[k];
+            f[C_TLAST] = G[C_TLAST];
+            f[C_PEND] = -1;
+            f[C_ERROR] = G[C_ERROR];
+        }
     }
 }
 
@@ -1633,6 +1657,9 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 
     // The launches of `count` consecutive moves (labels alpha0 ..., move indices t0 ...) solved on the same labeling, contexts
     // 0 .. count - 1.  count == 1: a move alone, the sequential form.
+    CtxFlags all_flags{};
+    for (int k = 0; k < n_ctx; ++k) all_flags.p[k] = all.c[k].flags;
+    bool prepared = false;       // the contexts beyond 0 hold the global control words as they stand (nothing but batches has run since)
     auto enqueue_moves = [&](int alpha0, int t0, int count, int cycle) -> hipError_t {
         MoveBatch b = all;
         b.count = count;
@@ -1648,7 +1675,9 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             if (count == 1) c.took_list = nullptr;             // a move alone: nobody walks the list
         }
         const dim3 grid_w(wblocks, (unsigned)count);
-        if (count > 1) { hipLaunchKernelGGL(k_batch_prep, dim3(1), dim3(64), 0, s, b, w.bctl); ++stats.launches; }
+        // (a batch right behind another batch's commit finds the contexts prepared by that commit)
+        if (count > 1 && !prepared) { hipLaunchKernelGGL(k_batch_prep, dim3(1), dim3(64), 0, s, b, w.bctl); ++stats.launches; }
+        prepared = count > 1;
         hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, w.reduce_rounds > 0 ? 1 : 0, w.label, w.cur_cost, b);
         if (w.reduce_launches > 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, 1);
@@ -1660,7 +1689,7 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
         hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b);
         if (count > 1) {
             hipLaunchKernelGGL(k_batch_check, dim3(32, (unsigned)count), blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b, w.bctl);
-            hipLaunchKernelGGL(k_batch_commit, dim3(32), blk, 0, s, cost, L, w.label, w.cur_cost, b, w.bctl, w.h_batch_dev);
+            hipLaunchKernelGGL(k_batch_commit, dim3(32), blk, 0, s, cost, L, w.label, w.cur_cost, b, w.bctl, w.h_batch_dev, all_flags, n_ctx);
             stats.launches += 2;
         }
         stats.launches += w.reduce_launches > 1 ? 5 : 4;
