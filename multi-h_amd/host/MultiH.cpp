@@ -484,18 +484,17 @@ bool MultiH::EstablishStablePointSets()
     const double ms_shift = ms_since(t0) - ms_local;
     std::vector<std::vector<int>> members(k);
     for (int i = 0; i < N; ++i) if (assign[i] >= 0) members[assign[i]].push_back(i);
-    for (int c = 0; c < k; ++c) {
-        const int ni = static_cast<int>(members[c].size());
-        if (ni < 3) continue;                                                             // :667
-        std::vector<double> p1(2 * (size_t)ni), p2(2 * (size_t)ni);
-        for (int j = 0; j < ni; ++j) {
-            const int idx = members[c][j];
-            p1[2 * j] = src_points[idx].x; p1[2 * j + 1] = src_points[idx].y;
-            p2[2 * j] = dst_points[idx].x; p2[2 * j + 1] = dst_points[idx].y;
+    {
+        // one 3-point fit with LM per cluster of at least three points (:664-688), on the host's cores (r06), taken in cluster order
+        std::vector<double> sxy(2 * (size_t)N), dxy(2 * (size_t)N), Hc;
+        std::vector<unsigned char> okc;
+        for (int i = 0; i < N; ++i) {
+            sxy[2 * (size_t)i] = src_points[i].x; sxy[2 * (size_t)i + 1] = src_points[i].y;
+            dxy[2 * (size_t)i] = dst_points[i].x; dxy[2 * (size_t)i + 1] = dst_points[i].y;
         }
-        double H[9];
-        if (multih::Homography3PT(p1.data(), p2.data(), ni, fundamental_matrix, H, true))  // :685
-            cluster_homographies.push_back(MatFrom9(H));
+        multih::Homography3PTClusters(sxy.data(), dxy.data(), members, fundamental_matrix, Hc, okc);
+        for (int c = 0; c < k; ++c)
+            if (okc[c]) cluster_homographies.push_back(MatFrom9(&Hc[9 * (size_t)c]));
     }
     if (timing)
         printf("[Multi-H] stable sets: per-point homographies %.2f ms, mean shift %.2f ms (%d modes), 3-point fits %.2f ms\n",

@@ -740,6 +740,27 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
     return kept;
 }
 
+void Homography3PTClusters(const double* src_xy, const double* dst_xy, const std::vector<std::vector<int>>& members, const double F[9],
+                           std::vector<double>& H, std::vector<unsigned char>& ok)
+{
+    const int k = (int)members.size();
+    H.assign(9 * (size_t)k, 0.0);
+    ok.assign((size_t)k, 0);
+    size_t cost = 0;
+    for (const auto& m : members) if (m.size() >= 3) cost += 600 + 40 * m.size();
+    ParallelFor(k, cost, [&](int c) {
+        const int ni = (int)members[c].size();
+        if (ni < 3) return;                                                                 // :667
+        std::vector<double> p1(2 * (size_t)ni), p2(2 * (size_t)ni);
+        for (int j = 0; j < ni; ++j) {
+            const int idx = members[c][j];
+            p1[2 * j] = src_xy[2 * (size_t)idx]; p1[2 * j + 1] = src_xy[2 * (size_t)idx + 1];
+            p2[2 * j] = dst_xy[2 * (size_t)idx]; p2[2 * j + 1] = dst_xy[2 * (size_t)idx + 1];
+        }
+        ok[c] = Homography3PT(p1.data(), p2.data(), ni, F, &H[9 * (size_t)c], true) ? 1 : 0;  // :685
+    });
+}
+
 int MergeCandidates(const double* H, int nh, const double F[9], double thr_h, uint64_t seed, std::vector<double>* feat_out,
                     std::vector<double>* modes_out, std::vector<double>& cand, std::vector<int>* cand_mode, uint64_t* draws)
 {

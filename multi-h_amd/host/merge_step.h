@@ -76,6 +76,13 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
                        // called with H = ok = nullptr and the host fits none
                        bool stats_fn_fits = false);
 
+// r06: one 3-point least-squares homography with LM refinement per cluster of at least three members (EstablishStablePointSets,
+// M/MultiH.cpp:664-688), the clusters spread over the host's cores (each fit is independent; the results are taken in cluster
+// order, so nothing depends on the number of threads).  H: 9 doubles per cluster; ok: 1 where the cluster had >= 3 members and its
+// fit is finite.
+void Homography3PTClusters(const double* src_xy, const double* dst_xy, const std::vector<std::vector<int>>& members, const double F[9],
+                           std::vector<double>& H, std::vector<unsigned char>& ok);
+
 // The reference's neighbourhood as FLANN's default search answers it (approx_neighbours.cpp): `trees` randomised KD-trees,
 // best-bin-first with `checks` examined points per query, the hits among them within `radius`; pv = n x 4 float32-rounded
 // (x1, y1, x2, y2) as doubles.
