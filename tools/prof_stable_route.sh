@@ -1,3 +1,4 @@
+# rocprofv3 kernel stats of Process() by the reference's own route (tools/loop_bench.py INIT=stable) at 20 000 points; runs on the GPU box.
 export TMPDIR=/tmp
 cd /tmp && N=20000 K=6 HYP=50000 INIT=stable rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stable -- python3 $GRAFT_REPO_ROOT/tools/loop_bench.py > /tmp/prof_stable.log 2>&1
 cd $GRAFT_REPO_ROOT
