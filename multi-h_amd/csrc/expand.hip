@@ -1425,13 +1425,30 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
 {
     __shared__ int s_first, s_err, s_last_t, s_n_acc;
     __shared__ unsigned s_acc;
+    // the words the walk below looks at, fetched by one lane per move (the walk itself is sequential: on one lane's own loads it
+    // cost a memory round trip per move and word, 12 us for sixteen moves)
+    __shared__ int s_ek[EXPAND_MAX_CTX], s_pend[EXPAND_MAX_CTX], s_nt[EXPAND_MAX_CTX];
+    __shared__ unsigned s_bad[EXPAND_MAX_CTX];
+    __shared__ int s_g[5];                               // B_TLAST0, the global C_ERROR / C_TLAST / C_ACCEPTED, B_SEQ: written by this launch's LAST workgroup only
+    if ((int)threadIdx.x < b.count) {
+        const int* f = b.c[threadIdx.x].flags;
+        s_ek[threadIdx.x] = f[C_ERROR];
+        s_pend[threadIdx.x] = f[C_PEND];
+        s_nt[threadIdx.x] = f[C_TOOK_N];
+        s_bad[threadIdx.x] = (unsigned)bctl[B_BAD + threadIdx.x];
+    } else if (threadIdx.x >= 64 && threadIdx.x < 69) {
+        const int q = threadIdx.x - 64;
+        const int* G = b.c[0].flags;
+        s_g[q] = q == 0 ? bctl[B_TLAST0] : q == 1 ? G[C_ERROR] : q == 2 ? G[C_TLAST] : q == 3 ? G[C_ACCEPTED] : bctl[B_SEQ];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const int tlast0 = bctl[B_TLAST0];
+        const int tlast0 = s_g[0];
         unsigned accepted = 0;
         int first_invalid = b.count, err = 0, last_t = -1, n_acc = 0;
         for (int k = 0; k < b.count; ++k) {
             const MoveCtx& c = b.c[k];
-            const int ek = c.flags[C_ERROR];
+            const int ek = s_ek[k];
             if (ek) err = ek;
             const bool skipped = ek != 0 || (c.t >= L && tlast0 <= c.t - L);
             bool valid = true;
@@ -1439,10 +1456,10 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
                 if (skipped) valid = false;                  // no longer idempotent: something in front of it changed the labeling
                 else
                     for (int j = 0; j < k; ++j)
-                        if ((accepted >> j & 1u) && ((unsigned)bctl[B_BAD + j] >> k & 1u)) valid = false;
+                        if ((accepted >> j & 1u) && (s_bad[j] >> k & 1u)) valid = false;
             }
             if (!valid) { first_invalid = k; break; }
-            if (!skipped && c.flags[C_PEND] >= 0) { accepted |= 1u << k; last_t = c.t; ++n_acc; }
+            if (!skipped && s_pend[k] >= 0) { accepted |= 1u << k; last_t = c.t; ++n_acc; }
         }
         s_first = first_invalid; s_err = err; s_acc = accepted; s_last_t = last_t; s_n_acc = n_acc;
     }
@@ -1451,7 +1468,7 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
     for (int k = 0; k < b.count; ++k) {
         if (!(accepted >> k & 1u)) continue;
         const MoveCtx& c = b.c[k];
-        const int nt = c.flags[C_TOOK_N], a = c.alpha;
+        const int nt = s_nt[k], a = c.alpha;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gridDim.x * 256) {
             const int p = c.took_list[i];
             label[p] = a;
@@ -1470,15 +1487,18 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
     if (s_is_last && threadIdx.x == 0) {
         bctl[B_TICKET] = 0;
         int* G = b.c[0].flags;
-        if (s_err && !G[C_ERROR]) G[C_ERROR] = s_err;
+        // (the global words as they stood when the launch began — nobody but this thread writes them in it)
+        const int g_err = s_g[1] ? s_g[1] : s_err;
         // (context 0's k_delta wrote the global words for its own move itself: count the others)
-        if (s_last_t > G[C_TLAST]) G[C_TLAST] = s_last_t;
-        G[C_ACCEPTED] += s_n_acc - (int)(accepted & 1u);
-        const int seq = bctl[B_SEQ] + 1;
+        const int g_tlast = s_last_t > s_g[2] ? s_last_t : s_g[2];
+        const int seq = s_g[4] + 1;
+        if (g_err != s_g[1]) G[C_ERROR] = g_err;
+        if (g_tlast != s_g[2]) G[C_TLAST] = g_tlast;
+        G[C_ACCEPTED] = s_g[3] + s_n_acc - (int)(accepted & 1u);
         bctl[B_SEQ] = seq;
         h_batch[HB_FIRST_INVALID] = s_first;
-        h_batch[HB_TLAST] = G[C_TLAST];
-        h_batch[HB_ERROR] = G[C_ERROR];
+        h_batch[HB_TLAST] = g_tlast;
+        h_batch[HB_ERROR] = g_err;
         h_batch[HB_ACCEPTED_HERE] = s_n_acc;
         h_batch[HB_DIRTY] = 0;
         // the host POLLS the sequence word (run_expansion): everything above — and every label the other workgroups wrote, which
@@ -1487,14 +1507,14 @@ k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int
         __hip_atomic_store(&h_batch[HB_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // ... and what k_batch_prep would do in front of the NEXT batch, whatever that batch will hold (every context, not just the
         // ones it uses): a batch that follows a commit directly needs no launch of its own for it
-        bctl[B_TLAST0] = G[C_TLAST];
+        bctl[B_TLAST0] = g_tlast;
         G[C_PEND] = -1;
         for (int k = 0; k < EXPAND_MAX_CTX; ++k) bctl[B_BAD + k] = 0;
         for (int k = 1; k < n_ctx_all; ++k) {
             int* f = all_flags.p[k];
-            f[C_TLAST] = G[C_TLAST];
+            f[C_TLAST] = g_tlast;
             f[C_PEND] = -1;
-            f[C_ERROR] = G[C_ERROR];
+            f[C_ERROR] = g_err;
         }
     }
 }
