@@ -658,6 +658,11 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
     const int trials = 501;                                               // MAX(501, MIN(501, ...)), :128
     if (failed) *failed = false;
     std::vector<std::vector<double>> src(nh), dst(nh);
+    {
+        std::vector<int> count(nh, 0);
+        for (int i = 0; i < n; ++i) if (labels[i] > -1 && labels[i] < nh) ++count[labels[i]];
+        for (int c = 0; c < nh; ++c) { src[c].reserve(2 * (size_t)count[c]); dst[c].reserve(2 * (size_t)count[c]); }
+    }
     for (int i = 0; i < n; ++i) {
         const int l = labels[i];
         if (l > -1 && l < nh) {
@@ -667,21 +672,32 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
     }
     std::vector<char> remove(nh, 0), has_median(nh, 0);
     std::vector<double> median(nh, std::nan(""));
-    // (1) the draws of every cluster that gets a median, in cluster order (one RNG counter runs through them)
+    // (1) the draws of every cluster that gets a median, in cluster order: one RNG counter runs through them, and every such
+    // cluster takes exactly 3 * trials draws, so a cluster's first counter is known up front and the replays run side by side
     std::vector<std::vector<int>> tri(nh);
     std::vector<int> big;                                                 // clusters whose trials go through the order statistics
-    uint64_t counter = 0;
+    std::vector<int> drawn;                                               // clusters that get a median, in order
+    std::vector<uint64_t> first_counter;
+    size_t replay_cost = 0;
     for (int c = 0; c < nh; ++c) {
         const int N = (int)(src[c].size() / 2);
         if (N >= std::max(min_inliers, 4)) {
-            tri[c] = ReplayDraws(N, trials, seed, counter);
+            first_counter.push_back(3 * (uint64_t)trials * drawn.size());
+            drawn.push_back(c);
             has_median[c] = 1;
-            if (N - 3 < 16) median[c] = TinyClusterMedian(src[c], dst[c], tri[c], F, trials);
-            else big.push_back(c);
+            if (N - 3 >= 16) big.push_back(c);
+            replay_cost += 8 * (size_t)N + 180 * (size_t)trials + (N - 3 < 16 ? 600 * (size_t)trials : 0);
         } else if (N < min_inliers) {
             remove[c] = 1;                                                // :199-200
         }
     }
+    ParallelFor((int)drawn.size(), replay_cost, [&](int q) {
+        const int c = drawn[q];
+        const int N = (int)(src[c].size() / 2);
+        uint64_t counter = first_counter[q];
+        tri[c] = ReplayDraws(N, trials, seed, counter);
+        if (N - 3 < 16) median[c] = TinyClusterMedian(src[c], dst[c], tri[c], F, trials);
+    });
     // (2) per trial, independent of each other: the 3-point fit, then the order statistics of its distances
     if (!big.empty()) {
         const int nb = (int)big.size();
@@ -720,8 +736,9 @@ int CompatibilityCheck(const double* src_xy, const double* dst_xy, int n, int* l
                 TrialSelect(buf, st[i]);
             });
         }
-        for (int b = 0; b < nb; ++b)
+        ParallelFor(nb, (size_t)nb * trials * 150, [&](int b) {
             median[big[b]] = MedianFromStats(&st[(size_t)b * trials], (int)(src[big[b]].size() / 2) - 3, trials);
+        });
     }
     for (int c = 0; c < nh; ++c) {
         if (medians) medians[c] = median[c];
