@@ -1416,8 +1416,9 @@ k_batch_check(Graph g, const int* __restrict__ cost, int L, int potts, const int
 }
 
 // ... then the commit, in the reference's order (see above): every workgroup derives the same decisions from the same words —
-// none of which this launch writes — and applies its share of the accepted moves' took lists (applyNewLabeling, :423-441);
-// workgroup 0 records them in the global control words and publishes to the host.
+// none of which is written before all workgroups have read them — and applies its share of the accepted moves' took lists
+// (applyNewLabeling, :423-441); the LAST workgroup to finish records the outcome in the global control words, publishes it to the
+// host and prepares the contexts for the next batch.
 struct CtxFlags { int* p[EXPAND_MAX_CTX]; };       // the control words of ALL contexts of the engine (a batch may use fewer)
 __global__ void __launch_bounds__(256)
 k_batch_commit(const int* __restrict__ cost, int L, int* __restrict__ label, int* __restrict__ cur_cost, MoveBatch b,
