@@ -401,6 +401,8 @@ MH_API int mh_profile_get(mh_engine* e, int kernel, int* launches, double* total
  *                     validated against what its predecessors changed (1: one move after the other, the form until r05) — same labels,
  *                     energies and cycle counts
  *  38   S     16      ... from the first cycle on for label sets of at least this many labels (smaller sets from the second cycle)
+ *  39   S     0       ... sites per wavefront in the setup and reduction launches of a batch of moves: 16 / 32 / 64, 0 = by the size of the
+ *                     launch (moves x sites); a move alone takes 16, a batch's energy-difference launch 64
  * (34 and 35 are not assigned.) */
 MH_API int mh_set_tuning(mh_engine* e, int key, int value);
 

@@ -766,6 +766,7 @@ int mh_set_tuning(mh_engine* e, int key, int value)
     if (key == 32 && (value == 0 || value == 1)) { e->tune_ms_indexed = value; return MH_OK; }     // mean shift: indexed climbs (1, default) or the launched / persistent schedule (0): same modes
     if (key == 37 && value >= 1 && value <= EXPAND_MAX_CTX) { e->tune_expand_ctx = value; return MH_OK; }     // alpha-moves solved together (1: one after the other) — schedule only
     if (key == 38 && value >= 0 && value <= (1 << 20)) { e->tune_batch_min_labels = value; return MH_OK; }    // ... from the first cycle on for label sets of at least this many labels
+    if (key == 39 && (value == 0 || value == 16 || value == 32 || value == 64)) { e->tune_batch_spw = value; return MH_OK; }    // sites per wave in a batch's setup and reduction launches, 0 = by size (schedule only)
     if (key == 36 && (value == 0 || value == 1)) { e->tune_select_decrement = value; return MH_OK; }     // greedy selection: decremental rounds (1, default) — schedule only
     if (key == 33 && value >= 0 && value <= (1 << 20)) { e->tune_ms_dense = value; return MH_OK; }     // ... and the member count beyond which an indexed climb is handed on
     // key 30 CHANGES RESULTS (the one such key the product library accepts): every winner of mh_select_greedy is refitted to its

@@ -196,6 +196,7 @@ struct mh_engine {
     int* h_batch_dev = nullptr;
     int tune_expand_ctx = 16;                // key 37: alpha-moves solved together (1 = one after the other, the form until r05)
     int tune_batch_min_labels = 16;          // key 38: label sets of at least this many labels are batched from the first cycle on (smaller ones from the second)
+    int tune_batch_spw = 0;                  // key 39: sites per wave in the setup and reduction launches of a batch of moves (16 / 32 / 64; 0 = by the size of the launch); schedule only
     int cu_count = 256;
     DevBuf<int> sweep_ctl;                   // work counter + exit counter of the resident sweep (cleared by the launch itself)
     int sweep_wg_per_cu = -1;                // workgroups of the materialising sweep a compute unit holds (-1 = not queried yet)

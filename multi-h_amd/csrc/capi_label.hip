@@ -126,6 +126,7 @@ int do_expand(mh_engine* e, const int* init_dev, long long* energy, int* cycles)
         w.h_batch = e->h_batch; w.h_batch_dev = e->h_batch_dev;
         w.took_list0 = e->ew_took_list.p;
         w.batch_min_labels = e->tune_batch_min_labels;
+        w.batch_spw = e->tune_batch_spw;
     }
     // flow recycling (expand.hip, k_solve): L x (nnz + n) ints, cleared per expansion; left out (every move starts from
     // the zero flow) beyond 8 GiB.  Flows are not kept from one call to the next: measured in the alternation, the

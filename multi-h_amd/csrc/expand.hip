@@ -255,14 +255,18 @@ __device__ __forceinline__ void for_flagged(unsigned long long mask, F body)
 // Sites per wavefront in step one.  64 would use every lane, but then a 50k-site graph is 782 waves — less than one
 // per SIMD — and a wave with many flagged sites serves them one group of four after the other (k_reduce at 11 labels:
 // 27 us against 16 us for the plain LPN-lanes-per-site mapping).  16 keeps 3 125 waves and at most four rounds.
-constexpr int SPW = 16;
-constexpr int SITES_PER_WBLOCK = 4 * SPW;      // per 256-thread workgroup
+// r06: with several moves per launch (context = blockIdx.y) the launch has that many times the waves, and 16 sites per wave
+// leave it with several rounds of residency, each paying the kernel's chain of dependent loads: `spw` is a launch argument,
+// 64 for a batch's k_delta (few sites move), 16 / 32 / 64 by the size of the launch for its setup and reduction (run_expansion).
+constexpr int SPW = 16;                         // a move alone
+constexpr int SPW_MAX = 64;
+constexpr int SITES_PER_WBLOCK_MAX = 4 * SPW_MAX;      // per 256-thread workgroup
 
 // `label` is read (neighbours) and written (own site, pending move) in the same launch: a neighbour
 // j with took[j] reads as `pa` whether or not its row has already stored the new label.
 __global__ void __launch_bounds__(256)
 k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int reduce_on,
-             int* label, int* __restrict__ cur_cost, MoveBatch b)
+             int* label, int* __restrict__ cur_cost, MoveBatch b, int spw)
 {
     const MoveCtx& c = b.c[blockIdx.y];
     const int alpha = c.alpha, t = c.t;
@@ -275,9 +279,9 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int reduce
     long long* __restrict__ acc = c.acc;
     const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
-    const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW;
+    const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * spw;
     const int i = s0 + lane;
-    const bool in = lane < SPW && i < g.n;
+    const bool in = lane < spw && i < g.n;
     const int pa = flags[C_PEND];
     int li = 0, cc = 0;
     if (in) {
@@ -354,7 +358,7 @@ k_move_setup(Graph g, const int* __restrict__ cost, int L, int potts, int reduce
 // COMPACT: sites still undecided when their row finishes are appended to the core list.
 template <bool COMPACT>
 __global__ void __launch_bounds__(256)
-k_reduce(Graph g, int L, MoveBatch b, int ROUNDS, int housekeep)
+k_reduce(Graph g, int L, MoveBatch b, int ROUNDS, int housekeep, int spw)
 {
     const MoveCtx& c = b.c[blockIdx.y];
     const int t = c.t;
@@ -371,11 +375,11 @@ k_reduce(Graph g, int L, MoveBatch b, int ROUNDS, int housekeep)
     // a phase.  Measured with the core in Z-curve order: 55-60 ms of solver time per LabelingStep instead of 20.
     const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
-    const int slot = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW + lane;
-    const int u = (lane < SPW && slot < g.n) ? (COMPACT ? g.order[slot] : slot) : -1;
+    const int slot = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * spw + lane;
+    const int u = (lane < spw && slot < g.n) ? (COMPACT ? g.order[slot] : slot) : -1;
     __shared__ int s_skip;                               // one evaluation per workgroup: C_ERROR may be raised meanwhile
     __shared__ int s_cnt, s_base;
-    __shared__ int s_list[SITES_PER_WBLOCK];
+    __shared__ int s_list[SITES_PER_WBLOCK_MAX];
     if (threadIdx.x == 0) { s_skip = move_is_skipped(flags, t, L) ? 1 : 0; s_cnt = 0; }
     __syncthreads();
     const bool skipped = s_skip != 0;
@@ -1222,7 +1226,7 @@ k_solve(Graph g, int L, MoveBatch b, int mslots, SolveParams sp)
 // workgroup to finish, the verdict of the move: accept iff the energy strictly decreases (:1259).
 __global__ void __launch_bounds__(256)
 k_delta(Graph g, const int* __restrict__ cost, int L, int potts,
-        const int* __restrict__ label, const int* __restrict__ cur_cost, MoveBatch b)
+        const int* __restrict__ label, const int* __restrict__ cur_cost, MoveBatch b, int spw)
 {
     const MoveCtx& c = b.c[blockIdx.y];
     const int alpha = c.alpha, t = c.t;
@@ -1240,12 +1244,12 @@ k_delta(Graph g, const int* __restrict__ cost, int L, int potts,
     // moving — from the end with the larger index.
     const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x % LPN;
-    const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * SPW;
+    const int s0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * spw;
     const int i = s0 + lane;
     long long mine = 0;
     int oi = 0;
     bool ti = false;
-    if (lane < SPW && i < g.n) {
+    if (lane < spw && i < g.n) {
         oi = label[i];
         ti = decided[i] == 1;
         took[i] = ti ? 1 : 0;
@@ -1629,7 +1633,15 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
 {
     const dim3 grid1((g.n + 255) / 256), blk(256);                          // one thread per site
     const dim3 grid((g.n + SITES_PER_BLOCK - 1) / SITES_PER_BLOCK);        // LPN lanes per site, 256 threads
-    const unsigned wblocks = (unsigned)((g.n + SITES_PER_WBLOCK - 1) / SITES_PER_WBLOCK);    // one lane per site first, then LPN lanes for the sites that need them
+    // whole-graph launches of a move: one lane per site first (spw sites per wave), then LPN lanes for the sites that need them
+    // (setup and reduction: a wave with many sites to walk serves them four at a time, so more sites per wave pay only once the
+    // launch would otherwise need several rounds of residency — 16 moves x 50 000 sites at 16 per wave are 50 000 waves, six
+    // rounds: loop of the reference's route at configs[4] 0.363 -> 0.349 s with 64; at 20 000 sites no difference.  0 = by size)
+    auto spw_for = [&](int count) {
+        if (w.batch_spw == 16 || w.batch_spw == 32 || w.batch_spw == 64) return w.batch_spw;
+        const long long site_moves = (long long)count * g.n;
+        return site_moves > (1ll << 19) ? 64 : site_moves > (1ll << 18) ? 32 : 16;
+    };
     ExpandStats stats = {};
     // the contexts: 0 = the work area's own buffers (and the global control words), k = w.ctx[k - 1]
     const int n_ctx = std::max(1, std::min(w.n_ctx, EXPAND_MAX_CTX));
@@ -1695,19 +1707,22 @@ hipError_t run_expansion(const Graph& g, const int* cost, int L, int potts, Expa
             c.warm = (w.saved_flow && cycle > 1) ? 1 : 0;
             if (count == 1) c.took_list = nullptr;             // a move alone: nobody walks the list
         }
-        const dim3 grid_w(wblocks, (unsigned)count);
+        const int spw = count > 1 ? spw_for(count) : SPW;
+        const int spw_d = count > 1 ? SPW_MAX : SPW;                  // k_delta: few sites move, every lane looks at one
+        const dim3 grid_w((unsigned)((g.n + 4 * spw - 1) / (4 * spw)), (unsigned)count);
+        const dim3 grid_d((unsigned)((g.n + 4 * spw_d - 1) / (4 * spw_d)), (unsigned)count);
         // (a batch right behind another batch's commit finds the contexts prepared by that commit)
         if (count > 1 && !prepared) { hipLaunchKernelGGL(k_batch_prep, dim3(1), dim3(64), 0, s, b, w.bctl); ++stats.launches; }
         prepared = count > 1;
-        hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, w.reduce_rounds > 0 ? 1 : 0, w.label, w.cur_cost, b);
+        hipLaunchKernelGGL(k_move_setup, grid_w, blk, 0, s, g, cost, L, potts, w.reduce_rounds > 0 ? 1 : 0, w.label, w.cur_cost, b, spw);
         if (w.reduce_launches > 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, 1);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, w.reduce_launches > 1 ? 0 : 1);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<false>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, 1, spw);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<true>), grid_w, blk, 0, s, g, L, b, w.reduce_rounds, w.reduce_launches > 1 ? 0 : 1, spw);
         if (count == 1 && w.comp_out && t0 < w.comp_moves)             // diagnostic: components of the core the reduction left
             hipLaunchKernelGGL(k_core_components, dim3(1), dim3(1024), 0, s, g, L, t0, w.decided, w.flags, w.comp_scratch,
                                w.comp_scratch + g.n, w.comp_out + 16 * (size_t)t0);
         hipLaunchKernelGGL(k_solve, dim3((unsigned)solve_grid, (unsigned)count), dim3(SOLVE_THREADS), solve_lds, s, g, L, b, mslots, sp);
-        hipLaunchKernelGGL(k_delta, grid_w, blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b);
+        hipLaunchKernelGGL(k_delta, grid_d, blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b, spw_d);
         if (count > 1) {
             hipLaunchKernelGGL(k_batch_check, dim3(32, (unsigned)count), blk, 0, s, g, cost, L, potts, w.label, w.cur_cost, b, w.bctl);
             hipLaunchKernelGGL(k_batch_commit, dim3(32), blk, 0, s, cost, L, w.label, w.cur_cost, b, w.bctl, w.h_batch_dev, all_flags, n_ctx);

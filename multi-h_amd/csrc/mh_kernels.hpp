@@ -221,6 +221,7 @@ struct ExpandWork {         // scratch owned by the engine
     int* h_batch = nullptr;       // 8   k_batch_commit's publication, pinned + device-mapped (host address) ...
     int* h_batch_dev = nullptr;   //     ... and its device address
     int batch_min_labels = 0;     // batches only when the label set has at least this many labels
+    int batch_spw = 0;            // sites per wave in a batch's setup and reduction launches: 16 / 32 / 64, 0 = by the size of the launch (a move alone: 16)
 };
 constexpr int EXPAND_MAX_CTX = 16;
 static_assert(sizeof(ExpandWork::ctx) / sizeof(ExpandWork::Ctx) == EXPAND_MAX_CTX - 1, "one context is the work area itself");

@@ -46,6 +46,7 @@ def restore(engine):
     yield
     engine.set_tuning(37, 16)
     engine.set_tuning(38, 16)
+    engine.set_tuning(39, 0)
 
 
 @pytest.mark.parametrize("n,planes,copies,spread,dlt,seed", [
@@ -107,6 +108,28 @@ def test_hundreds_of_labels_batches_pay_off_and_change_nothing(engine, synth, re
     assert b["batch_invalid"] < 0.15 * b["batch_committed"], b
     assert bat[4]["launches"] < 0.3 * seq[4]["launches"], (bat[4]["launches"], seq[4]["launches"])
     assert bat[4]["accepted"] == seq[4]["accepted"], "the same moves lower the energy in both forms"
+
+
+@pytest.mark.parametrize("spw", [16, 32, 64])
+def test_sites_per_wave_of_a_batchs_launches_change_nothing(engine, synth, oracle, restore, spw):
+    """Key 39: the whole-graph launches of a batch take 16, 32 or 64 sites per wavefront (by the size of the launch when 0): a
+    schedule, never a result — 146 labels on 4 000 sites and 35 on 3 000, cold and from a given labeling, against the oracle."""
+    for n, planes, copies, dlt, seed in ((4000, 5, 40, 100, 5), (3000, 4, 10, 20, 3)):
+        sc = synth.make_scene(n, planes, seed=seed)
+        _load(engine, sc)
+        rng = np.random.default_rng(seed)
+        H = _label_set(sc, rng, copies, 3e-3, dlt, engine)
+        engine.set_models(H)
+        cost = engine.data_cost()
+        init = rng.integers(0, H.shape[0] + 1, size=sc.n).astype(np.int32)
+        want = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM))
+        want_w = oracle.expand(cost, sc.hit_rowptr, sc.hit_col, oracle.potts(LAM), init_labels=init)
+        engine.set_tuning(39, spw)
+        got = _expand(engine, 16, 0)
+        got_w = _expand(engine, 16, 0, init)
+        assert np.array_equal(got[0], want[0]) and got[1] == want[1] and got[2] == want[2]
+        assert np.array_equal(got_w[0], want_w[0]) and got_w[1] == want_w[1] and got_w[2] == want_w[2]
+        assert got[3]["batch_committed"] > 0
 
 
 def test_the_loop_and_process_do_not_depend_on_the_batch_size(mh, engine_lib, synth):

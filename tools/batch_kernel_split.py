@@ -49,6 +49,7 @@ rng = np.random.default_rng(1)
 H = np.ascontiguousarray(np.concatenate([sc.H_true, sc.H_true[rng.integers(0, K, EXTRA // 3)] * (1 + rng.normal(0, 3e-3, (EXTRA // 3, 9))), e.get_models()]))
 e.set_neighbors_csr(sc.hit_rowptr, sc.hit_col)
 e.set_tuning(37, CTX)
+if "TUNE39" in os.environ: e.set_tuning(39, int(os.environ["TUNE39"]))     # sites per wave in a batch's setup / reduction launches
 for r in range(REPS):
     e.set_models(H)
     t0 = time.perf_counter()

@@ -33,6 +33,7 @@ while time.time() - t0 < budget:
     e.set_tuning(17, int(rng.choice([0, 1, 2, 2, 4])))        # passes of the dominance cascade inside the solver launch
     e.set_tuning(37, int(rng.choice([1, 2, 3, 5, 8, 16, 16])))     # r06: alpha-moves solved together ...
     e.set_tuning(38, int(rng.choice([0, 0, 4, 16])))               # ... from the first cycle on for label sets of at least this size
+    e.set_tuning(39, int(rng.choice([0, 16, 32, 64])))             # ... sites per wave in a batch's setup / reduction launches
     extra = int(rng.integers(0, 6)) if rng.integers(0, 3) else int(rng.integers(6, 60))      # (r06: now and then dozens of labels — the batches' case)
     H = np.concatenate([sc.H_true] + [sc.H_true[rng.integers(0, k)][None] * (1 + rng.normal(0, 3e-4, (1, 9))) for _ in range(extra)])
     e.set_models(H)
